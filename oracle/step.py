@@ -1,0 +1,65 @@
+"""oracle.step -- CPU restatement of the whole contrastive step (towers -> embeddings -> gather ->
+similarity -> loss).  TEST INFRASTRUCTURE ONLY (see oracle/ops.py)."""
+import torch
+
+from . import losses, ops, towers
+
+
+def univl_stage1(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads,
+                 gather=None, training=True):
+    """UnivlForVideoTextRetrieval stage-1 step, arch_type "clip", no MoCo
+    (prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:357-387,457-480;
+    univl_video_base.py:56-166,272-299).
+
+    image_data [B, n_clips*f, 3, H, W] with f = 1 frame per clip; P holds the reference's state_dict
+    (keys prefixed "module.").  `gather(t)` maps a local [b, D] tensor to the global [B_g, D]
+    (identity when None).  Returns dict(loss, l1_simi [T, V], text_embed, video_embed)."""
+    b, t = image_data.shape[:2]
+    frames_per_clip = t // n_clips
+    vis = towers.clip_vit(towers._sub(P, "module.img_encoder.visual."), image_data.flatten(0, 1), vit_heads, patch)
+    d = vis.shape[-1]
+    # mean over the frames of a clip (the grid is 1x1 and unmasked for the ViT encoder: clip_visual_encoder.py:86-94,
+    # univl_video_base.py:78-97), then L2 normalise each clip feature (:114)
+    clip_feat = vis.view(b * n_clips, frames_per_clip, d).mean(1)
+    video_embed = ops.l2_normalize(clip_feat)
+    _, pooled = towers.roberta_bert_encoder(towers._sub(P, "module.text_encoder."), input_ids, input_mask, bert_heads)
+    text_embed = ops.l2_normalize(pooled)
+    g_text = gather(text_embed) if gather else text_embed
+    g_video = gather(video_embed) if gather else video_embed
+    bg = g_text.shape[0]
+    # [V, n, D] x [D, T] -> [T, V, n]   (univl_video_ret.py:208-213)
+    simi = torch.matmul(g_video.view(bg, n_clips, d), g_text.t()).permute(2, 0, 1)
+    out = dict(text_embed=text_embed, video_embed=video_embed, l1_simi=torch.logsumexp(simi, dim=-1))
+    if training:
+        # tile every text row n times: [T*n, V*n]  (univl_video_ret.py:375-379)
+        mil = simi.unsqueeze(1).expand(bg, n_clips, bg, n_clips).reshape(bg * n_clips, bg * n_clips)
+        out["loss"] = losses.mil_nce(mil, bg, n_clips)
+    return out
+
+
+def m2_itc(P, image, text_ids, text_masks, heads, patch, gather=None):
+    """M2 two-level ITC step: towers pinned by VLMo.infer_image/infer_text, logits formula from
+    prj/M2_Encoder/m2_encoder.py:92-95, symmetric CE on both the cls and the cls_vlffn pairs
+    (loss form is this build's: see oracle.losses.clip_itc)."""
+    oi = towers.m2_infer_image(P, image, heads, patch)
+    ot = towers.m2_infer_text(P, text_ids, text_masks, heads)
+    g = gather if gather else (lambda x: x)
+    l1, logits = losses.clip_itc(g(oi["cls_feats"]), g(ot["cls_feats"]), P["logit_scale"])
+    l2, logits_vl = losses.clip_itc(g(oi["cls_vlffn_feats"]), g(ot["cls_vlffn_feats"]), P["logit_vl_scale"])
+    return dict(loss=0.5 * (l1 + l2), logits=logits, logits_vl=logits_vl, img=oi, txt=ot)
+
+
+class GatherWithGrad(torch.autograd.Function):
+    """Single-process model of GradientAllGather + gather_tensor(method="cat")
+    (antmmf/utils/distributed_utils.py:92-189) for W simulated ranks: forward concatenates the W
+    local shards; backward hands rank r the SUM over all ranks' gradients for its shard.  When every
+    rank computes the same global loss this is W x the single-process gradient."""
+
+    @staticmethod
+    def forward(ctx, world, *shards):
+        ctx.world = world
+        return torch.cat(shards, dim=0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (None,) + tuple(ctx.world * g for g in grad.chunk(ctx.world, dim=0))

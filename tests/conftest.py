@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ant-multi-modal-framework_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import torch
+
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = torch.load(os.path.join(GOLDEN, name), map_location="cpu")
+        return cache[name]
+
+    return load

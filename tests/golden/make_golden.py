@@ -1,0 +1,300 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by EXECUTING the reference implementation.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+The reference modules are imported unmodified through `_ref_loader`;
+parameters are filled by `weightgen` (name-keyed, deterministic) so that the fixtures hold only
+inputs and expected outputs / gradients.  Each fixture is a flat dict of float32/int64 tensors saved
+with torch.save (a few KB each).
+
+Fixtures and the reference symbols that produced them:
+  ops_clip_block.pt    ResidualAttentionBlock            antmmf/modules/vision/backbone/clip/model.py:227-256
+  ops_bert_layer.pt    BertLayer (+additive -10000 mask)  antmmf/modules/vision/backbone/clip/modeling_bert.py:253-270
+  ops_m2_layer.pt      torchscale EncoderLayer A/B branch prj/M2_Encoder/vlmo/torchscale/architecture/encoder.py:113-168
+  loss_mil_nce.pt      get_mil_nce_loss                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197
+  loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
+  e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
+  e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
+  gather_w2.pt         gather_tensor(back_gradient=True)  antmmf/utils/distributed_utils.py:92-189 (2-proc gloo)
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_loader as L  # noqa: E402
+import weightgen as W  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(4)
+
+
+def save(name, d):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            v = v.detach().clone().contiguous()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    torch.save(out, path)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} entries")
+
+
+def grads_of(module, prefix="grad."):
+    return {prefix + n: p.grad for n, p in module.named_parameters() if p.grad is not None}
+
+
+# ----------------------------------------------------------------------------- per-op fixtures
+def gen_clip_block():
+    vit = L.load_antmmf_core()["vit"]
+    blk = vit.ResidualAttentionBlock(128, 2)
+    W.fill_module_(blk)
+    x = W.data_tensor("clip_block.x", (17, 3, 128)).requires_grad_(True)  # LND
+    w = W.data_tensor("clip_block.w", (17, 3, 128))
+    y = blk(x)
+    (y * w).sum().backward()
+    d = dict(x=x, w=w, y=y, dx=x.grad)
+    d.update(grads_of(blk))
+    save("ops_clip_block.pt", d)
+
+
+def gen_bert_layer():
+    core = L.load_antmmf_core()
+    cfg = core["bert_cfg"].BertConfig(
+        vocab_size_or_config_json_file=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+        intermediate_size=512, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+        layer_norm_eps=1e-12)
+    layer = core["bert"].BertLayer(cfg)
+    W.fill_module_(layer)
+    x = W.data_tensor("bert_layer.x", (3, 12, 128)).requires_grad_(True)
+    w = W.data_tensor("bert_layer.w", (3, 12, 128))
+    lengths = torch.tensor([12, 7, 3])
+    mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
+    ext = (1.0 - mask[:, None, None, :].float()) * -10000.0
+    y = layer(x, ext, None)
+    (y * w).sum().backward()
+    d = dict(x=x, w=w, mask=mask, y=y, dx=x.grad)
+    d.update(grads_of(layer))
+    save("ops_bert_layer.pt", d)
+
+
+def gen_m2_layer():
+    L.load_m2()
+    from vlmo.torchscale.architecture.config import EncoderConfig
+    from vlmo.torchscale.architecture.encoder import EncoderLayer
+
+    args = EncoderConfig(multiway=True, encoder_embed_dim=128, encoder_attention_heads=2, encoder_ffn_embed_dim=512,
+                         encoder_layers=2, layernorm_embedding=False, normalize_output=True, no_output_layer=True,
+                         img_size=32, patch_size=8, vocab_size=100)
+    layer = EncoderLayer(args, depth=0)
+    W.fill_module_(layer)
+    d = {}
+    lengths = torch.tensor([12, 7, 3])
+    pad = ~(torch.arange(12)[None, :] < lengths[:, None])
+    for tag, split, padmask in (("A", -1, None), ("B", 0, pad)):
+        layer.zero_grad()
+        x = W.data_tensor(f"m2_layer.x{tag}", (3, 12, 128)).requires_grad_(True)
+        w = W.data_tensor(f"m2_layer.w{tag}", (3, 12, 128))
+        y, _ = layer(x, encoder_padding_mask=padmask, multiway_split_position=split)
+        (y * w).sum().backward()
+        d.update({f"{tag}.x": x, f"{tag}.w": w, f"{tag}.y": y, f"{tag}.dx": x.grad})
+        d.update(grads_of(layer, prefix=f"{tag}.grad."))
+    d["pad"] = pad
+    save("ops_m2_layer.pt", d)
+
+
+def gen_losses():
+    vtp = L.load_vtp("base_vtp")
+    Ret = vtp["ret"].UnivlForVideoTextRetrieval
+    d = {}
+    for (b, n, use_w) in [(4, 1, False), (8, 1, False), (6, 2, True), (3, 3, False), (5, 1, True)]:
+        s = W.data_tensor(f"milnce.{b}.{n}", (b * n, b * n), scale=1.5).requires_grad_(True)
+        wv = (W.data_tensor(f"milnce.w.{b}.{n}", (b,)).abs() + 0.1) if use_w else None
+        loss = Ret.get_mil_nce_loss(None, s, b, n, wv)
+        loss.backward()
+        key = f"b{b}n{n}"
+        d.update({f"{key}.sim": s, f"{key}.loss": loss, f"{key}.dsim": s.grad})
+        if wv is not None:
+            d[f"{key}.weight"] = wv
+    save("loss_mil_nce.pt", d)
+
+    d = {}
+    moco = vtp["moco"].MocoUtils
+
+    class _T:
+        T = 0.05
+
+    pos = W.data_tensor("moco.pos", (6, 2), 0.5).requires_grad_(True)
+    neg = W.data_tensor("moco.neg", (6, 40), 0.5).requires_grad_(True)
+    loss = moco.moco_loss(_T, pos, neg)
+    loss.backward()
+    d.update({"moco.pos": pos, "moco.neg": neg, "moco.loss": loss, "moco.dpos": pos.grad, "moco.dneg": neg.grad})
+    dm = L.load_vtp("dmae_vtp")["dmae"]
+    for name, cls in (("crossen", dm.CrossEn), ("negnce", dm.NegNCE)):
+        s = W.data_tensor(f"{name}.sim", (7, 7), 0.02).requires_grad_(True)
+        loss = cls()(s)
+        loss.backward()
+        d.update({f"{name}.sim": s, f"{name}.loss": loss, f"{name}.dsim": s.grad})
+    save("loss_misc.pt", d)
+    L.load_vtp("base_vtp")
+
+
+# ----------------------------------------------------------------------------- end-to-end fixtures
+TINY_CLIP_CFG = dict(
+    training_head_type="video_text_retrieval", arch_type="clip", training_stage="stage1", with_moco=False,
+    with_cross_encoder=False, hidden_size=128,
+    image_encoder=dict(type="VitImageEncoder", params=dict(
+        model_name="ViT-tiny", input_resolution=32, patch_size=8, width=128, layers=2, out_dim=128, pretrained=False)),
+    text_encoder=dict(type="RobertBertEncoder", params=dict(
+        pretrained=False, vocab_size=300, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+        num_attention_heads=2, max_position_embeddings=40, hidden_dropout_prob=0.0,
+        attention_probs_dropout_prob=0.0, out_dim=128, is_proj=True)),
+)
+
+
+def tiny_clip_batch(bsz, n_clips, seq=12, tag="e2e"):
+    img = W.data_tensor(f"{tag}.image", (bsz, n_clips, 3, 32, 32))
+    ids = W.data_ints(f"{tag}.ids", (bsz, seq), 1, 300)
+    lengths = W.data_ints(f"{tag}.len", (bsz,), 3, seq + 1)
+    lengths[0] = seq
+    mask = (torch.arange(seq)[None, :] < lengths[:, None]).long()
+    ids = ids * mask
+    ids[:, 0] = 101
+    return dict(
+        image=dict(image_data=img, image_pad_mask=torch.zeros(bsz, n_clips, 32, 32, dtype=torch.bool),
+                   image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz),
+        caption=dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids.clone()),
+    )
+
+
+def gen_e2e_clip():
+    vtp = L.load_vtp("base_vtp")
+    d = {}
+    for tag, bsz, n_clips in (("b4n1", 4, 1), ("b3n2", 3, 2)):
+        model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(TINY_CLIP_CFG))
+        W.fill_module_(model)
+        model.train()
+        batch = tiny_clip_batch(bsz, n_clips, tag=tag)
+        out = model(batch["image"], batch["caption"])
+        loss = out["losses"]["level1_similarity_loss"]
+        loss.backward()
+        cap_input, vis_input, _, _ = model.module.get_l2_input(batch["image"], batch["caption"])
+        d.update({
+            f"{tag}.image_data": batch["image"]["image_data"],
+            f"{tag}.input_ids": batch["caption"]["caption_input_ids"],
+            f"{tag}.input_mask": batch["caption"]["caption_input_mask"],
+            f"{tag}.loss": loss, f"{tag}.l1_simi": out["l1_simi"],
+            f"{tag}.text_embed": cap_input[2], f"{tag}.video_embed": vis_input[2],
+        })
+        full = ["module.img_encoder.visual.conv1.weight", "module.text_encoder.text_projection",
+                "module.img_encoder.visual.proj", "module.img_encoder.visual.class_embedding",
+                "module.img_encoder.visual.transformer.resblocks.0.attn.in_proj_bias",
+                "module.text_encoder.encoder.layer.1.attention.self.query.bias",
+                "module.text_encoder.embeddings.LayerNorm.weight"]
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            d[f"{tag}.gnorm.{n}"] = p.grad.norm()
+            if n in full:
+                d[f"{tag}.grad.{n}"] = p.grad
+    save("e2e_clip_arch.pt", d)
+
+
+TINY_M2 = dict(beit_version="base", encoder_embed_dim=128, out_embed_dim=64, encoder_layers=2, beit3_vl_layers=1,
+               image_size=32, patch_size=8, vocab_size=300, max_text_len=12, encoder_attention_heads=2)
+
+
+def m2_config():
+    m2 = L.load_m2()
+    src = m2["cfg_src"]
+    body = src[src.index("def config():"):]
+    end = body.index("\n@ex.named_config") if "\n@ex.named_config" in body else len(body)
+    ns = {"_loss_names": m2["cfgmod"]._loss_names}
+    exec(body[:end].replace("def config():", "def config():\n    pass", 1) + "\n    return dict(locals())\n", ns)
+    cfg = ns["config"]()
+    cfg.update(TINY_M2)
+    cfg.update(loss_names=m2["cfgmod"]._loss_names({"itc": 1}), test_only=True, load_path="",
+               tokenizer=m2["root"] + "/vlmo/tokenizer", tokenizer_type="GLMChineseTokenizer")
+    return cfg
+
+
+def gen_e2e_m2():
+    m2 = L.load_m2()
+    cfg = m2_config()
+    model = m2["VLMo"](cfg)
+    W.fill_module_(model)
+    model.eval()  # dropout is 0 everywhere in the M2 configs; eval == train numerically
+    img = (W.data_tensor("m2.image", (3, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1)
+    ids = W.data_ints("m2.ids", (3, 12), 1, 300)
+    lengths = torch.tensor([12, 5, 8])
+    mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
+    ids = ids * mask
+    img.requires_grad_(False)
+    out_i = model.infer_image({"image": [img]})
+    out_t = model.infer_text({"text_ids": ids, "text_labels": ids, "text_masks": mask})
+    ls, lvs = model.logit_scale.exp(), model.logit_vl_scale.exp()
+    logits = ls * out_i["cls_feats"] @ out_t["cls_feats"].t()
+    logits_vl = lvs * out_i["cls_vlffn_feats"] @ out_t["cls_vlffn_feats"].t()
+    # scalar used only to pin gradients of the towers (the reference ships no M2 training loss)
+    pin = (logits * W.data_tensor("m2.wl", (3, 3))).sum() + (logits_vl * W.data_tensor("m2.wvl", (3, 3))).sum()
+    pin.backward()
+    d = {"image": img, "text_ids": ids, "text_masks": mask,
+         "img.cls_feats": out_i["cls_feats"], "img.cls_vlffn_feats": out_i["cls_vlffn_feats"],
+         "img.image_feats": out_i["image_feats"],
+         "txt.cls_feats": out_t["cls_feats"], "txt.cls_vlffn_feats": out_t["cls_vlffn_feats"],
+         "logits": logits, "logits_vl": logits_vl, "pin": pin}
+    full = ["backbone.vision_embed.proj.weight", "itc_image_proj.fc.weight", "itc_vl_text_proj.fc.weight",
+            "backbone.encoder.layers.0.self_attn.q_proj.B.bias", "backbone_vl.layers.0.ffn.A.ffn_layernorm.weight",
+            "logit_scale"]
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        d[f"gnorm.{n}"] = p.grad.norm()
+        if n in full:
+            d[f"grad.{n}"] = p.grad
+    d["param_names"] = [n for n, _ in model.named_parameters()]
+    save("e2e_m2.pt", d)
+
+
+# ----------------------------------------------------------------------------- distributed fixture
+def _gather_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    du = L.load_antmmf_core()["du"]
+    full_t = W.data_tensor("gather.t", (world * 3, 8))
+    full_v = W.data_tensor("gather.v", (world * 3, 8))
+    t = full_t[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    v = full_v[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    gt = du.gather_tensor(t, method="cat", back_gradient=True, pad_tensors=True)
+    gv = du.gather_tensor(v, method="cat", back_gradient=True, pad_tensors=True)
+    Ret = L.load_vtp("base_vtp")["ret"].UnivlForVideoTextRetrieval
+    loss = Ret.get_mil_nce_loss(None, gt @ gv.t(), world * 3, 1)
+    loss.backward()
+    ret[rank] = dict(loss=loss.detach(), dt=t.grad.clone(), dv=v.grad.clone())
+    dist.destroy_process_group()
+
+
+def gen_gather():
+    import torch.multiprocessing as mp
+
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, 29611, ret), nprocs=world, join=True)
+    d = {"world": world}
+    for r in range(world):
+        for k, v in ret[r].items():
+            d[f"rank{r}.{k}"] = v
+    save("gather_w2.pt", d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "losses", "e2e_clip", "e2e_m2", "gather"]
+    fns = dict(clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+               e2e_clip=gen_e2e_clip, e2e_m2=gen_e2e_m2, gather=gen_gather)
+    for w in which:
+        fns[w]()

@@ -1,0 +1,120 @@
+"""Shapes of the tiny models behind e2e_clip_arch.pt / e2e_m2.pt, and their name-keyed weights.
+Shared by the oracle tests (CPU) and the HIP parity tests (GPU).  Shapes mirror TINY_CLIP_CFG /
+TINY_M2 in make_golden.py."""
+import torch
+
+import weightgen as W
+
+CLIP_ARCH = dict(width=128, layers=2, heads=2, patch=8, res=32, out_dim=128,
+                 vocab=300, hidden=128, inter=512, bert_layers=2, bert_heads=2, max_pos=40)
+
+
+def clip_arch_shapes(c=CLIP_ARCH):
+    d, s = c["width"], {}
+    v = "module.img_encoder.visual."
+    s[v + "class_embedding"] = (d,)
+    s[v + "positional_embedding"] = ((c["res"] // c["patch"]) ** 2 + 1, d)
+    s[v + "proj"] = (d, c["out_dim"])
+    s[v + "conv1.weight"] = (d, 3, c["patch"], c["patch"])
+    for ln in ("ln_pre", "ln_post"):
+        s[v + ln + ".weight"] = (d,)
+        s[v + ln + ".bias"] = (d,)
+    for i in range(c["layers"]):
+        b = v + f"transformer.resblocks.{i}."
+        s[b + "attn.in_proj_weight"] = (3 * d, d)
+        s[b + "attn.in_proj_bias"] = (3 * d,)
+        s[b + "attn.out_proj.weight"] = (d, d)
+        s[b + "attn.out_proj.bias"] = (d,)
+        for ln in ("ln_1", "ln_2"):
+            s[b + ln + ".weight"] = (d,)
+            s[b + ln + ".bias"] = (d,)
+        s[b + "mlp.c_fc.weight"] = (4 * d, d)
+        s[b + "mlp.c_fc.bias"] = (4 * d,)
+        s[b + "mlp.c_proj.weight"] = (d, 4 * d)
+        s[b + "mlp.c_proj.bias"] = (d,)
+    t, h = "module.text_encoder.", c["hidden"]
+    s[t + "text_projection"] = (h, c["out_dim"])
+    s[t + "embeddings.word_embeddings.weight"] = (c["vocab"], h)
+    s[t + "embeddings.position_embeddings.weight"] = (c["max_pos"], h)
+    s[t + "embeddings.token_type_embeddings.weight"] = (2, h)
+    s[t + "embeddings.LayerNorm.weight"] = (h,)
+    s[t + "embeddings.LayerNorm.bias"] = (h,)
+    for i in range(c["bert_layers"]):
+        b = t + f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            s[b + f"attention.self.{nm}.weight"] = (h, h)
+            s[b + f"attention.self.{nm}.bias"] = (h,)
+        s[b + "attention.output.dense.weight"] = (h, h)
+        s[b + "attention.output.dense.bias"] = (h,)
+        s[b + "attention.output.LayerNorm.weight"] = (h,)
+        s[b + "attention.output.LayerNorm.bias"] = (h,)
+        s[b + "intermediate.dense.weight"] = (c["inter"], h)
+        s[b + "intermediate.dense.bias"] = (c["inter"],)
+        s[b + "output.dense.weight"] = (h, c["inter"])
+        s[b + "output.dense.bias"] = (h,)
+        s[b + "output.LayerNorm.weight"] = (h,)
+        s[b + "output.LayerNorm.bias"] = (h,)
+    # BertModel2 also owns a pooler (unused by the clip arch) -- it gets no gradient and is not needed here
+    return s
+
+
+def clip_arch_params(requires_grad=False):
+    P = W.fill_dict(clip_arch_shapes())
+    if requires_grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    return P
+
+
+M2 = dict(d=128, heads=2, layers=2, vl_layers=1, patch=8, res=32, vocab=300, out=64, max_src_pos=1024)
+
+
+def m2_shapes(c=M2):
+    d, s = c["d"], {}
+    s["logit_scale"] = ()
+    s["logit_vl_scale"] = ()
+    s["backbone.text_embed.weight"] = (c["vocab"], d)
+    s["backbone.vision_embed.mask_token"] = (1, 1, d)
+    s["backbone.vision_embed.cls_token"] = (1, 1, d)
+    s["backbone.vision_embed.proj.weight"] = (d, 3, c["patch"], c["patch"])
+    s["backbone.vision_embed.proj.bias"] = (d,)
+    s["backbone.encoder.embed_positions.A.weight"] = ((c["res"] // c["patch"]) ** 2 + 1 + 2, d)
+    s["backbone.encoder.embed_positions.B.weight"] = (c["max_src_pos"], d)
+
+    def enc(prefix, nl):
+        for i in range(nl):
+            b = prefix + f"layers.{i}."
+            for br in "AB":
+                for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                    s[b + f"self_attn.{nm}.{br}.weight"] = (d, d)
+                    s[b + f"self_attn.{nm}.{br}.bias"] = (d,)
+                for ln in ("self_attn.inner_attn_ln", "self_attn_layer_norm", "final_layer_norm"):
+                    s[b + f"{ln}.{br}.weight"] = (d,)
+                    s[b + f"{ln}.{br}.bias"] = (d,)
+                s[b + f"ffn.{br}.fc1.weight"] = (4 * d, d)
+                s[b + f"ffn.{br}.fc1.bias"] = (4 * d,)
+                s[b + f"ffn.{br}.fc2.weight"] = (d, 4 * d)
+                s[b + f"ffn.{br}.fc2.bias"] = (d,)
+                s[b + f"ffn.{br}.ffn_layernorm.weight"] = (4 * d,)
+                s[b + f"ffn.{br}.ffn_layernorm.bias"] = (4 * d,)
+        for br in "AB":
+            s[prefix + f"layer_norm.{br}.weight"] = (d,)
+            s[prefix + f"layer_norm.{br}.bias"] = (d,)
+
+    enc("backbone.encoder.", c["layers"])
+    enc("backbone_vl.", c["vl_layers"])
+    for h in ("itc_text_proj", "itc_image_proj", "itc_vl_text_proj", "itc_vl_image_proj"):
+        s[h + ".fc.weight"] = (c["out"], d)
+    return s
+
+
+def m2_params(expected_names=None, requires_grad=False):
+    shapes = m2_shapes()
+    if expected_names is not None:
+        missing = [n for n in expected_names if n not in shapes and not n.startswith(("norm.", "pooler."))]
+        assert not missing, f"tiny M2 shape table is missing reference parameters: {missing[:8]}"
+    P = W.fill_dict(shapes)
+    if requires_grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    return P

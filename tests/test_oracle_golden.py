@@ -1,0 +1,165 @@
+"""Pin the CPU oracle against fixtures produced by executing the reference (tests/golden/make_golden.py)."""
+import torch
+
+import weightgen as W
+from oracle import losses, ops, step, towers
+
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    """fp32 parity: rtol elementwise, atol scaled by the tensor's own magnitude (sum-order noise)."""
+    scale = max(1.0, float(b.detach().abs().max())) if b.numel() else 1.0
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol * scale)
+
+
+def params_like(fix, prefix, salt=0):
+    """Re-create the weights make_golden.py used: name-keyed fill, shapes taken from the stored grads."""
+    out = {}
+    for k, v in fix.items():
+        if k.startswith(prefix):
+            name = k[len(prefix):]
+            out[name] = W.tensor_for(name, v.shape, salt).requires_grad_(True)
+    return out
+
+
+def test_clip_block(golden):
+    g = golden("ops_clip_block.pt")
+    P = params_like(g, "grad.")
+    x = g["x"].clone().requires_grad_(True)
+    y = towers.clip_block(P, x.transpose(0, 1), heads=2).transpose(0, 1)  # fixture is LND
+    close(y, g["y"])
+    (y * g["w"]).sum().backward()
+    close(x.grad, g["dx"], 1e-4, 1e-5)
+    for n, p in P.items():
+        close(p.grad, g["grad." + n], 1e-4, 1e-5)
+
+
+def test_bert_layer(golden):
+    g = golden("ops_bert_layer.pt")
+    P = params_like(g, "grad.")
+    x = g["x"].clone().requires_grad_(True)
+    y = towers.bert_layer(P, x, towers.bert_key_bias(g["mask"]), heads=2)
+    close(y, g["y"])
+    (y * g["w"]).sum().backward()
+    close(x.grad, g["dx"], 1e-4, 1e-5)
+    for n, p in P.items():
+        close(p.grad, g["grad." + n], 1e-4, 1e-5)
+
+
+def test_m2_layer(golden):
+    g = golden("ops_m2_layer.pt")
+    for br, pad in (("A", None), ("B", g["pad"])):
+        P = params_like(g, "A.grad.")  # A.grad.* lists every parameter that got a grad in the A pass
+        P.update(params_like(g, "B.grad."))
+        x = g[f"{br}.x"].clone().requires_grad_(True)
+        y = towers.m2_layer(P, x, br, heads=2, pad=pad)
+        close(y, g[f"{br}.y"])
+        (y * g[f"{br}.w"]).sum().backward()
+        close(x.grad, g[f"{br}.dx"], 1e-4, 1e-5)
+        for n, p in P.items():
+            if f"{br}.grad.{n}" in g and p.grad is not None:
+                close(p.grad, g[f"{br}.grad.{n}"], 1e-4, 1e-5)
+
+
+def test_mil_nce(golden):
+    g = golden("loss_mil_nce.pt")
+    for key in sorted({k.split(".")[0] for k in g}):
+        b, n = int(key[1:key.index("n")]), int(key[key.index("n") + 1:])
+        s = g[f"{key}.sim"].clone().requires_grad_(True)
+        loss = losses.mil_nce(s, b, n, g.get(f"{key}.weight"))
+        close(loss, g[f"{key}.loss"])
+        loss.backward()
+        close(s.grad, g[f"{key}.dsim"], 1e-4, 1e-6)
+
+
+def test_misc_losses(golden):
+    g = golden("loss_misc.pt")
+    pos, neg = g["moco.pos"].clone().requires_grad_(True), g["moco.neg"].clone().requires_grad_(True)
+    loss = losses.moco(pos, neg, 0.05)
+    close(loss, g["moco.loss"])
+    loss.backward()
+    close(pos.grad, g["moco.dpos"], 1e-4, 1e-6)
+    close(neg.grad, g["moco.dneg"], 1e-4, 1e-6)
+    for name, fn in (("crossen", losses.cross_en), ("negnce", losses.neg_nce)):
+        s = g[f"{name}.sim"].clone().requires_grad_(True)
+        loss = fn(s)
+        close(loss, g[f"{name}.loss"])
+        loss.backward()
+        close(s.grad, g[f"{name}.dsim"], 1e-4, 1e-6)
+
+
+def tiny_clip_params(g, tag):
+    shapes = {}
+    P = {}
+    for k, v in g.items():
+        if k.startswith(f"{tag}.gnorm."):
+            P[k[len(f"{tag}.gnorm."):]] = None
+    return P
+
+
+def test_e2e_clip_arch(golden):
+    import tiny_models
+
+    g = golden("e2e_clip_arch.pt")
+    for tag, n_clips in (("b4n1", 1), ("b3n2", 2)):
+        P = tiny_models.clip_arch_params(requires_grad=True)
+        out = step.univl_stage1(P, g[f"{tag}.image_data"], g[f"{tag}.input_ids"], g[f"{tag}.input_mask"],
+                                n_clips, vit_heads=2, patch=8, bert_heads=2)
+        close(out["text_embed"], g[f"{tag}.text_embed"], 1e-4, 1e-6)
+        close(out["video_embed"], g[f"{tag}.video_embed"], 1e-4, 1e-6)
+        close(out["l1_simi"], g[f"{tag}.l1_simi"], 1e-4, 1e-6)
+        close(out["loss"], g[f"{tag}.loss"], 1e-5, 1e-6)
+        out["loss"].backward()
+        checked = 0
+        for n, p in P.items():
+            if f"{tag}.gnorm.{n}" in g:
+                close(p.grad.norm(), g[f"{tag}.gnorm.{n}"], 2e-3, 1e-7)
+                checked += 1
+            if f"{tag}.grad.{n}" in g:
+                close(p.grad, g[f"{tag}.grad.{n}"], 2e-3, 1e-7)
+        assert checked > 50
+
+
+def test_e2e_m2(golden):
+    import tiny_models
+
+    g = golden("e2e_m2.pt")
+    P = tiny_models.m2_params(g["param_names"], requires_grad=True)
+    oi = towers.m2_infer_image(P, g["image"], heads=2, patch=8)
+    ot = towers.m2_infer_text(P, g["text_ids"], g["text_masks"], heads=2)
+    close(oi["image_feats"], g["img.image_feats"], 1e-4, 1e-5)
+    for k in ("cls_feats", "cls_vlffn_feats"):
+        close(oi[k], g[f"img.{k}"], 1e-4, 1e-6)
+        close(ot[k], g[f"txt.{k}"], 1e-4, 1e-6)
+    logits = P["logit_scale"].exp() * oi["cls_feats"] @ ot["cls_feats"].t()
+    logits_vl = P["logit_vl_scale"].exp() * oi["cls_vlffn_feats"] @ ot["cls_vlffn_feats"].t()
+    close(logits, g["logits"], 1e-4, 1e-5)
+    pin = (logits * W.data_tensor("m2.wl", (3, 3))).sum() + (logits_vl * W.data_tensor("m2.wvl", (3, 3))).sum()
+    close(pin, g["pin"], 1e-4, 1e-5)
+    pin.backward()
+    checked = 0
+    for n, p in P.items():
+        if f"gnorm.{n}" in g:
+            close(p.grad.norm(), g[f"gnorm.{n}"], 2e-3, 1e-6)
+            checked += 1
+        if f"grad.{n}" in g:
+            close(p.grad, g[f"grad.{n}"], 2e-3, 1e-6)
+    assert checked > 50
+
+
+def test_gather_scaling(golden):
+    """W-rank gather: loss identical on every rank, local grad == W x single-process grad slice
+    (antmmf/utils/distributed_utils.py:98-116)."""
+    g = golden("gather_w2.pt")
+    world = g["world"]
+    t = [W.data_tensor("gather.t", (world * 3, 8))[r * 3:(r + 1) * 3].clone().requires_grad_(True) for r in range(world)]
+    v = [W.data_tensor("gather.v", (world * 3, 8))[r * 3:(r + 1) * 3].clone().requires_grad_(True) for r in range(world)]
+    gt = step.GatherWithGrad.apply(world, *t)
+    gv = step.GatherWithGrad.apply(world, *v)
+    loss = losses.mil_nce(gt @ gv.t(), world * 3, 1)
+    loss.backward()
+    for r in range(world):
+        close(loss, g[f"rank{r}.loss"])
+        close(t[r].grad, g[f"rank{r}.dt"], 1e-4, 1e-6)
+        close(v[r].grad, g[f"rank{r}.dv"], 1e-4, 1e-6)
