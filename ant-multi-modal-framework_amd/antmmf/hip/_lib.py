@@ -1,0 +1,96 @@
+"""ctypes binding of libantmmf_hip.so (C ABI: include/antmmf_hip.h).
+
+The library is the product: if it cannot be loaded this module raises -- there is no eager / CPU
+fallback for the hot path.  `ANTMMF_HIP_LIB` may point at another build of the same ABI (the unit
+tests use it to run the kernels' CPU lane emulation, tests/emu, whose `antmmf_backend()` is 0 and
+which only accepts host tensors).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libantmmf_hip.so"))
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
+ACT_IDS = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "quick_gelu": 2, "relu": 3}
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+_SIGNATURES = {
+    "antmmf_backend": [],
+    "antmmf_abi_version": [],
+    "antmmf_layernorm_fwd": [P, P, P, P, P, P, L, I, F, I, P],
+    "antmmf_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, P],
+    "antmmf_act_fwd": [P, P, L, I, I, P],
+    "antmmf_act_bwd": [P, P, P, L, I, I, P],
+    "antmmf_l2norm_fwd": [P, P, P, L, I, F, I, I, P],
+    "antmmf_l2norm_bwd": [P, P, P, P, L, I, I, I, P],
+    "antmmf_colsum": [P, P, L, I, L, I, P],
+    "antmmf_transpose_bf16": [P, P, I, I, P],
+    "antmmf_cast_f32_bf16": [P, P, L, P],
+    "antmmf_patchify": [P, P, I, I, I, I, I, I, F, F, I, P],
+    "antmmf_assemble_tokens": [P, P, P, P, P, L, I, I, P],
+    "antmmf_split_tokens": [P, P, L, I, I, P],
+    "antmmf_embed_gather": [P, P, P, P, P, P, P, L, I, I, I, P],
+    "antmmf_embed_scatter_add": [P, P, P, P, L, I, I, I, P],
+    "antmmf_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, F, P],
+    "antmmf_sumsq": [P, P, L, P],
+    "antmmf_gemm_bf16": [P, P, P, I, I, I, L, L, L, I, I, I, F, P, I, P, L, P, L, P, L, I, I, P],
+    "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, P],
+    "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
+    "antmmf_milnce_fwd": [P, P, I, I, I, I, I, P, P, P],
+    "antmmf_milnce_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P],
+    "antmmf_softmax_ce_fwd": [P, I, I, I, P, F, P, P, P],
+    "antmmf_softmax_ce_bwd": [P, P, P, I, I, I, P, F, P, P, I, P],
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+_backend = None
+
+
+def lib_path():
+    return os.environ.get("ANTMMF_HIP_LIB") or DEFAULT_LIB
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises HipLibraryError if the extension is missing."""
+    global _lib, _backend
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.isfile(path):
+        raise HipLibraryError(
+            f"libantmmf_hip.so not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C ant-multi-modal-framework_amd/csrc`). The HIP path has no fallback.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {path}: {e}") from e
+    for name, args in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{path} does not export {name}") from e
+        fn.argtypes = args
+        fn.restype = c_int
+    _lib = lib
+    _backend = lib.antmmf_backend()
+    return lib
+
+
+def backend():
+    """1 = gfx950 device library, 0 = CPU lane emulator."""
+    load()
+    return _backend
+
+
+def reset_for_tests():
+    global _lib, _backend
+    _lib = None
+    _backend = None

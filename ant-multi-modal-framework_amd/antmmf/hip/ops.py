@@ -1,0 +1,325 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see antmmf.hip.functional).
+
+Every wrapper validates device / dtype / layout, passes raw pointers + torch's current HIP stream and
+raises on a non-zero return code.  PyTorch is used for memory and streams only.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, BF16, F32
+
+
+def _stream():
+    if _lib.backend() == 1:
+        return torch.cuda.current_stream().cuda_stream
+    return 0
+
+
+def _dev_ok(*ts):
+    want_cuda = _lib.backend() == 1
+    for t in ts:
+        if t is None:
+            continue
+        if t.is_cuda != want_cuda:
+            raise RuntimeError(
+                "antmmf.hip: tensors must live on the MI355X (cuda) for libantmmf_hip.so"
+                if want_cuda else "antmmf.hip: the CPU lane emulator only accepts host tensors")
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"antmmf.hip: unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rc(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _c(t, name):
+    if not t.is_contiguous():
+        raise ValueError(f"antmmf.hip: {name} must be contiguous")
+    return t
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise TypeError(f"antmmf.hip: {name} must be float32")
+    return t
+
+
+# ------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
+    _dev_ok(x, gamma, beta)
+    _c(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    _rc(_lib.load().antmmf_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, float(eps),
+                                         _dt(x), _stream()), "antmmf_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None):
+    """dgamma / dbeta (fp32) are accumulated in place when given."""
+    _dev_ok(dy, x, mean, rstd, gamma, dgamma, dbeta, dres)
+    _c(dy, "dy"); _c(x, "x")
+    if dres is not None:
+        _c(dres, "dres")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty_like(x)
+    _rc(_lib.load().antmmf_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
+                                         _p(dbeta), rows, cols, _dt(x), _stream()), "antmmf_layernorm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------ activations
+def act_fwd(u, act):
+    _dev_ok(u); _c(u, "u")
+    g = torch.empty_like(u)
+    _rc(_lib.load().antmmf_act_fwd(_p(u), _p(g), u.numel(), ACT_IDS[act], _dt(u), _stream()), "antmmf_act_fwd")
+    return g
+
+
+def act_bwd(dg, u, act):
+    _dev_ok(dg, u); _c(dg, "dg"); _c(u, "u")
+    du = torch.empty_like(u)
+    _rc(_lib.load().antmmf_act_bwd(_p(dg), _p(u), _p(du), u.numel(), ACT_IDS[act], _dt(u), _stream()), "antmmf_act_bwd")
+    return du
+
+
+# ------------------------------------------------------------------------------ L2 normalise
+def l2norm_fwd(x, eps=1e-12, out_dtype=None):
+    _dev_ok(x); _c(x, "x")
+    out_dtype = out_dtype or x.dtype
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _rc(_lib.load().antmmf_l2norm_fwd(_p(x), _p(y), _p(inv), rows, cols, float(eps), _dt(x), _dt(y), _stream()),
+        "antmmf_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv, in_dtype):
+    _dev_ok(dy, y, inv); _c(dy, "dy"); _c(y, "y")
+    cols = y.shape[-1]
+    rows = y.numel() // cols
+    dx = torch.empty(y.shape, dtype=in_dtype, device=y.device)
+    _rc(_lib.load().antmmf_l2norm_bwd(_p(dy), _p(y), _p(inv), _p(dx), rows, cols, _dt(dx), _dt(y), _stream()),
+        "antmmf_l2norm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------ small movers
+def colsum_(out, x2d):
+    """out[c] += sum_r x2d[r, c]; x2d may be a row-strided 2-D view (stride(1) == 1)."""
+    _dev_ok(out, x2d); _f32(out, "out")
+    if x2d.dim() != 2 or x2d.stride(1) != 1:
+        raise ValueError("colsum_: x2d must be 2-D with unit inner stride")
+    _rc(_lib.load().antmmf_colsum(_p(x2d), _p(out), x2d.shape[0], x2d.shape[1], x2d.stride(0), _dt(x2d), _stream()),
+        "antmmf_colsum")
+    return out
+
+
+def transpose_bf16(x):
+    _dev_ok(x); _c(x, "x")
+    assert x.dim() == 2 and x.dtype == torch.bfloat16
+    out = torch.empty(x.shape[1], x.shape[0], dtype=x.dtype, device=x.device)
+    _rc(_lib.load().antmmf_transpose_bf16(_p(x), _p(out), x.shape[0], x.shape[1], _stream()), "antmmf_transpose_bf16")
+    return out
+
+
+def cast_bf16(x, out=None):
+    _dev_ok(x, out); _c(x, "x"); _f32(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _rc(_lib.load().antmmf_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "antmmf_cast_f32_bf16")
+    return out
+
+
+def patchify(img, patch, kpad=None, shift=0.0, scale=1.0):
+    _dev_ok(img); _c(img, "img")
+    b, c, h, w = img.shape
+    kk = c * patch * patch
+    kpad = kpad or ((kk + 63) // 64) * 64
+    out = torch.empty(b * (h // patch) * (w // patch), kpad, dtype=torch.bfloat16, device=img.device)
+    _rc(_lib.load().antmmf_patchify(_p(img), _p(out), b, c, h, w, patch, kpad, float(shift), float(scale), _dt(img),
+                                    _stream()), "antmmf_patchify")
+    return out
+
+
+def assemble_tokens(patch_tokens, cls, pos, bias, batch, grid):
+    _dev_ok(patch_tokens, cls, pos, bias); _c(patch_tokens, "patch_tokens")
+    _f32(cls, "cls"); _f32(pos, "pos"); _f32(bias, "bias")
+    d = patch_tokens.shape[-1]
+    out = torch.empty(batch, grid + 1, d, dtype=torch.bfloat16, device=patch_tokens.device)
+    _rc(_lib.load().antmmf_assemble_tokens(_p(patch_tokens), _p(cls), _p(pos), _p(bias), _p(out), batch, grid, d,
+                                           _stream()), "antmmf_assemble_tokens")
+    return out
+
+
+def split_tokens(dx):
+    _dev_ok(dx); _c(dx, "dx")
+    b, n, d = dx.shape
+    out = torch.empty(b * (n - 1), d, dtype=torch.bfloat16, device=dx.device)
+    _rc(_lib.load().antmmf_split_tokens(_p(dx), _p(out), b, n - 1, d, _stream()), "antmmf_split_tokens")
+    return out
+
+
+def embed_gather(ids, word, pos=None, type_table=None, type_ids=None, zero_rows=None, pos_offset=0):
+    _dev_ok(ids, word, pos, type_table, type_ids, zero_rows); _c(ids, "ids")
+    assert ids.dtype == torch.int64
+    b, seq = ids.shape
+    d = word.shape[1]
+    out = torch.empty(b, seq, d, dtype=torch.bfloat16, device=word.device)
+    if zero_rows is not None:
+        assert zero_rows.dtype == torch.uint8 and zero_rows.is_contiguous()
+    _rc(_lib.load().antmmf_embed_gather(_p(ids), _p(word), _p(pos), _p(type_table), _p(type_ids), _p(zero_rows), _p(out),
+                                        b * seq, seq, d, pos_offset, _stream()), "antmmf_embed_gather")
+    return out
+
+
+def embed_scatter_add_(dtable, dx, idx=None, skip_rows=None, seq=1, offset=0):
+    _dev_ok(dtable, dx, idx, skip_rows); _c(dx, "dx"); _f32(dtable, "dtable")
+    d = dx.shape[-1]
+    rows = dx.numel() // d
+    _rc(_lib.load().antmmf_embed_scatter_add(_p(dx), _p(idx), _p(skip_rows), _p(dtable), rows, seq, d, offset, _stream()),
+        "antmmf_embed_scatter_add")
+    return dtable
+
+
+def adamw_step_(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _dev_ok(p, g, m, v, shadow)
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _c(t, n); _f32(t, n)
+    _rc(_lib.load().antmmf_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
+                                      float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+                                      _stream()), "antmmf_adamw_step")
+
+
+def sumsq_(out, x):
+    _dev_ok(out, x); _c(x, "x"); _f32(x, "x"); _f32(out, "out")
+    _rc(_lib.load().antmmf_sumsq(_p(x), _p(out), x.numel(), _stream()), "antmmf_sumsq")
+    return out
+
+
+# ------------------------------------------------------------------------------ GEMM
+def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None,
+         residual=None, aux=None, gate=None, accumulate=False, split_k=1):
+    """out[i, j] = epi(alpha * sum_r P[i, r] Q[j, r]).  P is [I, R] (or [R, I] when p_rmajor), Q likewise.
+    2-D operands with unit inner stride; row strides are passed through (views of packed buffers are fine)."""
+    _dev_ok(P, Q, out, bias, residual, aux, gate)
+    for t, n in ((P, "P"), (Q, "Q")):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
+            raise ValueError(f"gemm: {n} must be a 2-D bf16 tensor with unit inner stride")
+    I, R = (P.shape[1], P.shape[0]) if p_rmajor else (P.shape[0], P.shape[1])
+    J, R2 = (Q.shape[1], Q.shape[0]) if q_rmajor else (Q.shape[0], Q.shape[1])
+    if R != R2:
+        raise ValueError(f"gemm: reduction mismatch {R} vs {R2}")
+    if out is None:
+        out = torch.empty(I, J, dtype=out_dtype, device=P.device)
+    if out.dim() != 2 or out.stride(1) != 1 or tuple(out.shape) != (I, J):
+        raise ValueError("gemm: bad output")
+    _f32(bias, "bias")
+
+    def ld(t):
+        return 0 if t is None else t.stride(0)
+
+    for t, n in ((residual, "residual"), (aux, "aux"), (gate, "gate")):
+        if t is not None and (t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1 or tuple(t.shape) != (I, J)):
+            raise ValueError(f"gemm: bad {n}")
+    _rc(_lib.load().antmmf_gemm_bf16(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0),
+                                     int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias), ACT_IDS[act],
+                                     _p(residual), ld(residual), _p(aux), ld(aux), _p(gate), ld(gate), int(accumulate),
+                                     int(split_k), _stream()), "antmmf_gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------ attention
+def _tok_ld(t, name):
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.dtype != torch.bfloat16:
+        raise ValueError(f"attention: {name} must be a [B, N, heads*64] bf16 view with unit inner stride and dense batch stride")
+    return t.stride(1)
+
+
+def attention_fwd(q, k, v, heads, scale, key_bias=None):
+    _dev_ok(q, k, v, key_bias)
+    B, Nq, D = q.shape
+    Nk = k.shape[1]
+    assert D == heads * 64, "head_dim must be 64"
+    o = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+    if key_bias is not None:
+        _f32(key_bias, "key_bias"); _c(key_bias, "key_bias")
+        assert tuple(key_bias.shape) == (B, Nk)
+    _rc(_lib.load().antmmf_attention_fwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), B, heads, Nq, Nk,
+                                         _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, float(scale), _stream()),
+        "antmmf_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None):
+    _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
+    B, Nq, D = q.shape
+    Nk = k.shape[1]
+    _c(o, "o"); _c(d_o, "d_o")
+    if dq is None:
+        dq = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=q.device)
+    if dk is None:
+        dk = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
+    if dv is None:
+        dv = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
+    _rc(_lib.load().antmmf_attention_bwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
+                                         B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
+                                         _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), _stream()),
+        "antmmf_attention_bwd")
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------ losses
+def milnce_fwd(Rm, Cm, n_pair, row_offset):
+    _dev_ok(Rm, Cm); _c(Rm, "Rm"); _c(Cm, "Cm"); _f32(Rm, "Rm"); _f32(Cm, "Cm")
+    B = Rm.shape[0]
+    loss_rows = torch.empty(B, dtype=torch.float32, device=Rm.device)
+    denom = torch.empty(B, dtype=torch.float32, device=Rm.device)
+    _rc(_lib.load().antmmf_milnce_fwd(_p(Rm), _p(Cm), B, Rm.shape[1], Cm.shape[1], n_pair, row_offset, _p(loss_rows),
+                                      _p(denom), _stream()), "antmmf_milnce_fwd")
+    return loss_rows, denom
+
+
+def milnce_bwd(Rm, Cm, denom, coef, n_pair, row_offset, out_dtype=torch.bfloat16):
+    _dev_ok(Rm, Cm, denom, coef); _f32(coef, "coef"); _c(coef, "coef")
+    dR = torch.empty(Rm.shape, dtype=out_dtype, device=Rm.device)
+    dC = torch.empty(Cm.shape, dtype=out_dtype, device=Rm.device)
+    _rc(_lib.load().antmmf_milnce_bwd(_p(Rm), _p(Cm), _p(denom), _p(coef), Rm.shape[0], Rm.shape[1], Cm.shape[1], n_pair,
+                                      row_offset, _p(dR), _p(dC), _dt(dR), _stream()), "antmmf_milnce_bwd")
+    return dR, dC
+
+
+def softmax_ce_fwd(x, row_offset, log_scale=None, scale_mul=1.0):
+    _dev_ok(x, log_scale); _c(x, "x"); _f32(x, "x"); _f32(log_scale, "log_scale")
+    B, Wd = x.shape
+    loss_rows = torch.empty(B, dtype=torch.float32, device=x.device)
+    lse = torch.empty(B, dtype=torch.float32, device=x.device)
+    _rc(_lib.load().antmmf_softmax_ce_fwd(_p(x), B, Wd, row_offset, _p(log_scale), float(scale_mul), _p(loss_rows), _p(lse),
+                                          _stream()), "antmmf_softmax_ce_fwd")
+    return loss_rows, lse
+
+
+def softmax_ce_bwd(x, lse, coef, row_offset, log_scale=None, scale_mul=1.0, dscale=None, out_dtype=torch.bfloat16):
+    _dev_ok(x, lse, coef, log_scale, dscale); _f32(coef, "coef"); _c(coef, "coef")
+    dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _rc(_lib.load().antmmf_softmax_ce_bwd(_p(x), _p(lse), _p(coef), x.shape[0], x.shape[1], row_offset, _p(log_scale),
+                                          float(scale_mul), _p(dx), _p(dscale), _dt(dx), _stream()), "antmmf_softmax_ce_bwd")
+    return dx

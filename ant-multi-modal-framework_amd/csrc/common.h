@@ -1,0 +1,110 @@
+// common.h -- shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of libantmmf_hip.so.
+// Wave = 64 lanes everywhere.  bf16 is carried as raw uint16_t; all arithmetic is fp32.
+#pragma once
+#ifdef ANTMMF_EMULATE  // CPU lane-level emulation used only by tests/emu (never by the product build)
+#include "hip_emu.h"
+#define ANTMMF_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem())
+#else
+#include <hip/hip_runtime.h>
+#define ANTMMF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+#include <stdint.h>
+
+#define ANTMMF_OK 0
+#define ANTMMF_EINVAL (-22)
+#define ANTMMF_ELAUNCH (-5)
+
+#define ANTMMF_F32 0
+#define ANTMMF_BF16 1
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;  // MFMA A/B fragment (8 bf16 = 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // MFMA 16x16 C/D fragment
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// element load/store by dtype tag (T = float or bf16_t)
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 8-element vector load/store (16 B for bf16, 2 x 16 B for f32); p must be 16-B aligned
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = bf_lo(a.x); v[1] = bf_hi(a.x); v[2] = bf_lo(a.y); v[3] = bf_hi(a.y);
+    v[4] = bf_lo(a.z); v[5] = bf_hi(a.z); v[6] = bf_lo(a.w); v[7] = bf_hi(a.w);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// wave-wide (64-lane) butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16-B slot swizzle for [rows][64 bf16] (128-B row) LDS tiles: physical slot = slot ^ lds_swz(row).
+// Conflict-free for ds_read_b128 MFMA fragment reads (16 consecutive rows x one slot per 16-lane group).
+__device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) ^ (row >> 3)) & 7; }
+
+// activation ids shared with the host side (include/antmmf_hip.h)
+#define ANTMMF_ACT_NONE 0
+#define ANTMMF_ACT_GELU_ERF 1    // 0.5 x (1 + erf(x/sqrt2))   (BERT, torchscale)
+#define ANTMMF_ACT_QUICK_GELU 2  // x sigmoid(1.702 x)         (CLIP)
+#define ANTMMF_ACT_RELU 3
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case ANTMMF_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ANTMMF_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ANTMMF_ACT_RELU: return fmaxf(x, 0.0f);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
+    switch (act) {
+        case ANTMMF_ACT_GELU_ERF: {
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+            const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case ANTMMF_ACT_QUICK_GELU: {
+            const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+            return s * (1.0f + 1.702f * x * (1.0f - s));
+        }
+        case ANTMMF_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+
+static inline int antmmf_check_launch() { return hipGetLastError() == hipSuccess ? ANTMMF_OK : ANTMMF_ELAUNCH; }
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,363 @@
+// elementwise.hip -- HBM-bound helpers of the contrastive step (gfx950): activations, L2 normalise,
+// bias-gradient column sums, weight transposes, patch extraction, token assembly, embedding
+// gather / scatter, fused AdamW over a flat parameter arena.
+//
+// Everything here is byte-moving work: 16-B vector accesses per lane, grid-stride loops capped at
+// 2048 workgroups (256 CUs x 8), no LDS unless a transpose needs it.
+#include "common.h"
+
+static inline int ew_grid(long nvec) { long g = (nvec + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+// ------------------------------------------------------------------ activation forward / backward
+// reference: QuickGELU clip/model.py:222-224; gelu(erf) modeling_bert.py:31-37; F.gelu feedforward_network.py:120
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ u, T* __restrict__ g, long n, int act) {
+    const long nv = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float v[8];
+        ld8<T>(u + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], act);
+        st8<T>(g + i * 8, v);
+    }
+}
+// du = dg * act'(u)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ u, T* __restrict__ du, long n, int act) {
+    const long nv = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float a[8], b[8];
+        ld8<T>(dg + i * 8, a);
+        ld8<T>(u + i * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= act_grad(b[e], act);
+        st8<T>(du + i * 8, a);
+    }
+}
+extern "C" int antmmf_act_fwd(const void* u, void* g, long n, int act, int dtype, hipStream_t s) {
+    if (!u || !g || n < 0 || (n & 7)) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    if (dtype == ANTMMF_BF16) hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16_t*)u, (bf16_t*)g, n, act);
+    else if (dtype == ANTMMF_F32) hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const float*)u, (float*)g, n, act);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_act_bwd(const void* dg, const void* u, void* du, long n, int act, int dtype, hipStream_t s) {
+    if (!dg || !u || !du || n < 0 || (n & 7)) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    if (dtype == ANTMMF_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16_t*)dg, (const bf16_t*)u, (bf16_t*)du, n, act);
+    else if (dtype == ANTMMF_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const float*)dg, (const float*)u, (float*)du, n, act);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ L2 normalise rows (one wave per row)
+// reference: F.normalize(x, p=2, dim=-1) univl_video_base.py:114,158 (eps 1e-12); x / x.norm() vlmo_module.py:346-349 (eps 0)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, float* __restrict__ inv_norm,
+                                                         long rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) { const float v = ld1<TI>(x + row * cols + c); s += v * v; }
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), eps);
+        for (int c = lane; c < cols; c += 64) st1<TO>(y + row * cols + c, ld1<TI>(x + row * cols + c) * inv);
+        if (lane == 0 && inv_norm) inv_norm[row] = inv;
+    }
+}
+// y = x * inv ; dx = inv * (dy - y * <dy, y>)      (exact where the eps clamp is inactive)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TO* __restrict__ dy, const TO* __restrict__ y, const float* __restrict__ inv_norm,
+                                                         TI* __restrict__ dx, long rows, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s += ld1<TO>(dy + row * cols + c) * ld1<TO>(y + row * cols + c);
+        s = wave_sum(s);
+        const float inv = inv_norm[row];
+        for (int c = lane; c < cols; c += 64)
+            st1<TI>(dx + row * cols + c, inv * (ld1<TO>(dy + row * cols + c) - ld1<TO>(y + row * cols + c) * s));
+    }
+}
+// in_dtype: dtype of x/dx; out_dtype: dtype of y/dy
+extern "C" int antmmf_l2norm_fwd(const void* x, void* y, float* inv_norm, long rows, int cols, float eps, int in_dtype, int out_dtype, hipStream_t s) {
+    if (!x || !y || rows < 0 || cols <= 0) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+#define L2F(TI, TO) hipLaunchKernelGGL((l2norm_fwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, s, (const TI*)x, (TO*)y, inv_norm, rows, cols, eps)
+    if (in_dtype == ANTMMF_BF16 && out_dtype == ANTMMF_BF16) L2F(bf16_t, bf16_t);
+    else if (in_dtype == ANTMMF_BF16 && out_dtype == ANTMMF_F32) L2F(bf16_t, float);
+    else if (in_dtype == ANTMMF_F32 && out_dtype == ANTMMF_F32) L2F(float, float);
+    else if (in_dtype == ANTMMF_F32 && out_dtype == ANTMMF_BF16) L2F(float, bf16_t);
+    else return ANTMMF_EINVAL;
+#undef L2F
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, long rows, int cols, int in_dtype, int out_dtype, hipStream_t s) {
+    if (!dy || !y || !inv_norm || !dx || rows < 0 || cols <= 0) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+#define L2B(TI, TO) hipLaunchKernelGGL((l2norm_bwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, s, (const TO*)dy, (const TO*)y, inv_norm, (TI*)dx, rows, cols)
+    if (in_dtype == ANTMMF_BF16 && out_dtype == ANTMMF_BF16) L2B(bf16_t, bf16_t);
+    else if (in_dtype == ANTMMF_BF16 && out_dtype == ANTMMF_F32) L2B(bf16_t, float);
+    else if (in_dtype == ANTMMF_F32 && out_dtype == ANTMMF_F32) L2B(float, float);
+    else if (in_dtype == ANTMMF_F32 && out_dtype == ANTMMF_BF16) L2B(float, bf16_t);
+    else return ANTMMF_EINVAL;
+#undef L2B
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ column sum: out[c] (+)= sum_r x[r][c]   (bias / pos-emb gradients)
+// Each workgroup takes a slab of rows and 512 columns (a lane owns 8 columns via one 16-B load), sums in fp32
+// registers, then one atomicAdd per column per workgroup.  `out` must be zero-initialised or hold a running sum.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int cols, long ld, long rows_per_block) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < cols) {
+        for (long r = r0 + wave; r < r1; r += 4) {
+            float v[8];
+            ld8<T>(x + r * ld + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int c = blockIdx.x * 512 + i;
+        if (c < cols) atomicAdd(&out[c], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    }
+}
+extern "C" int antmmf_colsum(const void* x, float* out, long rows, int cols, long ld, int dtype, hipStream_t s) {
+    if (!x || !out || rows < 0 || cols <= 0 || (cols & 7) || (ld & 7)) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    const int gx = (cols + 511) / 512;
+    int gy = 2048 / gx; if (gy < 1) gy = 1;
+    long rpb = (rows + gy - 1) / gy; if (rpb < 16) rpb = 16;
+    gy = (int)((rows + rpb - 1) / rpb);
+    if (dtype == ANTMMF_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, s, (const bf16_t*)x, out, rows, cols, ld, rpb);
+    else if (dtype == ANTMMF_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, gy), dim3(256), 0, s, (const float*)x, out, rows, cols, ld, rpb);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ 2-D transpose of a bf16 matrix  out[c][r] = in[r][c]   (weights, for dX = dY W)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(long)(r0 + r) * cols + c0 + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < rows && c0 + c < cols) out[(long)(c0 + c) * rows + r0 + r] = tile[r][c];
+    }
+}
+extern "C" int antmmf_transpose_bf16(const void* in, void* out, int rows, int cols, hipStream_t s) {
+    if (!in || !out || rows <= 0 || cols <= 0) return ANTMMF_EINVAL;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, rows, cols);
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ cast fp32 -> bf16 (flat)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            float v[8];
+            ld8<float>(in + i, v);
+            st8<bf16_t>(out + i, v);
+        } else {
+            for (long j = i; j < n; ++j) out[j] = f2bf(in[j]);
+        }
+    }
+}
+extern "C" int antmmf_cast_f32_bf16(const float* in, void* out, long n, hipStream_t s) {
+    if (!in || !out || n < 0) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid((n + 7) / 8)), dim3(256), 0, s, in, (bf16_t*)out, n);
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ patch extraction (im2col for a stride == kernel conv)
+// image [B, C, H, W] (fp32 or bf16, optional affine (x - shift) * scale: M2's inception normalise) ->
+// patches [B * Gh * Gw, Kpad] bf16, inner order (c, py, px) == Conv2d weight.flatten(1); columns >= C*P*P are zero.
+// reference: nn.Conv2d(3, W, k=P, s=P) clip/model.py:289-295,310-312; VisionEmbedding.proj embedding.py:49,69; img_norm transforms/utils.py:48
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W, int P,
+                                                       int kpad, float shift, float scale) {
+    const int gw = W / P, gh = H / P;
+    const long total = (long)B * gh * gw * kpad;
+    const int kk = C * P * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % kpad);
+        const long prow = i / kpad;
+        float v = 0.f;
+        if (col < kk) {
+            const int px = col % P, py = (col / P) % P, c = col / (P * P);
+            const int gx = (int)(prow % gw), gy = (int)((prow / gw) % gh);
+            const long b = prow / ((long)gw * gh);
+            v = (ld1<T>(img + ((b * C + c) * H + gy * P + py) * W + gx * P + px) - shift) * scale;
+        }
+        out[i] = f2bf(v);
+    }
+}
+extern "C" int antmmf_patchify(const void* img, void* out, int B, int C, int H, int W, int P, int kpad, float shift, float scale, int dtype, hipStream_t s) {
+    if (!img || !out || B <= 0 || P <= 0 || H % P || W % P || kpad < C * P * P || (kpad & 7)) return ANTMMF_EINVAL;
+    const long total = (long)B * (H / P) * (W / P) * kpad;
+    if (dtype == ANTMMF_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)img, (bf16_t*)out, B, C, H, W, P, kpad, shift, scale);
+    else if (dtype == ANTMMF_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)img, (bf16_t*)out, B, C, H, W, P, kpad, shift, scale);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ token assembly: x[b, 0] = cls + pos[0]; x[b, 1+p] = patch[b, p] (+ bias) + pos[1+p]
+// reference: cat([class_embedding, x]) + positional_embedding clip/model.py:313-323; VisionEmbedding cls cat embedding.py:80-83 + PositionalEmbedding :92-110
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16_t* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ out, long B, int G, int d) {
+    const int dv = d >> 3;
+    const long total = B * (G + 1) * dv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % dv);
+        const long tok = i / dv;
+        const int t = (int)(tok % (G + 1));
+        const long b = tok / (G + 1);
+        float o[8], p[8];
+        if (t == 0) ld8<float>(cls + v * 8, o);
+        else {
+            ld8<bf16_t>(patch + ((b * G + t - 1) * d) + v * 8, o);
+            if (bias) { float bb[8]; ld8<float>(bias + v * 8, bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += bb[e]; }
+        }
+        if (pos) { ld8<float>(pos + (long)t * d + v * 8, p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += p[e]; }
+        st8<bf16_t>(out + tok * d + v * 8, o);
+    }
+}
+extern "C" int antmmf_assemble_tokens(const void* patch, const float* cls, const float* pos, const float* bias, void* out, long B, int G, int d, hipStream_t s) {
+    if (!patch || !cls || !out || B <= 0 || G <= 0 || d <= 0 || (d & 7)) return ANTMMF_EINVAL;
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(ew_grid(B * (G + 1) * (d / 8))), dim3(256), 0, s, (const bf16_t*)patch, cls, pos, bias, (bf16_t*)out, B, G, d);
+    return antmmf_check_launch();
+}
+// backward of the assembly: dpatch[b, p] = dx[b, 1+p] (contiguous copy for the patch GEMM's dW);  the cls / pos / bias
+// gradients are column sums of dx taken with antmmf_colsum on strided views by the host.
+__global__ __launch_bounds__(256) void split_tokens_kernel(const bf16_t* __restrict__ dx, bf16_t* __restrict__ dpatch, long B, int G, int d) {
+    const int dv = d >> 3;
+    const long total = B * G * dv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % dv);
+        const long tok = i / dv;
+        const int p = (int)(tok % G);
+        const long b = tok / G;
+        *reinterpret_cast<uint4*>(dpatch + tok * d + v * 8) = *reinterpret_cast<const uint4*>(dx + ((b * (G + 1) + 1 + p) * d) + v * 8);
+    }
+}
+extern "C" int antmmf_split_tokens(const void* dx, void* dpatch, long B, int G, int d, hipStream_t s) {
+    if (!dx || !dpatch || B <= 0 || G <= 0 || d <= 0 || (d & 7)) return ANTMMF_EINVAL;
+    hipLaunchKernelGGL(split_tokens_kernel, dim3(ew_grid(B * G * (d / 8))), dim3(256), 0, s, (const bf16_t*)dx, (bf16_t*)dpatch, B, G, d);
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ embedding gather (sum of up to three tables) and scatter-add of its gradient
+// out[r] = word[ids[r]] (+ pos[pos_ids ? pos_ids[r] : pos_offset + r % seq]) (+ type[type_ids ? type_ids[r] : 0]); padded rows can be zeroed (M2: encoder.py:440)
+// reference: BertEmbeddings clip_text_encoder.py:36-60; TextEmbedding / PositionalEmbedding embedding.py:86-110
+__global__ __launch_bounds__(256) void embed_gather_kernel(const long* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type, const long* __restrict__ type_ids,
+                                                           const unsigned char* __restrict__ zero_rows, bf16_t* __restrict__ out,
+                                                           long rows, int seq, int d, int pos_offset) {
+    const int dv = d >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * dv; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % dv);
+        const long r = i / dv;
+        float o[8], t[8];
+        ld8<float>(word + ids[r] * d + v * 8, o);
+        if (pos) { ld8<float>(pos + (long)(pos_offset + (int)(r % seq)) * d + v * 8, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += t[e]; }
+        if (type) { ld8<float>(type + (type_ids ? type_ids[r] : 0) * d + v * 8, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += t[e]; }
+        if (zero_rows && zero_rows[r]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f; }
+        st8<bf16_t>(out + r * d + v * 8, o);
+    }
+}
+extern "C" int antmmf_embed_gather(const long* ids, const float* word, const float* pos, const float* type, const long* type_ids,
+                                   const unsigned char* zero_rows, void* out, long rows, int seq, int d, int pos_offset, hipStream_t s) {
+    if (!ids || !word || !out || rows < 0 || seq <= 0 || d <= 0 || (d & 7)) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(rows * (d / 8))), dim3(256), 0, s, ids, word, pos, type, type_ids, zero_rows, (bf16_t*)out, rows, seq, d, pos_offset);
+    return antmmf_check_launch();
+}
+// dtable[idx[r]] += dx[r]  (fp32 atomics; idx == NULL means idx[r] = offset + r % seq, i.e. the position table)
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const bf16_t* __restrict__ dx, const long* __restrict__ idx, const unsigned char* __restrict__ skip_rows,
+                                                            float* __restrict__ dtable, long rows, int seq, int d, int offset) {
+    const int dv = d >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * dv; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % dv);
+        const long r = i / dv;
+        if (skip_rows && skip_rows[r]) continue;
+        const long t = idx ? idx[r] : (long)(offset + (int)(r % seq));
+        float g[8];
+        ld8<bf16_t>(dx + r * d + v * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dtable + t * d + v * 8 + e, g[e]);
+    }
+}
+extern "C" int antmmf_embed_scatter_add(const void* dx, const long* idx, const unsigned char* skip_rows, float* dtable, long rows, int seq, int d, int offset, hipStream_t s) {
+    if (!dx || !dtable || rows < 0 || seq <= 0 || d <= 0 || (d & 7)) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(ew_grid(rows * (d / 8))), dim3(256), 0, s, (const bf16_t*)dx, idx, skip_rows, dtable, rows, seq, d, offset);
+    return antmmf_check_launch();
+}
+
+// ------------------------------------------------------------------ fused AdamW over a flat arena segment (decoupled weight decay, torch.optim.AdamW semantics)
+// p, m, v fp32 master state; g fp32 gradient (scaled by grad_scale first, e.g. 1/world or a clip coefficient); writes the bf16 compute shadow.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ shadow, long n, float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2, float grad_scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        pi *= (1.f - lr * wd);
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (shadow) shadow[i] = f2bf(pi);
+    }
+}
+extern "C" int antmmf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int step, float grad_scale, hipStream_t s) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    return antmmf_check_launch();
+}
+
+// sum of squares of a flat fp32 buffer into *out (fp32 atomics; out must be zeroed) -- gradient-norm clipping (antmmf/utils/general.py:47-56)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = x[i]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+extern "C" int antmmf_sumsq(const float* x, float* out, long n, hipStream_t s) {
+    if (!x || !out || n < 0) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, out, n);
+    return antmmf_check_launch();
+}

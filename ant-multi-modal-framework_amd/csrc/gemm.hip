@@ -1,0 +1,249 @@
+// gemm.hip -- bf16 MFMA GEMM with fused epilogues for gfx950 (CDNA4, MI355X).
+//
+//     out[i][j] = epilogue( alpha * sum_r P[i][r] * Q[j][r] )          i < I, j < J, r < R
+//
+// P and Q are bf16 matrices, each either "r-contiguous" (stored [I][R] / [J][R]) or "r-major"
+// (stored [R][I] / [R][J]); the three layouts a training step needs are
+//     forward   Y = X W^T      P = X  [M][K]  r-contig,  Q = W  [N][K]  r-contig          (pt=0, qt=0)
+//     dgrad     dX = dY W      P = dY [M][N]  r-contig,  Q = W  [N][K]  r-major (R = N)    (pt=0, qt=1)
+//     wgrad     dW = dY^T X    P = dY [M][N]  r-major,   Q = X  [M][K]  r-major (R = M)    (pt=1, qt=1)
+// so no operand is ever transposed in HBM.  Replaces the cuBLAS calls behind (reference)
+//   nn.MultiheadAttention in/out proj   antmmf/modules/vision/backbone/clip/model.py:231,251
+//   BERT query/key/value/dense          antmmf/modules/vision/backbone/clip/modeling_bert.py:120-122,182-186,221-238
+//   M2 q/k/v/out_proj, fc1/fc2          prj/M2_Encoder/vlmo/torchscale/component/multihead_attention.py:46-50, feedforward_network.py:117-128
+//   patch-embed conv as GEMM            clip/model.py:289-295 ; embedding.py:49,69
+//   similarity matrix                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:208-213 ; clip/model.py:442-444
+//
+// Kernel shape: 256 threads = 4 waves (2 x 2), workgroup tile 128 (i) x 128 (j) x 64 (r), each wave
+// 64 x 64 as 4 x 4 v_mfma_f32_16x16x32_bf16 tiles (64 fp32 accumulators / lane).  Both operand tiles
+// sit in LDS as [128 rows][64 r] bf16 (128-B rows) with the 16-B slot index XOR-swizzled by
+// f(row) = ((row>>1) ^ (row>>3)) & 7, which makes the ds_read_b128 fragment reads (16 consecutive
+// rows x one slot per 16-lane group) bank-conflict-free AND keeps the ds_write_b32 pattern of the
+// transposing stager at <= 2-way.  r-major operands are transposed on the way into LDS: a thread
+// loads two consecutive r-rows x 8 columns (2 x 16 B, coalesced along the row), interleaves them
+// into 8 packed (r, r+1) words and writes one word per column.  Global loads for tile t+1 are
+// issued before the MFMAs of tile t and written to the other LDS buffer after them (one barrier per
+// r-step).  The MFMA is issued with Q rows as the A operand and P rows as the B operand so that a
+// lane ends up holding 4 CONSECUTIVE j of one output row: bias / residual / store are 8-B (bf16) or
+// 16-B (fp32) vector accesses.  Workgroup ids are remapped so that each XCD (private 4 MiB L2)
+// walks consecutive j-tiles of the same i-panel.
+//
+// Roofline: MFMA-bound (2*I*J*R flop).  Algorithmic HBM bytes: 2*(I*R + J*R) + out bytes.
+#include "common.h"
+
+#define ANTMMF_GEMM_EINVAL ANTMMF_EINVAL
+
+struct GemmArgs {
+    const bf16_t* P; const bf16_t* Q; void* C;
+    const float* bias;        // [J] added before the activation (nullable)
+    const bf16_t* residual;   // [I][J] (ldr) added after the activation (nullable)
+    bf16_t* aux;              // [I][J] (ldaux) receives the pre-activation value (nullable)
+    const bf16_t* gate;       // [I][J] (ldgate): out *= act'(gate)  (dgrad through an activation; nullable)
+    long ldp, ldq, ldc, ldr, ldaux, ldgate;
+    int I, J, R;
+    int act, c_dtype, accumulate, ksteps_per_split;
+    float alpha;
+};
+
+
+// r-contiguous operand: 128 rows x 64 r = 1024 16-B vectors, 4 per thread
+__device__ __forceinline__ void load_rc(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int r0, int R, uint4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = threadIdx.x + 256 * q, row = id >> 3, slot = id & 7;
+        const int gr = row0 + row, gc = r0 + slot * 8;
+        v[q] = (gr < nrows && gc < R) ? *reinterpret_cast<const uint4*>(base + (long)gr * ld + gc) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void store_rc(char* lds, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = threadIdx.x + 256 * q, row = id >> 3, slot = id & 7;
+        *reinterpret_cast<uint4*>(lds + row * 128 + ((slot ^ lds_swz(row)) << 4)) = v[q];
+    }
+}
+// r-major operand (stored [R][ncols]): 32 r-pairs x 16 column chunks = 512 units, 2 per thread
+__device__ __forceinline__ void load_rm(const bf16_t* __restrict__ base, long ld, int col0, int ncols, int r0, int R, uint4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = threadIdx.x + 256 * q, c = u & 15, rp = u >> 4;
+        const int gc = col0 + c * 8, gr = r0 + 2 * rp;
+        const bool okc = gc < ncols;
+        v[2 * q] = (okc && gr < R) ? *reinterpret_cast<const uint4*>(base + (long)gr * ld + gc) : make_uint4(0, 0, 0, 0);
+        v[2 * q + 1] = (okc && gr + 1 < R) ? *reinterpret_cast<const uint4*>(base + (long)(gr + 1) * ld + gc) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void store_rm(char* lds, const uint4 (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = threadIdx.x + 256 * q, c = u & 15, rp = u >> 4;
+        const uint32_t a[4] = {v[2 * q].x, v[2 * q].y, v[2 * q].z, v[2 * q].w};
+        const uint32_t b[4] = {v[2 * q + 1].x, v[2 * q + 1].y, v[2 * q + 1].z, v[2 * q + 1].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t lo = (e & 1) ? (a[e >> 1] >> 16) : (a[e >> 1] & 0xffffu);
+            const uint32_t hi = (e & 1) ? (b[e >> 1] & 0xffff0000u) : (b[e >> 1] << 16);
+            const int row = c * 8 + e;
+            *reinterpret_cast<uint32_t*>(lds + row * 128 + ((((rp >> 2) ^ lds_swz(row))) << 4) + (rp & 3) * 4) = lo | hi;
+        }
+    }
+}
+
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);  // [2 buffers][P tile 16 KiB | Q tile 16 KiB]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+
+    // XCD-aware, bijective workgroup remap (8 XCDs): XCD x owns a contiguous range of tile ids
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tiles_j = (g.J + 127) >> 7;
+    const int i0 = (wgid / tiles_j) << 7, j0 = (wgid % tiles_j) << 7;
+
+    const int nk_total = (g.R + 63) >> 6;
+    const int kbeg = blockIdx.z * g.ksteps_per_split;
+    int kend = kbeg + g.ksteps_per_split;
+    if (kend > nk_total) kend = nk_total;
+    if (kbeg >= kend) return;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 pv[4], qv[4];
+    auto gload = [&](int kt) {
+        if (PT) load_rm(g.P, g.ldp, i0, g.I, kt << 6, g.R, pv); else load_rc(g.P, g.ldp, i0, g.I, kt << 6, g.R, pv);
+        if (QT) load_rm(g.Q, g.ldq, j0, g.J, kt << 6, g.R, qv); else load_rc(g.Q, g.ldq, j0, g.J, kt << 6, g.R, qv);
+    };
+    auto lstore = [&](int buf) {
+        char* ps = smem + buf * 32768;
+        if (PT) store_rm(ps, pv); else store_rc(ps, pv);
+        if (QT) store_rm(ps + 16384, qv); else store_rc(ps + 16384, qv);
+    };
+
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kbeg; kt < kend; ++kt) {
+        const bool more = kt + 1 < kend;
+        if (more) gload(kt + 1);
+        const char* ps = smem + cur * 32768;
+        const char* qs = ps + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t qa[4], pb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int qrow = wj * 64 + t * 16 + l15;
+                qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + qrow * 128 + (((kk * 4 + grp) ^ lds_swz(qrow)) << 4));
+                const int prow = wi * 64 + t * 16 + l15;
+                pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + prow * 128 + (((kk * 4 + grp) ^ lds_swz(prow)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt)
+    const bool splitk = gridDim.z > 1;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = i0 + wi * 64 + it * 16 + l15;
+        if (i >= g.I) continue;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = j0 + wj * 64 + jt * 16 + grp * 4;
+            if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
+            float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
+            if (g.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (g.gate) {
+                const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
+                v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
+                v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+            } else if (g.act != ANTMMF_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
+            }
+            if (g.residual) {
+                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                v[0] += bf_lo(u.x); v[1] += bf_hi(u.x); v[2] += bf_lo(u.y); v[3] += bf_hi(u.y);
+            }
+            if (g.c_dtype == ANTMMF_BF16) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (long)i * g.ldc + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            } else {
+                float* cp = reinterpret_cast<float*>(g.C) + (long)i * g.ldc + j;
+                if (splitk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
+                } else if (g.accumulate) {
+                    float4 o = *reinterpret_cast<float4*>(cp);
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+// C ABI: see include/antmmf_hip.h for the contract.
+extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
+                                int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
+                                const void* residual, long ldr, void* aux, long ldaux, const void* gate, long ldgate,
+                                int accumulate, int split_k, hipStream_t stream) {
+    if (!P || !Q || !C || I < 0 || J < 0 || R <= 0) return ANTMMF_EINVAL;
+    if (I == 0 || J == 0) return ANTMMF_OK;
+    if ((J & 3) || (ldc & 3)) return ANTMMF_EINVAL;
+    if ((ldp & 7) || (ldq & 7)) return ANTMMF_EINVAL;
+    if (!p_rmajor && (R & 7)) return ANTMMF_EINVAL;
+    if (!q_rmajor && (R & 7)) return ANTMMF_EINVAL;
+    if (p_rmajor && (I & 7)) return ANTMMF_EINVAL;
+    if (q_rmajor && (J & 7)) return ANTMMF_EINVAL;
+    if (p_rmajor && !q_rmajor) return ANTMMF_EINVAL;  // layout not needed by the step
+    if (c_dtype != ANTMMF_BF16 && c_dtype != ANTMMF_F32) return ANTMMF_EINVAL;
+    if ((residual && (ldr & 3)) || (aux && (ldaux & 3)) || (gate && (ldgate & 3))) return ANTMMF_EINVAL;
+    if (accumulate && c_dtype != ANTMMF_F32) return ANTMMF_EINVAL;
+    const int nk = (R + 63) / 64;
+    if (split_k < 1) split_k = 1;
+    if (split_k > nk) split_k = nk;
+    if (split_k > 1 && (c_dtype != ANTMMF_F32 || !accumulate || bias || act != ANTMMF_ACT_NONE || residual || aux || gate)) return ANTMMF_EINVAL;
+    GemmArgs g;
+    g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.C = C; g.bias = bias; g.residual = (const bf16_t*)residual;
+    g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
+    g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
+    g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha;
+    g.ksteps_per_split = (nk + split_k - 1) / split_k;
+    const int splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
+    const long tiles = (long)((I + 127) / 128) * ((J + 127) / 128);
+    if (tiles > 0x7fffffffL) return ANTMMF_EINVAL;
+    const dim3 grid((unsigned)tiles, 1, splits), block(256);
+    const size_t lds = 65536;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
+    else if (!p_rmajor && q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, stream, g);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
+    return antmmf_check_launch();
+}

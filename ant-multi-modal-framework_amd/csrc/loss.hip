@@ -1,0 +1,143 @@
+// loss.hip -- row-sharded contrastive losses on fp32 similarity slabs (gfx950).
+//
+// Each rank owns B pairs and holds two slabs of the global similarity matrix, produced by the MFMA
+// GEMM directly in fp32 and never materialised as the reference's [B_g*n]^2 kron/cat/mask temporaries:
+//     Rm[i][c] = <text_i, clip_c>            i local (global index row_offset + i), c over ALL B_g*n clips
+//     Cm[i][t] = <centre clip of video_i, text_t>                                     t over ALL B_g texts
+// MIL-NCE (reference: get_mil_nce_loss, prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197;
+// closed form SURVEY.md 8a L1, restated per local row and checked against oracle/losses.py):
+//     denom_i = LSE( { log n + Cm[i][t] }_t  U  { Rm[i][c] : c / n != gi } ),   l_i = denom_i - (log n + Cm[i][gi])
+// Symmetric InfoNCE / CrossEn (reference logits: prj/M2_Encoder/m2_encoder.py:92-95, clip/model.py:442-444;
+// CrossEn prj/dmae_vtp/.../dmae_utils.py:528-537) is softmax-CE over a scaled row with target column gi.
+//
+// HBM-bound: one workgroup per row, online (max, sum) per thread over 16-B loads, wave butterflies + one LDS hop.
+// Algorithmic bytes / row: fwd 4*(Wr + Wc); bwd 4*(Wr + Wc) read + out-dtype*(Wr + Wc) written.
+#include "common.h"
+
+struct MS { float m, s; };
+__device__ __forceinline__ void ms_add(MS& a, float x) {
+    if (x == -INFINITY) return;
+    if (x > a.m) { a.s = a.s * __expf(a.m - x) + 1.0f; a.m = x; } else a.s += __expf(x - a.m);
+}
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+    if (b.m == -INFINITY) return a;
+    if (a.m == -INFINITY) return b;
+    MS r; r.m = fmaxf(a.m, b.m); r.s = a.s * __expf(a.m - r.m) + b.s * __expf(b.m - r.m); return r;
+}
+__device__ __forceinline__ MS block_ms(MS v, MS* sh) {  // 256 threads; result valid in every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { MS t; t.m = __shfl_xor(v.m, o, 64); t.s = __shfl_xor(v.s, o, 64); v = ms_merge(v, t); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return ms_merge(ms_merge(sh[0], sh[1]), ms_merge(sh[2], sh[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void milnce_fwd_kernel(const float* __restrict__ Rm, const float* __restrict__ Cm, int Wr, int Wc, int n_pair,
+                                                         int row_offset, float* __restrict__ loss_rows, float* __restrict__ denom) {
+    __shared__ MS sh[4];
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float logn = __logf((float)n_pair);
+    MS acc; acc.m = -INFINITY; acc.s = 0.f;
+    const float* r = Rm + (long)i * Wr;
+    for (int c = threadIdx.x; c < Wr; c += 256) if (c / n_pair != gi) ms_add(acc, r[c]);
+    const float* cm = Cm + (long)i * Wc;
+    for (int t = threadIdx.x; t < Wc; t += 256) ms_add(acc, cm[t] + logn);
+    const MS tot = block_ms(acc, sh);
+    if (threadIdx.x == 0) {
+        const float d = tot.m + __logf(tot.s);
+        denom[i] = d;
+        loss_rows[i] = d - (logn + cm[gi]);
+    }
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void milnce_bwd_kernel(const float* __restrict__ Rm, const float* __restrict__ Cm, const float* __restrict__ denom,
+                                                         const float* __restrict__ coef, int Wr, int Wc, int n_pair, int row_offset,
+                                                         TO* __restrict__ dRm, TO* __restrict__ dCm) {
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float d = denom[i], k = coef[i], logn = __logf((float)n_pair);
+    for (int c = threadIdx.x; c < Wr; c += 256)
+        st1<TO>(dRm + (long)i * Wr + c, (c / n_pair != gi) ? k * __expf(Rm[(long)i * Wr + c] - d) : 0.f);
+    for (int t = threadIdx.x; t < Wc; t += 256)
+        st1<TO>(dCm + (long)i * Wc + t, k * (__expf(Cm[(long)i * Wc + t] + logn - d) - (t == gi ? 1.f : 0.f)));
+}
+
+// softmax cross-entropy of scale * x[i][:] against column row_offset + i
+__global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ x, int W, int row_offset, const float* __restrict__ log_scale,
+                                                             float scale_mul, float* __restrict__ loss_rows, float* __restrict__ lse) {
+    __shared__ MS sh[4];
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float sc = scale_mul * (log_scale ? __expf(*log_scale) : 1.0f);
+    MS acc; acc.m = -INFINITY; acc.s = 0.f;
+    const float* r = x + (long)i * W;
+    for (int c = threadIdx.x; c < W; c += 256) ms_add(acc, sc * r[c]);
+    const MS tot = block_ms(acc, sh);
+    if (threadIdx.x == 0) {
+        const float l = tot.m + __logf(tot.s);
+        lse[i] = l;
+        loss_rows[i] = l - sc * r[gi];
+    }
+}
+// dx = coef * sc * (softmax - onehot);  *dscale += coef * sum_c (softmax - onehot) * x      (d loss / d sc)
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lse, const float* __restrict__ coef,
+                                                             int W, int row_offset, const float* __restrict__ log_scale, float scale_mul,
+                                                             TO* __restrict__ dx, float* __restrict__ dscale) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float sc = scale_mul * (log_scale ? __expf(*log_scale) : 1.0f);
+    const float l = lse[i], k = coef[i];
+    float ds = 0.f;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        const float xv = x[(long)i * W + c];
+        const float p = __expf(sc * xv - l) - (c == gi ? 1.f : 0.f);
+        st1<TO>(dx + (long)i * W + c, k * sc * p);
+        ds += p * xv;
+    }
+    if (dscale) {
+        const float tot = block_sum(ds, sh);
+        if (threadIdx.x == 0) atomicAdd(dscale, k * tot);
+    }
+}
+
+extern "C" int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
+                                 float* loss_rows, float* denom, hipStream_t s) {
+    if (!Rm || !Cm || !loss_rows || !denom || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1 || row_offset < 0 || row_offset + B > Wc) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    hipLaunchKernelGGL(milnce_fwd_kernel, dim3(B), dim3(256), 0, s, Rm, Cm, Wr, Wc, n_pair, row_offset, loss_rows, denom);
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_milnce_bwd(const float* Rm, const float* Cm, const float* denom, const float* coef, int B, int Wr, int Wc, int n_pair,
+                                 int row_offset, void* dRm, void* dCm, int out_dtype, hipStream_t s) {
+    if (!Rm || !Cm || !denom || !coef || !dRm || !dCm || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    if (out_dtype == ANTMMF_BF16) hipLaunchKernelGGL(milnce_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, Rm, Cm, denom, coef, Wr, Wc, n_pair, row_offset, (bf16_t*)dRm, (bf16_t*)dCm);
+    else if (out_dtype == ANTMMF_F32) hipLaunchKernelGGL(milnce_bwd_kernel<float>, dim3(B), dim3(256), 0, s, Rm, Cm, denom, coef, Wr, Wc, n_pair, row_offset, (float*)dRm, (float*)dCm);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_softmax_ce_fwd(const float* x, int B, int W, int row_offset, const float* log_scale, float scale_mul,
+                                     float* loss_rows, float* lse, hipStream_t s) {
+    if (!x || !loss_rows || !lse || B < 0 || W <= 0 || row_offset < 0 || row_offset + B > W) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3(B), dim3(256), 0, s, x, W, row_offset, log_scale, scale_mul, loss_rows, lse);
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_softmax_ce_bwd(const float* x, const float* lse, const float* coef, int B, int W, int row_offset, const float* log_scale,
+                                     float scale_mul, void* dx, float* dscale, int out_dtype, hipStream_t s) {
+    if (!x || !lse || !coef || !dx || B < 0 || W <= 0) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    if (out_dtype == ANTMMF_BF16) hipLaunchKernelGGL(softmax_ce_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, lse, coef, W, row_offset, log_scale, scale_mul, (bf16_t*)dx, dscale);
+    else if (out_dtype == ANTMMF_F32) hipLaunchKernelGGL(softmax_ce_bwd_kernel<float>, dim3(B), dim3(256), 0, s, x, lse, coef, W, row_offset, log_scale, scale_mul, (float*)dx, dscale);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}

@@ -1,0 +1,154 @@
+/* antmmf_hip.h -- C ABI of libantmmf_hip.so: the MI355X (gfx950) kernels behind AntMMF's
+ * contrastive image/video-text training step.
+ *
+ * The reference (alipay/Ant-Multi-Modal-Framework) has no FFI and no native kernels: every operator
+ * on this path is a stock torch op.  Its plugin surface is the Python registries
+ * (antmmf.modules / antmmf.models) plus the op-replacement seam antmmf/utils/optim_utils.py:24-33,59-93
+ * (`replace_speedup_op`).  This header is the boundary a maintainer binds from that seam; each entry
+ * names the reference arithmetic it replaces (file:line, paths relative to the reference checkout).
+ * INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - the caller owns every buffer (device memory; kernels never allocate, free or synchronise);
+ *  - row-major; "ld*" are row strides in ELEMENTS; all pointers 16-byte aligned;
+ *  - dtype tags: ANTMMF_F32 = 0, ANTMMF_BF16 = 1 (bf16 = upper 16 bits of an IEEE fp32, RNE);
+ *  - every function enqueues on `stream` (a hipStream_t; pass torch's current stream) and returns
+ *    0, or a negative errno-style code (-22 bad argument, -5 launch failure); nothing throws;
+ *  - re-entrant, no global state; one process per GPU.
+ */
+#ifndef ANTMMF_HIP_H
+#define ANTMMF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANTMMF_F32 0
+#define ANTMMF_BF16 1
+#define ANTMMF_ACT_NONE 0
+#define ANTMMF_ACT_GELU_ERF 1   /* modeling_bert.py:31-37; torchscale feedforward_network.py:80-86,120 */
+#define ANTMMF_ACT_QUICK_GELU 2 /* clip/model.py:222-224 */
+#define ANTMMF_ACT_RELU 3
+
+typedef void* antmmf_stream_t; /* hipStream_t */
+
+/* 1 = real gfx950 library, 0 = the CPU lane emulator used by tests/emu. */
+int antmmf_backend(void);
+/* ABI version of this header (bumped on any signature change). */
+int antmmf_abi_version(void);
+
+/* ---- LayerNorm: y = (x - mean) * rstd * gamma + beta, statistics in fp32.
+ * Replaces clip/model.py:213-219 (fp32-upcast LN), modeling_bert.py:63 (eps 1e-12),
+ * torchscale LayerNorm (encoder.py:34,77; multihead_attention.py:51-55; feedforward_network.py:109).
+ * cols % 8 == 0, cols <= 4096.  mean/rstd ([rows] fp32) may be NULL in fwd. */
+int antmmf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int64_t rows, int cols, float eps, int dtype, antmmf_stream_t stream);
+/* dx = LN'(dy) (+ dres if non-NULL); dgamma/dbeta (fp32, may be NULL) are ACCUMULATED (+=). */
+int antmmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype,
+                         antmmf_stream_t stream);
+
+/* ---- activations (n % 8 == 0): g = act(u);  du = dg * act'(u). */
+int antmmf_act_fwd(const void* u, void* g, int64_t n, int act, int dtype, antmmf_stream_t stream);
+int antmmf_act_bwd(const void* dg, const void* u, void* du, int64_t n, int act, int dtype, antmmf_stream_t stream);
+
+/* ---- row L2 normalise: y = x / max(||x||, eps).  Replaces F.normalize (univl_video_base.py:114,158)
+ * and x / x.norm() (vlmo_module.py:346-349; eps = 0).  inv_norm [rows] fp32 is saved for bwd. */
+int antmmf_l2norm_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int cols, float eps, int in_dtype,
+                      int out_dtype, antmmf_stream_t stream);
+int antmmf_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int cols,
+                      int in_dtype, int out_dtype, antmmf_stream_t stream);
+
+/* ---- out[c] += sum_r x[r][c]   (bias / positional-embedding gradients; cols % 8 == 0, ld % 8 == 0). */
+int antmmf_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dtype, antmmf_stream_t stream);
+/* ---- out[c][r] = in[r][c] for a bf16 matrix. */
+int antmmf_transpose_bf16(const void* in, void* out, int rows, int cols, antmmf_stream_t stream);
+/* ---- flat fp32 -> bf16 cast. */
+int antmmf_cast_f32_bf16(const float* in, void* out, int64_t n, antmmf_stream_t stream);
+
+/* ---- patch extraction for a stride == kernel conv (nn.Conv2d(3, W, P, P): clip/model.py:289-295,310-312;
+ * VisionEmbedding.proj: torchscale/component/embedding.py:49,69), with the optional input affine
+ * (x - shift) * scale (M2 img_norm, transforms/utils.py:48).  img [B,C,H,W] (dtype) -> out [B*(H/P)*(W/P), kpad]
+ * bf16, inner order (c, py, px); columns >= C*P*P are zero (kpad % 8 == 0). */
+int antmmf_patchify(const void* img, void* out, int B, int C, int H, int W, int P, int kpad, float shift, float scale,
+                    int dtype, antmmf_stream_t stream);
+/* ---- x[b,0] = cls + pos[0];  x[b,1+p] = patch[b,p] (+ bias) + pos[1+p]   (clip/model.py:313-323; embedding.py:80-83,92-110).
+ * patch [B*G, d] bf16, cls [d] / pos [(G+1), d] (nullable) / bias [d] (nullable) fp32, out [B, G+1, d] bf16. */
+int antmmf_assemble_tokens(const void* patch, const float* cls, const float* pos, const float* bias, void* out,
+                           int64_t B, int G, int d, antmmf_stream_t stream);
+/* ---- dpatch[b,p] = dx[b,1+p]  (backward of the assembly; bf16). */
+int antmmf_split_tokens(const void* dx, void* dpatch, int64_t B, int G, int d, antmmf_stream_t stream);
+
+/* ---- embedding lookup: out[r] = word[ids[r]] (+ pos[pos_offset + r % seq]) (+ type[type_ids ? type_ids[r] : 0]),
+ * rows flagged in zero_rows are zeroed (torchscale encoder.py:440).  Tables fp32, out bf16, d % 8 == 0.
+ * Replaces BertEmbeddings (clip_text_encoder.py:36-60) and TextEmbedding/PositionalEmbedding (embedding.py:86-110). */
+int antmmf_embed_gather(const int64_t* ids, const float* word, const float* pos, const float* type,
+                        const int64_t* type_ids, const unsigned char* zero_rows, void* out, int64_t rows, int seq,
+                        int d, int pos_offset, antmmf_stream_t stream);
+/* ---- dtable[idx ? idx[r] : offset + r % seq] += dx[r]  (fp32 atomics; rows flagged in skip_rows are skipped). */
+int antmmf_embed_scatter_add(const void* dx, const int64_t* idx, const unsigned char* skip_rows, float* dtable,
+                             int64_t rows, int seq, int d, int offset, antmmf_stream_t stream);
+
+/* ---- fused AdamW over a flat fp32 arena segment (torch.optim.AdamW semantics, decoupled decay);
+ * g is multiplied by grad_scale first; `shadow` (bf16 compute copy, nullable) is rewritten. */
+int antmmf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, float grad_scale,
+                      antmmf_stream_t stream);
+/* ---- *out += sum x[i]^2  (gradient-norm clipping, antmmf/utils/general.py:47-56). */
+int antmmf_sumsq(const float* x, float* out, int64_t n, antmmf_stream_t stream);
+
+/* ---- bf16 MFMA GEMM:  C[i][j] = epi( alpha * sum_r P[i][r] Q[j][r] ),  i < I, j < J, r < R.
+ * P is [I][R] (p_rmajor = 0) or [R][I] (p_rmajor = 1); Q likewise.  Supported: (0,0) forward Y = X W^T,
+ * (0,1) dgrad dX = dY W, (1,1) wgrad dW = dY^T X.  epi: + bias[j] (fp32) -> store aux (pre-activation,
+ * bf16) -> act, or * act'(gate[i][j]) when gate is given -> + residual[i][j] (bf16) -> store C
+ * (bf16 or fp32; accumulate = 1 adds into an fp32 C; split_k > 1 needs fp32 + accumulate and no epilogue).
+ * J % 4 == 0, ld* % 8 == 0 (ldc/ldr/ldaux/ldgate % 4 == 0), R % 8 == 0 for an r-contiguous operand.
+ * Replaces the cuBLAS GEMMs behind nn.MultiheadAttention in/out proj (clip/model.py:231,251), BERT
+ * query/key/value/dense (modeling_bert.py:120-122,182-186,221-238), M2 q/k/v/out_proj + fc1/fc2
+ * (multihead_attention.py:46-50,91-93; feedforward_network.py:117-128), the patch-embed conv, the
+ * projection heads (clip/model.py:330-333; heads.py:17-24) and the similarity matrix
+ * (univl_video_ret.py:208-213; clip/model.py:442-444). */
+int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R, int64_t ldp, int64_t ldq,
+                     int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
+                     const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
+                     int accumulate, int split_k, antmmf_stream_t stream);
+
+/* ---- fused multi-head attention, head_dim = 64, bf16, Nk <= 288 (whole key row in LDS):
+ *   O[b,q,h,:] = softmax_k( scale * <Q[b,q,h,:], K[b,k,h,:]> + key_bias[b,k] ) V[b,k,h,:]
+ * element (b, n, h, e) of Q lives at q + (b*Nq + n)*ldq + h*64 + e (K, V with Nk / ldk / ldv; O with ldo), so a packed
+ * [B, N, 3, heads, 64] projection output is addressed with ld = 3*heads*64 and no copy.  key_bias [B, Nk] fp32 (nullable):
+ * BERT's additive -10000 (modeling_bert.py:144-161; clip_text_encoder.py:97-100), torchscale's -inf key padding
+ * (multihead_attention.py:130-142); CLIP's ViT passes none (clip/model.py:245-251).  Co-attention (vilbert.py:360-400)
+ * is two calls with the streams swapped.  lse [B, heads, Nq] fp32 is saved for the backward. */
+int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
+                         int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         float scale, antmmf_stream_t stream);
+/* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs. */
+int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
+                         const float* lse, const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq,
+                         int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                         int64_t lddk, int64_t lddv, float scale, antmmf_stream_t stream);
+
+/* ---- row-sharded MIL-NCE (get_mil_nce_loss, univl_video_ret.py:146-197) on fp32 similarity slabs:
+ *   Rm[i][c] = <text_i, clip_c> (c over all Wr = B_g*n clips),  Cm[i][t] = <centre clip of video_i, text_t> (Wc = B_g),
+ *   denom_i = LSE({log n + Cm[i][t]} U {Rm[i][c] : c / n != gi}),  loss_rows[i] = denom_i - (log n + Cm[i][gi]),
+ *   gi = row_offset + i. */
+int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
+                      float* loss_rows, float* denom, antmmf_stream_t stream);
+/* dRm / dCm (out_dtype) for upstream per-row coefficients coef[i] = d loss / d loss_rows[i]. */
+int antmmf_milnce_bwd(const float* Rm, const float* Cm, const float* denom, const float* coef, int B, int Wr, int Wc,
+                      int n_pair, int row_offset, void* dRm, void* dCm, int out_dtype, antmmf_stream_t stream);
+/* ---- softmax cross-entropy of s * x[i][:] against column row_offset + i, s = scale_mul * (log_scale ? exp(*log_scale) : 1).
+ * InfoNCE over logit_scale.exp() * img @ txt.T (m2_encoder.py:92-95; clip/model.py:442-444); DMAE CrossEn (dmae_utils.py:528-537). */
+int antmmf_softmax_ce_fwd(const float* x, int B, int W, int row_offset, const float* log_scale, float scale_mul,
+                          float* loss_rows, float* lse, antmmf_stream_t stream);
+/* dx = coef * s * (softmax - onehot);  *dscale += coef * sum_c (softmax - onehot) * x  (= d loss / d s; nullable). */
+int antmmf_softmax_ce_bwd(const float* x, const float* lse, const float* coef, int B, int W, int row_offset,
+                          const float* log_scale, float scale_mul, void* dx, float* dscale, int out_dtype,
+                          antmmf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANTMMF_HIP_H */

@@ -1,0 +1,155 @@
+// hip_emu.h -- TEST INFRASTRUCTURE: a minimal lane-level CPU emulation of the HIP constructs used by
+// ant-multi-modal-framework_amd/csrc/*.hip, so the kernels' index arithmetic (LDS swizzles, MFMA
+// fragment bookkeeping, guards, reductions, epilogues) can be exercised in the GPU-less build
+// container.  Every HIP thread is an OS thread; a wave's cross-lane operations (shuffles, MFMA)
+// rendezvous on a per-wave barrier; __syncthreads() is a per-workgroup barrier; workgroups run one
+// after another.  The MFMA model implements the documented gfx950 16x16x32 bf16 fragment layout
+// (A: lane l holds A[l&15][8*(l>>4)+e]; B: lane l holds B[8*(l>>4)+e][l&15]; D: lane l holds
+// D[4*(l>>4)+r][l&15]).  It is never linked into the product library and never runs on the GPU box's
+// product path; the real-hardware parity tests (-m gpu) remain the authority.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline uint2 make_uint2(uint32_t a, uint32_t b) { return {a, b}; }
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return {a, b, c, d}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+
+namespace emu {
+struct Wave {
+    std::barrier<> bar{64};
+    float fbuf[64];
+    uint16_t a[64][8], b[64][8];
+};
+struct Block {
+    int nthreads;
+    std::unique_ptr<std::barrier<>> bar;
+    std::vector<std::unique_ptr<Wave>> waves;
+    std::vector<char> dyn;
+};
+struct TLS { dim3 tid, bid, gdim, bdim; Block* blk; Wave* wave; int lane; };
+inline thread_local TLS tls;
+
+template <typename F>
+void launch(F&& body, dim3 grid, dim3 block, size_t lds) {
+    const int nt = (int)(block.x * block.y * block.z);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                Block blk;
+                blk.nthreads = nt;
+                blk.bar = std::make_unique<std::barrier<>>(nt);
+                for (int w = 0; w < (nt + 63) / 64; ++w) blk.waves.emplace_back(new Wave());
+                blk.dyn.assign(lds + 64, 0);
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; ++t)
+                    th.emplace_back([&, t] {
+                        tls.tid = dim3((unsigned)t, 0, 0);
+                        tls.bid = dim3(bx, by, bz);
+                        tls.gdim = grid;
+                        tls.bdim = block;
+                        tls.blk = &blk;
+                        tls.wave = blk.waves[t / 64].get();
+                        tls.lane = t % 64;
+                        body();
+                        // a thread that returns early must keep the barriers balanced
+                        tls.wave->bar.arrive_and_drop();
+                        blk.bar->arrive_and_drop();
+                    });
+                for (auto& x : th) x.join();
+            }
+}
+inline char* dyn_smem() {
+    char* p = tls.blk->dyn.data();
+    return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+}
+}  // namespace emu
+
+#define threadIdx (emu::tls.tid)
+#define blockIdx (emu::tls.bid)
+#define gridDim (emu::tls.gdim)
+#define blockDim (emu::tls.bdim)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch([&] { kernel(__VA_ARGS__); }, grid, block, lds)
+
+static inline void __syncthreads() { emu::tls.blk->bar->arrive_and_wait(); }
+static inline float __shfl_xor(float v, int mask, int = 64) {
+    auto* w = emu::tls.wave;
+    w->fbuf[emu::tls.lane] = v;
+    w->bar.arrive_and_wait();
+    const float r = w->fbuf[emu::tls.lane ^ mask];
+    w->bar.arrive_and_wait();
+    return r;
+}
+static inline float __shfl(float v, int src, int = 64) {
+    auto* w = emu::tls.wave;
+    w->fbuf[emu::tls.lane] = v;
+    w->bar.arrive_and_wait();
+    const float r = w->fbuf[src & 63];
+    w->bar.arrive_and_wait();
+    return r;
+}
+static inline float atomicAdd(float* p, float v) {
+    auto* a = reinterpret_cast<std::atomic<float>*>(p);
+    float old = a->load();
+    while (!a->compare_exchange_weak(old, old + v)) {}
+    return old;
+}
+static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float emu_expf(float x) { return std::exp(x); }
+static inline float emu_logf(float x) { return std::log(x); }
+#define __expf emu_expf
+#define __logf emu_logf
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+
+typedef __attribute__((ext_vector_type(8))) short emu_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
+static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+    auto* w = emu::tls.wave;
+    const int l = emu::tls.lane;
+    for (int e = 0; e < 8; ++e) { w->a[l][e] = (uint16_t)a[e]; w->b[l][e] = (uint16_t)b[e]; }
+    w->bar.arrive_and_wait();
+    emu_f32x4 d = c;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const float av = __uint_as_float((uint32_t)w->a[row + 16 * (k >> 3)][k & 7] << 16);
+            const float bv = __uint_as_float((uint32_t)w->b[col + 16 * (k >> 3)][k & 7] << 16);
+            s = std::fma(av, bv, s);
+        }
+        d[r] = s;
+    }
+    w->bar.arrive_and_wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32_bf16(a, b, c)

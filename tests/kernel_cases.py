@@ -1,0 +1,325 @@
+"""Backend-agnostic kernel parity cases: each function runs one C-ABI kernel family through
+antmmf.hip.ops on `dev` and checks it against the CPU oracle (oracle/, plain torch fp32) on the same
+seeded inputs.  Used by tests/test_kernels_emu.py (CPU lane emulator, build container) and
+tests/test_kernels_gpu.py (real MI355X, `-m gpu`).
+
+Tolerances: fp32-I/O kernels 1e-5-class; bf16-I/O kernels are compared against the fp32 oracle evaluated
+on the SAME bf16-rounded inputs, with rtol 2e-2 and an atol of 2e-2 x the reference tensor's own scale
+(bf16 has 8 mantissa bits: 2^-8 = 3.9e-3 per rounding)."""
+import math
+
+import torch
+
+from oracle import losses as olosses
+from oracle import ops as oops
+
+BF = torch.bfloat16
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def check(name, got, want, rtol, atol_rel):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = float(want.abs().max()) if want.numel() else 1.0
+    atol = atol_rel * max(scale, 1e-30)
+    err = (got - want).abs()
+    bad = err > (atol + rtol * want.abs())
+    if bad.any() or not torch.isfinite(got).all():
+        idx = int(torch.argmax(err.flatten()))
+        raise AssertionError(f"{name}: {int(bad.sum())}/{bad.numel()} out of tolerance, max abs err {float(err.max()):.4g} "
+                             f"(ref scale {scale:.4g}) at flat index {idx}: got {float(got.flatten()[idx]):.6g} want {float(want.flatten()[idx]):.6g}")
+
+
+def q(t):  # bf16 quantise, keep fp32 container
+    return t.to(BF).float()
+
+
+# ------------------------------------------------------------------------------ LayerNorm
+def case_layernorm(ops, dev, dtype, rows=13, cols=128, eps=1e-5):
+    x = rnd((rows, cols), 1, 2.0) + 0.5
+    g = 1 + 0.1 * rnd((cols,), 2)
+    b = 0.1 * rnd((cols,), 3)
+    dy = rnd((rows, cols), 4)
+    dres = rnd((rows, cols), 5)
+    if dtype == BF:
+        x, dy, dres = q(x), q(dy), q(dres)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = oops.layer_norm(xr, gr, br, eps)
+    yr.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), eps)
+    dgam = torch.zeros(cols, device=dev)
+    dbet = torch.zeros(cols, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, dres.to(dev, dtype))
+    rt, at = (2e-2, 2e-2) if dtype == BF else (1e-5, 1e-5)
+    check("ln.y", y, yr, rt, at)
+    check("ln.mean", mean, x.mean(-1), 1e-5, 1e-5)
+    check("ln.dx", dx, xr.grad + dres, rt, at)
+    check("ln.dgamma", dgam, gr.grad, 1e-4 if dtype != BF else 2e-2, 1e-4 if dtype != BF else 2e-2)
+    check("ln.dbeta", dbet, br.grad, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------ activations / l2norm / colsum / movers
+def case_activations(ops, dev):
+    for act, fn in (("gelu", oops.gelu_erf), ("quick_gelu", oops.quick_gelu), ("relu", torch.relu)):
+        u = rnd((6, 40), 7, 2.0)
+        dg = rnd((6, 40), 8)
+        ur = u.clone().requires_grad_(True)
+        fn(ur).backward(dg)
+        check(f"act.{act}.fwd", ops.act_fwd(u.to(dev), act), fn(u), 1e-5, 1e-6)
+        check(f"act.{act}.bwd", ops.act_bwd(dg.to(dev), u.to(dev), act), ur.grad, 1e-4, 1e-5)
+        ub, dgb = q(u), q(dg)
+        check(f"act.{act}.fwd.bf16", ops.act_fwd(ub.to(dev, BF), act), fn(ub), 2e-2, 1e-2)
+        ur = ub.clone().requires_grad_(True)
+        fn(ur).backward(dgb)
+        check(f"act.{act}.bwd.bf16", ops.act_bwd(dgb.to(dev, BF), ub.to(dev, BF), act), ur.grad, 2e-2, 1e-2)
+
+
+def case_l2norm(ops, dev):
+    x = rnd((9, 70), 11)
+    dy = rnd((9, 70), 12)
+    xr = x.clone().requires_grad_(True)
+    yr = oops.l2_normalize(xr)
+    yr.backward(dy)
+    y, inv = ops.l2norm_fwd(x.to(dev), 1e-12)
+    check("l2.y", y, yr, 1e-5, 1e-6)
+    check("l2.dx", ops.l2norm_bwd(dy.to(dev), y, inv, torch.float32), xr.grad, 1e-4, 1e-5)
+    xb = q(x)
+    yb, invb = ops.l2norm_fwd(xb.to(dev, BF), 1e-12, out_dtype=torch.float32)  # bf16 tower output -> fp32 embedding
+    check("l2.y.bf16in", yb, oops.l2_normalize(xb), 1e-5, 1e-6)
+    dxb = ops.l2norm_bwd(dy.to(dev), yb, invb, BF)
+    xr = xb.clone().requires_grad_(True)
+    oops.l2_normalize(xr).backward(dy)
+    check("l2.dx.bf16", dxb, xr.grad, 2e-2, 1e-2)
+
+
+def case_movers(ops, dev):
+    x = q(rnd((37, 24), 13))
+    out = torch.full((24,), 0.5, device=dev)
+    ops.colsum_(out, x.to(dev, BF))
+    check("colsum", out, x.sum(0) + 0.5, 1e-5, 1e-5)
+    big = q(rnd((40, 48), 14))
+    view = big.to(dev, BF)[:, 8:24]  # strided view
+    out = torch.zeros(16, device=dev)
+    ops.colsum_(out, view)
+    check("colsum.strided", out, big[:, 8:24].sum(0), 1e-5, 1e-5)
+    w = q(rnd((70, 130), 15))
+    check("transpose", ops.transpose_bf16(w.to(dev, BF)), w.t(), 0, 0)
+    f = rnd((1000,), 16)
+    check("cast", ops.cast_bf16(f.to(dev)), q(f), 0, 0)
+    # patchify + assemble + split
+    img = rnd((2, 3, 16, 16), 17)
+    from oracle.towers import patchify as opatch
+
+    pt = ops.patchify(img.to(dev), 4, kpad=64, shift=0.5, scale=2.0)
+    ref = q((opatch(img, 4) - 0.5) * 2.0).reshape(-1, 48)
+    check("patchify", pt[:, :48], ref, 0, 0)
+    assert float(pt[:, 48:].abs().max()) == 0.0
+    d = 32
+    patch_tokens = q(rnd((2 * 16, d), 18))
+    cls, pos, bias = rnd((d,), 19), rnd((17, d), 20), rnd((d,), 21)
+    tok = ops.assemble_tokens(patch_tokens.to(dev, BF), cls.to(dev), pos.to(dev), bias.to(dev), 2, 16)
+    ref = torch.cat([cls.expand(2, 1, d), patch_tokens.view(2, 16, d) + bias], 1) + pos
+    check("assemble", tok, q(ref), 0, 1e-6)
+    check("split", ops.split_tokens(tok), tok[:, 1:].reshape(-1, d), 0, 0)
+    # embedding gather / scatter
+    ids = torch.randint(0, 50, (3, 5), generator=torch.Generator().manual_seed(1))
+    word, posT, typ = rnd((50, d), 22), rnd((12, d), 23), rnd((2, d), 24)
+    zero = torch.zeros(3, 5, dtype=torch.uint8)
+    zero[1, 3:] = 1
+    e = ops.embed_gather(ids.to(dev), word.to(dev), posT.to(dev), typ.to(dev), None, zero.to(dev), pos_offset=2)
+    ref = (word[ids] + posT[2:7][None] + typ[0]) * (1 - zero[..., None].float())
+    check("embed_gather", e, q(ref), 0, 1e-6)
+    dx = q(rnd((3, 5, d), 25))
+    dword = torch.zeros(50, d, device=dev)
+    ops.embed_scatter_add_(dword, dx.to(dev, BF), ids.to(dev), zero.to(dev))
+    ref = torch.zeros(50, d).index_add_(0, ids.flatten(), (dx * (1 - zero[..., None].float())).reshape(-1, d))
+    check("embed_scatter", dword, ref, 1e-5, 1e-5)
+    dpos = torch.zeros(12, d, device=dev)
+    ops.embed_scatter_add_(dpos, dx.to(dev, BF), None, None, seq=5, offset=2)
+    ref = torch.zeros(12, d)
+    ref[2:7] = dx.sum(0)
+    check("embed_scatter.pos", dpos, ref, 1e-5, 1e-5)
+
+
+def case_adamw(ops, dev):
+    n = 1000
+    p, g = rnd((n,), 30), rnd((n,), 31)
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
+    pd, m, v = p.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    shadow = torch.empty(n, dtype=BF, device=dev)
+    for step in (1, 2, 3):
+        ref_p.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step_(pd, (g * step * 4).to(dev), m, v, shadow, 1e-2, 0.9, 0.98, 1e-6, 0.05, step, grad_scale=0.25)
+    check("adamw.p", pd, ref_p.data, 1e-5, 1e-6)
+    check("adamw.shadow", shadow, q(pd.cpu()), 0, 0)
+    s = torch.zeros(1, device=dev)
+    ops.sumsq_(s, g.to(dev))
+    check("sumsq", s, (g * g).sum()[None], 1e-5, 1e-6)
+
+
+# ------------------------------------------------------------------------------ GEMM
+def case_gemm(ops, dev, I=70, J=40, R=72):
+    X = q(rnd((I, R), 40))
+    Wt = q(rnd((J, R), 41, R ** -0.5))
+    bias = rnd((J,), 42)
+    res = q(rnd((I, J), 43))
+    Xd, Wd = X.to(dev, BF), Wt.to(dev, BF)
+    pre = X @ Wt.t() + bias
+    # forward, bias + quick_gelu + residual + aux
+    aux = torch.empty(I, J, dtype=BF, device=dev)
+    y = ops.gemm(Xd, Wd, bias=bias.to(dev), act="quick_gelu", residual=res.to(dev, BF), aux=aux)
+    check("gemm.nt.aux", aux, pre, 2e-2, 1e-2)
+    check("gemm.nt.fused", y, oops.quick_gelu(pre) + res, 2e-2, 1e-2)
+    # fp32 output with alpha, accumulate
+    c = torch.ones(I, J, device=dev)
+    ops.gemm(Xd, Wd, out=c, alpha=0.5, accumulate=True)
+    check("gemm.nt.f32.acc", c, 1 + 0.5 * (X @ Wt.t()), 1e-3, 1e-3)
+    # dgrad: dX = dY W  (P = dY [I, J], Q = W [J, R] r-major, reduction over J), gated by act'(u)
+    dY = q(rnd((I, J), 44))
+    u = q(rnd((I, R), 45))
+    dx = ops.gemm(dY.to(dev, BF), Wd, q_rmajor=True, gate=u.to(dev, BF), act="gelu")
+    ur = u.clone().requires_grad_(True)
+    oops.gelu_erf(ur).backward(dY @ Wt)
+    check("gemm.nn.gate", dx, ur.grad, 2e-2, 1e-2)
+    # wgrad: dW = dY^T X  (both r-major, reduction over tokens), fp32 accumulate, with and without split-k
+    for split in (1, 2):
+        dw = torch.full((J, R), 0.25, device=dev)
+        ops.gemm(dY.to(dev, BF), Xd, out=dw, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+        check(f"gemm.tn.split{split}", dw, 0.25 + dY.t() @ X, 1e-3, 1e-3)
+    # strided views of a packed buffer (ld != width), output into a column slice
+    packed = torch.zeros(I, 3 * J, dtype=BF, device=dev)
+    ops.gemm(Xd, Wd, out=packed[:, J:2 * J])
+    check("gemm.nt.ldc", packed[:, J:2 * J], X @ Wt.t(), 2e-2, 1e-2)
+    assert float(packed[:, :J].float().abs().max()) == 0.0 and float(packed[:, 2 * J:].float().abs().max()) == 0.0
+
+
+def case_gemm_multitile(ops, dev):
+    """> 1 tile in every direction, K tail (R % 64 != 0), asymmetric operands (catches transposed C)."""
+    I, J, R = 150, 136, 200
+    X = q(rnd((I, R), 46))
+    Wt = q(rnd((J, R), 47, R ** -0.5))
+    y = ops.gemm(X.to(dev, BF), Wt.to(dev, BF), out_dtype=torch.float32)
+    check("gemm.multitile", y, X @ Wt.t(), 1e-3, 1e-3)
+    dY = q(rnd((I, J), 48))
+    dw = torch.zeros(J, R, device=dev)
+    ops.gemm(dY.to(dev, BF), X.to(dev, BF), out=dw, p_rmajor=True, q_rmajor=True, accumulate=True)
+    check("gemm.multitile.tn", dw, dY.t() @ X, 1e-3, 1e-3)
+    dx = ops.gemm(dY.to(dev, BF), Wt.to(dev, BF), q_rmajor=True, out_dtype=torch.float32)
+    check("gemm.multitile.nn", dx, dY @ Wt, 1e-3, 1e-3)
+
+
+# ------------------------------------------------------------------------------ attention
+def _attn_ref(qh, kh, vh, scale, key_bias):
+    return oops.attention_core(qh, kh, vh, scale, key_bias)
+
+
+def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packed=True, seed=50):
+    D = heads * 64
+    if packed and Nq == Nk:
+        qkv = q(rnd((B, Nq, 3 * D), seed))
+        qt, kt, vt = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        dqkv = qkv.to(dev, BF)
+        qd, kd, vd = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+    else:
+        qt, kt, vt = q(rnd((B, Nq, D), seed)), q(rnd((B, Nk, D), seed + 1)), q(rnd((B, Nk, D), seed + 2))
+        qd, kd, vd = qt.to(dev, BF), kt.to(dev, BF), vt.to(dev, BF)
+    key_bias = None
+    if bias_kind != "none":
+        lengths = torch.tensor([Nk, max(1, Nk // 3)] * B)[:B]
+        valid = torch.arange(Nk)[None, :] < lengths[:, None]
+        key_bias = torch.zeros(B, Nk).masked_fill(~valid, -10000.0 if bias_kind == "bert" else float("-inf"))
+    scale = 0.125
+    d_o = q(rnd((B, Nq, D), seed + 3))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qt, kt, vt))
+    ref = oops.merge_heads(_attn_ref(oops.split_heads(qr, heads), oops.split_heads(kr, heads), oops.split_heads(vr, heads), scale, key_bias))
+    ref.backward(d_o)
+    kb = None if key_bias is None else key_bias.to(dev)
+    o, lse = ops.attention_fwd(qd, kd, vd, heads, scale, kb)
+    tag = f"attn[{B},{heads},{Nq},{Nk},{bias_kind}]"
+    check(tag + ".o", o, ref, 2e-2, 2e-2)
+    s = torch.matmul(oops.split_heads(qt, heads), oops.split_heads(kt, heads).transpose(-1, -2)) * scale
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    check(tag + ".lse", lse, torch.logsumexp(s, -1), 1e-2, 1e-2)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, kb)
+    check(tag + ".dq", dq, qr.grad, 3e-2, 3e-2)
+    check(tag + ".dk", dk, kr.grad, 3e-2, 3e-2)
+    check(tag + ".dv", dv, vr.grad, 3e-2, 3e-2)
+
+
+# ------------------------------------------------------------------------------ losses
+def case_milnce(ops, dev, Bg=6, n=2, world=2):
+    """Row-sharded MIL-NCE over `world` simulated ranks == oracle loss on the tiled global matrix, and the
+    slab gradients reproduce d loss / d (text, clip) embeddings."""
+    D = 16
+    T = rnd((Bg, D), 60, 0.7).requires_grad_(True)
+    V = rnd((Bg * n, D), 61, 0.7).requires_grad_(True)
+    simi = torch.matmul(V.view(Bg, n, D), T.t()).permute(2, 0, 1)
+    mil = simi.unsqueeze(1).expand(Bg, n, Bg, n).reshape(Bg * n, Bg * n)
+    wv = rnd((Bg,), 62).abs() + 0.2
+    ref = olosses.mil_nce(mil, Bg, n, wv)
+    ref.backward()
+    Bl = Bg // world
+    total = 0.0
+    dT, dV = torch.zeros(Bg, D), torch.zeros(Bg * n, D)
+    Td, Vd = T.detach(), V.detach()
+    for r in range(world):
+        lo = r * Bl
+        Rm = (Td[lo:lo + Bl] @ Vd.t()).contiguous()
+        Vc = Vd.view(Bg, n, D)[lo:lo + Bl, n // 2]
+        Cm = (Vc @ Td.t()).contiguous()
+        loss_rows, denom = ops.milnce_fwd(Rm.to(dev), Cm.to(dev), n, lo)
+        coef = wv[lo:lo + Bl] / Bg
+        total = total + float((loss_rows.cpu() * coef).sum())
+        dR, dC = ops.milnce_bwd(Rm.to(dev), Cm.to(dev), denom, coef.to(dev), n, lo, out_dtype=torch.float32)
+        dR, dC = dR.cpu(), dC.cpu()
+        dT[lo:lo + Bl] += dR @ Vd
+        dV += dR.t() @ Td[lo:lo + Bl]
+        dV.view(Bg, n, D)[lo:lo + Bl, n // 2] += dC @ Td
+        dT += dC.t() @ Vc
+    assert abs(total - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (total, float(ref))
+    check("milnce.dT", dT, T.grad, 1e-4, 1e-5)
+    check("milnce.dV", dV, V.grad, 1e-4, 1e-5)
+
+
+def case_softmax_ce(ops, dev, Bg=8, world=2):
+    D = 16
+    Im = oops.l2_normalize(rnd((Bg, D), 70)).requires_grad_(True)
+    Tx = oops.l2_normalize(rnd((Bg, D), 71)).requires_grad_(True)
+    ls = torch.tensor(math.log(1 / 0.07), requires_grad=True)
+    ref, _ = olosses.clip_itc(Im, Tx, ls)
+    ref.backward()
+    Bl = Bg // world
+    total, dI, dTx, dls = 0.0, torch.zeros(Bg, D), torch.zeros(Bg, D), torch.zeros(1, device=dev)
+    Id, Td = Im.detach(), Tx.detach()
+    lsd = ls.detach().reshape(1).to(dev)
+    for r in range(world):
+        lo = r * Bl
+        for A, Bm, dA, dB in ((Id, Td, dI, dTx), (Td, Id, dTx, dI)):
+            x = (A[lo:lo + Bl] @ Bm.t()).contiguous()
+            loss_rows, lse = ops.softmax_ce_fwd(x.to(dev), lo, lsd)
+            coef = torch.full((Bl,), 0.5 / Bg)
+            total += float((loss_rows.cpu() * coef).sum())
+            dx = ops.softmax_ce_bwd(x.to(dev), lse, coef.to(dev), lo, lsd, dscale=dls, out_dtype=torch.float32).cpu()
+            dA[lo:lo + Bl] += dx @ Bm
+            dB += dx.t() @ A[lo:lo + Bl]
+    assert abs(total - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (total, float(ref))
+    check("ce.dI", dI, Im.grad, 1e-4, 1e-5)
+    check("ce.dT", dTx, Tx.grad, 1e-4, 1e-5)
+    check("ce.dlogscale", dls.cpu() * float(ls.exp()), ls.grad.reshape(1), 1e-4, 1e-5)
+    # CrossEn (scale 100, no learnable scale)
+    s = rnd((7, 7), 72, 0.02).requires_grad_(True)
+    refc = olosses.cross_en(s)
+    refc.backward()
+    lr, lse = ops.softmax_ce_fwd(s.detach().to(dev), 0, None, 100.0)
+    assert abs(float(lr.mean()) - float(refc)) < 1e-5 * max(1.0, abs(float(refc)))
+    dx = ops.softmax_ce_bwd(s.detach().to(dev), lse, torch.full((7,), 1 / 7.).to(dev), 0, None, 100.0, out_dtype=torch.float32)
+    check("crossen.dx", dx, s.grad, 1e-4, 1e-5)

@@ -1,0 +1,101 @@
+"""Run the kernel parity cases against the CPU lane emulation of the HIP kernels (tests/emu).
+
+This validates the kernels' index arithmetic (LDS layouts, MFMA fragment bookkeeping, guards,
+epilogues) in the GPU-less build container; hardware parity is tests/test_kernels_gpu.py."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+import kernel_cases as kc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+CSRC = os.path.join(ROOT, "ant-multi-modal-framework_amd", "csrc")
+
+
+def _stale():
+    if not os.path.isfile(EMU_LIB):
+        return True
+    t = os.path.getmtime(EMU_LIB)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "tests", "emu", "hip_emu.h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not os.path.isfile("/opt/rocm/lib/llvm/bin/clang++") and not os.environ.get("EMU_CXX"):
+        pytest.skip("no clang++ to build the emulator")
+    if _stale():
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    from antmmf.hip import _lib
+
+    old = os.environ.get("ANTMMF_HIP_LIB")
+    os.environ["ANTMMF_HIP_LIB"] = EMU_LIB
+    _lib.reset_for_tests()
+    from antmmf.hip import ops as hops
+
+    assert _lib.backend() == 0
+    yield hops
+    if old is None:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+    else:
+        os.environ["ANTMMF_HIP_LIB"] = old
+    _lib.reset_for_tests()
+
+
+DEV = torch.device("cpu")
+
+
+def test_layernorm(ops):
+    kc.case_layernorm(ops, DEV, torch.float32)
+    kc.case_layernorm(ops, DEV, torch.bfloat16)
+    kc.case_layernorm(ops, DEV, torch.float32, rows=5, cols=1024 + 512, eps=1e-12)
+
+
+def test_activations(ops):
+    kc.case_activations(ops, DEV)
+
+
+def test_l2norm(ops):
+    kc.case_l2norm(ops, DEV)
+
+
+def test_movers(ops):
+    kc.case_movers(ops, DEV)
+
+
+def test_adamw(ops):
+    kc.case_adamw(ops, DEV)
+
+
+def test_gemm(ops):
+    kc.case_gemm(ops, DEV)
+
+
+def test_gemm_multitile(ops):
+    kc.case_gemm_multitile(ops, DEV)
+
+
+def test_attention_self(ops):
+    kc.case_attention(ops, DEV, B=2, heads=2, Nq=17, Nk=17, bias_kind="none")
+
+
+def test_attention_masks(ops):
+    kc.case_attention(ops, DEV, B=2, heads=1, Nq=12, Nk=12, bias_kind="bert")
+    kc.case_attention(ops, DEV, B=2, heads=1, Nq=12, Nk=12, bias_kind="inf")
+
+
+def test_attention_cross_multichunk(ops):
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
+
+
+def test_milnce(ops):
+    kc.case_milnce(ops, DEV, Bg=6, n=2, world=2)
+    kc.case_milnce(ops, DEV, Bg=4, n=1, world=1)
+    kc.case_milnce(ops, DEV, Bg=3, n=3, world=1)
+
+
+def test_softmax_ce(ops):
+    kc.case_softmax_ce(ops, DEV)

@@ -1,0 +1,98 @@
+"""Hardware parity: every C-ABI kernel family on a real MI355X against the CPU oracle (-m gpu)."""
+import os
+
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from antmmf.hip import _lib
+
+    os.environ.pop("ANTMMF_HIP_LIB", None)
+    _lib.reset_for_tests()
+    from antmmf.hip import ops as hops
+
+    assert _lib.backend() == 1, "the GPU tests must run against the gfx950 library, not the emulator"
+    assert torch.cuda.is_available()
+    return hops
+
+
+DEV = torch.device("cuda:0")
+
+
+def test_layernorm(ops):
+    for dtype in (torch.float32, torch.bfloat16):
+        kc.case_layernorm(ops, DEV, dtype)
+        kc.case_layernorm(ops, DEV, dtype, rows=1031, cols=768, eps=1e-12)
+        kc.case_layernorm(ops, DEV, dtype, rows=517, cols=1024)
+        kc.case_layernorm(ops, DEV, dtype, rows=130, cols=4096)
+        kc.case_layernorm(ops, DEV, dtype, rows=77, cols=3072)
+
+
+def test_activations(ops):
+    kc.case_activations(ops, DEV)
+
+
+def test_l2norm(ops):
+    kc.case_l2norm(ops, DEV)
+
+
+def test_movers(ops):
+    kc.case_movers(ops, DEV)
+
+
+def test_adamw(ops):
+    kc.case_adamw(ops, DEV)
+
+
+def test_gemm(ops):
+    kc.case_gemm(ops, DEV)
+    kc.case_gemm(ops, DEV, I=513, J=260, R=328)
+    kc.case_gemm_multitile(ops, DEV)
+
+
+def test_gemm_large_linearity(ops):
+    """Full-size property check (BASELINE sizes; the oracle would take minutes): the GEMM is linear in P,
+    and agrees with an fp32 matmul of the same bf16 operands on a random sample of rows."""
+    I, J, R = 257 * 64, 4096, 1024
+    g = torch.Generator(device="cuda").manual_seed(3)
+    X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
+    W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
+    y = ops.gemm(X, W, out_dtype=torch.float32)
+    y2 = ops.gemm((X.float() * 2).bfloat16(), W, out_dtype=torch.float32)
+    torch.testing.assert_close(y2, 2 * y, rtol=1e-5, atol=1e-5)
+    rows = torch.randint(0, I, (64,), device=DEV)
+    ref = X[rows].float() @ W.float().t()
+    torch.testing.assert_close(y[rows], ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, heads=2, Nq=17, Nk=17, bias_kind="none"),
+    dict(B=3, heads=2, Nq=12, Nk=12, bias_kind="bert"),
+    dict(B=2, heads=2, Nq=12, Nk=12, bias_kind="inf"),
+    dict(B=2, heads=12, Nq=77, Nk=77, bias_kind="bert"),
+    dict(B=2, heads=12, Nq=197, Nk=197, bias_kind="none"),
+    dict(B=2, heads=16, Nq=257, Nk=257, bias_kind="none"),
+    dict(B=2, heads=2, Nq=21, Nk=77, bias_kind="bert", packed=False),
+    dict(B=2, heads=2, Nq=288, Nk=33, bias_kind="inf", packed=False),
+])
+def test_attention(ops, cfg):
+    kc.case_attention(ops, DEV, **cfg)
+
+
+def test_milnce(ops):
+    kc.case_milnce(ops, DEV, Bg=6, n=2, world=2)
+    kc.case_milnce(ops, DEV, Bg=4, n=1, world=1)
+    kc.case_milnce(ops, DEV, Bg=3, n=3, world=1)
+    kc.case_milnce(ops, DEV, Bg=512, n=1, world=4)
+    kc.case_milnce(ops, DEV, Bg=96, n=4, world=2)
+
+
+def test_softmax_ce(ops):
+    kc.case_softmax_ce(ops, DEV)
+    kc.case_softmax_ce(ops, DEV, Bg=640, world=4)
