@@ -1,0 +1,486 @@
+"""Autograd functions that put the HIP kernels behind torch's tape.
+
+Design (MI355X-first, sized for 288 GB HBM at per-GPU batch 1024):
+  * activations are bf16, parameters are fp32 masters with a bf16 compute shadow (antmmf.hip.arena);
+  * one autograd node per transformer LAYER (`transformer_layer`): it saves only x, the packed QKV,
+    the attention context + log-sum-exp, the mid-layer residual stream and the MLP pre-activation
+    (20 bytes per token-channel) and RECOMPUTES the cheap HBM-bound pieces (LayerNorm outputs,
+    GELU outputs) in backward -- the reference keeps every intermediate alive (~34 B / token-channel);
+  * weight gradients are accumulated by the wgrad GEMM straight into the fp32 gradient arena when the
+    parameter lives in one (the function then returns None for that input), otherwise returned.
+
+Reference modules replaced by `transformer_layer`:
+  "clip"  ResidualAttentionBlock   antmmf/modules/vision/backbone/clip/model.py:227-256
+  "bert"  BertLayer                antmmf/modules/vision/backbone/clip/modeling_bert.py:134-270
+  "m2"    torchscale EncoderLayer  prj/M2_Encoder/vlmo/torchscale/architecture/encoder.py:113-168
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+
+BF = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------ parameter helpers
+def compute_copy(p):
+    """bf16 compute copy of an fp32 master parameter (arena shadow if present, else cast now)."""
+    if p is None:
+        return None
+    s = getattr(p, "_antmmf_bf16", None)
+    if s is not None:
+        return s
+    if p.dtype == BF:
+        return p.detach()
+    return ops.cast_bf16(p.detach().contiguous())
+
+
+def f32(p):
+    return None if p is None else p.detach()
+
+
+class GradSink:
+    """Where weight gradients go: the parameter's slice of the fp32 gradient arena (accumulated in
+    place, autograd gets None) or a fresh fp32 tensor that is handed back to autograd."""
+
+    def __init__(self):
+        self._fresh = {}
+
+    def buf(self, p):
+        mg = getattr(p, "_antmmf_main_grad", None)
+        if mg is not None:
+            return mg
+        if id(p) not in self._fresh:
+            self._fresh[id(p)] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+        return self._fresh[id(p)]
+
+    def result(self, p, needs):
+        if p is None or not needs:
+            return None
+        if getattr(p, "_antmmf_main_grad", None) is not None:
+            return None
+        return self._fresh.get(id(p))
+
+
+def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
+    """dW += dy^T x  (W stored [out, in]);  for W stored [in, out] (CLIP `proj`) dW += x^T dy."""
+    if W is None or not W.requires_grad:
+        return
+    out = sink.buf(W)
+    tiles = ((out.shape[0] + 127) // 128) * ((out.shape[1] + 127) // 128)
+    tokens = dy2d.shape[0]
+    split = 1
+    if tiles < 256 and tokens >= 4096:
+        split = min(8, max(1, 512 // tiles), tokens // 2048)
+    if w_is_in_out:
+        ops.gemm(x2d, dy2d, out=out, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+    else:
+        ops.gemm(dy2d, x2d, out=out, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+
+
+def _bgrad(sink, b, dy2d):
+    if b is None or not b.requires_grad:
+        return
+    ops.colsum_(sink.buf(b), dy2d)
+
+
+# ------------------------------------------------------------------------------ generic ops
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, f32(weight), f32(bias), eps)
+        ctx.save_for_backward(x, mean, rstd, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, weight, bias = ctx.saved_tensors
+        sink = GradSink()
+        dg = sink.buf(weight) if weight.requires_grad else None
+        db = sink.buf(bias) if bias.requires_grad else None
+        dx = ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, f32(weight), dg, db)
+        return dx, sink.result(weight, ctx.needs_input_grad[1]), sink.result(bias, ctx.needs_input_grad[2]), None
+
+
+def layer_norm(x, weight, bias, eps):
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual).  weight_layout "oi": W is [out, in] (nn.Linear); "io": W is [in, out]
+    (CLIP `proj` / `text_projection`, used as x @ W)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, residual, weight_layout):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        W = compute_copy(weight)
+        io = weight_layout == "io"
+        n_out = W.shape[1] if io else W.shape[0]
+        aux = torch.empty(x2.shape[0], n_out, dtype=BF, device=x.device) if act else None
+        res2 = residual.reshape(-1, n_out) if residual is not None else None
+        y = ops.gemm(x2, W, q_rmajor=io, bias=f32(bias), act=act, residual=res2, aux=aux)
+        ctx.save_for_backward(x2, weight, bias, aux)
+        ctx.act, ctx.io, ctx.shp, ctx.has_res = act, io, shp, residual is not None
+        return y.view(*shp[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, aux = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        sink = GradSink()
+        du = ops.act_bwd(dy2, aux, ctx.act) if ctx.act else dy2
+        _wgrad(sink, weight, du, x2, w_is_in_out=ctx.io)
+        _bgrad(sink, bias, du)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            W = compute_copy(weight)
+            dx = ops.gemm(du, W, q_rmajor=not ctx.io).view(ctx.shp)
+        return (dx, sink.result(weight, ctx.needs_input_grad[1]), sink.result(bias, bias is not None and ctx.needs_input_grad[2]),
+                None, dy if ctx.has_res else None, None)
+
+
+def linear(x, weight, bias=None, act=None, residual=None, weight_layout="oi"):
+    return _Linear.apply(x, weight, bias, act, residual, weight_layout)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        y, inv = ops.l2norm_fwd(x, eps, out_dtype=torch.float32)
+        ctx.save_for_backward(y, inv)
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(dy.contiguous().float(), y, inv, ctx.in_dtype), None
+
+
+def l2_normalize(x, eps=1e-12):
+    """bf16 (or fp32) rows -> fp32 unit rows (the embeddings feed the fp32-accurate similarity path)."""
+    return _L2Norm.apply(x, eps)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_bias, heads, scale):
+        o, lse = ops.attention_fwd(q, k, v, heads, scale, key_bias)
+        ctx.save_for_backward(q, k, v, o, lse, key_bias)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse, key_bias = ctx.saved_tensors
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, lse, d_o.contiguous(), ctx.heads, ctx.scale, key_bias)
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads, scale, key_bias=None):
+    """softmax(scale q k^T + key_bias) v on [B, N, heads*64] bf16 tensors (views of a packed projection are fine)."""
+    return _Attention.apply(q, k, v, key_bias, heads, scale)
+
+
+def co_attention(q1, k1, v1, q2, k2, v2, heads, bias1=None, bias2=None):
+    """ViLBERT BertBiAttention core (antmmf/models/vilbert.py:360-400): stream-2 queries attend stream-1
+    keys/values and vice versa; two launches of the same kernel with the streams swapped."""
+    scale = 1.0 / math.sqrt(64)
+    return attention(q2, k1, v1, heads, scale, bias1), attention(q1, k2, v2, heads, scale, bias2)
+
+
+# ------------------------------------------------------------------------------ fused transformer layer
+@dataclass(frozen=True)
+class LayerSpec:
+    kind: str          # "clip" | "bert" | "m2"
+    heads: int
+    eps: float
+    act: str           # "quick_gelu" | "gelu"
+    packed_qkv: bool   # True: one [3d, d] in_proj (CLIP);  False: separate q/k/v weights
+
+
+# parameter slots of `transformer_layer` (absent ones are None)
+SLOTS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wq", "bq", "wk", "bk", "wv", "bv", "inner_w", "inner_b", "wo", "bo",
+         "ln2_w", "ln2_b", "w1", "b1", "ffn_w", "ffn_b", "w2", "b2")
+
+
+def _packed_qkv_weight(P, spec):
+    if spec.packed_qkv:
+        return compute_copy(P["wqkv"]), f32(P["bqkv"])
+    w = torch.cat([compute_copy(P["wq"]), compute_copy(P["wk"]), compute_copy(P["wv"])], dim=0)
+    b = torch.cat([f32(P["bq"]), f32(P["bk"]), f32(P["bv"])], dim=0)
+    return w, b
+
+
+class _TransformerLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, key_bias, spec, *params):
+        P = dict(zip(SLOTS, params))
+        B, N, d = x.shape
+        x2 = x.reshape(B * N, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = B * N
+        dev = x.device
+        scale = 64 ** -0.5
+        wqkv, bqkv = _packed_qkv_weight(P, spec)
+        pre_ln = spec.kind in ("clip", "m2")
+        st1 = None
+        if pre_ln:
+            h, m1, r1 = ops.layernorm_fwd(x2, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps)
+            st1 = (m1, r1)
+        else:
+            h = x2
+        qkv = ops.gemm(h, wqkv, bias=bqkv)  # [T, 3d]
+        del h
+        q3 = qkv.view(B, N, 3 * d)
+        o, lse = ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], spec.heads, scale, key_bias)
+        o2 = o.view(T, d)
+        st_in = None
+        if spec.kind == "m2":
+            o_n, mi, ri = ops.layernorm_fwd(o2, f32(P["inner_w"]), f32(P["inner_b"]), spec.eps)
+            st_in = (mi, ri)
+        else:
+            o_n = o2
+        x1 = ops.gemm(o_n, compute_copy(P["wo"]), bias=f32(P["bo"]), residual=x2)  # attention output + residual
+        del o_n
+        if pre_ln:
+            mid = x1  # residual stream after attention
+            h2, m2_, r2 = ops.layernorm_fwd(mid, f32(P["ln2_w"]), f32(P["ln2_b"]), spec.eps)
+            st2 = (m2_, r2)
+        else:  # bert: a = LN(s1)
+            mid = x1  # s1 (pre-LN sum)
+            h2, m2_, r2 = ops.layernorm_fwd(mid, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps)
+            st2 = (m2_, r2)
+        u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
+        g = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
+        st_f = None
+        if spec.kind == "m2":
+            g_n, mf, rf = ops.layernorm_fwd(g, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps)
+            st_f = (mf, rf)
+            del g
+        else:
+            g_n = g
+        res = mid if pre_ln else h2
+        y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
+        del g_n
+        st_y = None
+        s2 = None
+        if not pre_ln:
+            s2 = y
+            y, my, ry = ops.layernorm_fwd(s2, f32(P["ln2_w"]), f32(P["ln2_b"]), spec.eps)
+            st_y = (my, ry)
+        saved = [x2, qkv, o, lse, mid, u, key_bias]
+        for st in (st1, st_in, st2, st_f, st_y):
+            saved += list(st) if st is not None else [None, None]
+        saved.append(s2)
+        ctx.save_for_backward(*saved, *params)
+        ctx.spec, ctx.shape, ctx.nsaved = spec, (B, N, d), len(saved)
+        return y.view(B, N, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec = ctx.spec
+        B, N, d = ctx.shape
+        T = B * N
+        sv = ctx.saved_tensors
+        x2, qkv, o, lse, mid, u, key_bias = sv[:7]
+        (m1, r1, mi, ri, m2_, r2, mf, rf, my, ry) = sv[7:17]
+        s2 = sv[17]
+        params = sv[ctx.nsaved:]
+        P = dict(zip(SLOTS, params))
+        sink = GradSink()
+        pre_ln = spec.kind in ("clip", "m2")
+        scale = 64 ** -0.5
+        dy2 = dy.reshape(T, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+
+        def lnw(slot):  # accumulate LayerNorm parameter grads
+            w, b = P[slot + "_w"], P[slot + "_b"]
+            return (sink.buf(w) if w.requires_grad else None), (sink.buf(b) if b.requires_grad else None)
+
+        # ---- MLP half
+        if pre_ln:
+            ds2 = dy2
+        else:
+            dgw, dgb = lnw("ln2")
+            ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb)
+        g = ops.act_fwd(u, spec.act)
+        if spec.kind == "m2":
+            g_n, _, _ = ops.layernorm_fwd(g, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False)
+        else:
+            g_n = g
+        _wgrad(sink, P["w2"], ds2, g_n)
+        _bgrad(sink, P["b2"], ds2)
+        del g_n
+        w2 = compute_copy(P["w2"])
+        if spec.kind == "m2":
+            dgn = ops.gemm(ds2, w2, q_rmajor=True)
+            dgw, dgb = lnw("ffn")
+            dg = ops.layernorm_bwd(dgn, g, mf, rf, f32(P["ffn_w"]), dgw, dgb)
+            del dgn, g
+            du = ops.act_bwd(dg, u, spec.act)
+            del dg
+        else:
+            del g
+            du = ops.gemm(ds2, w2, q_rmajor=True, gate=u, act=spec.act)  # (ds2 W2) * act'(u)
+        ln_mid = ("ln2" if pre_ln else "ln1")
+        h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
+        _wgrad(sink, P["w1"], du, h2)
+        _bgrad(sink, P["b1"], du)
+        del h2
+        w1 = compute_copy(P["w1"])
+        dgw, dgb = lnw(ln_mid)
+        if pre_ln:
+            dh2 = ops.gemm(du, w1, q_rmajor=True)
+            dmid = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2)  # + residual path
+        else:
+            da = ops.gemm(du, w1, q_rmajor=True, residual=ds2)  # bert: a feeds the MLP and the residual
+            dmid = ops.layernorm_bwd(da, mid, m2_, r2, f32(P["ln1_w"]), dgw, dgb)
+        del du
+
+        # ---- attention half
+        o2 = o.view(T, d)
+        if spec.kind == "m2":
+            o_n, _, _ = ops.layernorm_fwd(o2, f32(P["inner_w"]), f32(P["inner_b"]), spec.eps, want_stats=False)
+        else:
+            o_n = o2
+        _wgrad(sink, P["wo"], dmid, o_n)
+        _bgrad(sink, P["bo"], dmid)
+        del o_n
+        do = ops.gemm(dmid, compute_copy(P["wo"]), q_rmajor=True)
+        if spec.kind == "m2":
+            dgw, dgb = lnw("inner")
+            do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
+        q3 = qkv.view(B, N, 3 * d)
+        dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
+        ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+        del do
+        dqkv2 = dqkv.view(T, 3 * d)
+        if pre_ln:
+            h, _, _ = ops.layernorm_fwd(x2, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps, want_stats=False)
+        else:
+            h = x2
+        if spec.packed_qkv:
+            _wgrad(sink, P["wqkv"], dqkv2, h)
+            _bgrad(sink, P["bqkv"], dqkv2)
+        else:
+            for i, nm in enumerate("qkv"):
+                sl = dqkv2[:, i * d:(i + 1) * d]
+                _wgrad(sink, P["w" + nm], sl, h)
+                _bgrad(sink, P["b" + nm], sl)
+        del h
+        wqkv, _ = _packed_qkv_weight(P, spec)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if pre_ln:
+                dh = ops.gemm(dqkv2, wqkv, q_rmajor=True)
+                dgw, dgb = lnw("ln1")
+                dx = ops.layernorm_bwd(dh, x2, m1, r1, f32(P["ln1_w"]), dgw, dgb, dres=dmid)
+            else:
+                dx = ops.gemm(dqkv2, wqkv, q_rmajor=True, residual=dmid)
+            dx = dx.view(B, N, d)
+        grads = [sink.result(p, p is not None and ctx.needs_input_grad[3 + i]) for i, p in enumerate(params)]
+        return (dx, None, None, *grads)
+
+
+def transformer_layer(x, spec, params, key_bias=None):
+    """x [B, N, d] bf16 -> [B, N, d]; `params` maps SLOTS names to fp32 master parameters."""
+    return _TransformerLayer.apply(x, key_bias, spec, *[params.get(s) for s in SLOTS])
+
+
+# ------------------------------------------------------------------------------ embeddings
+class _PatchEmbed(torch.autograd.Function):
+    """image [B, 3, H, W] -> tokens [B, G+1, d]: patch GEMM (conv with stride == kernel), [cls] row, + positional
+    embedding (clip/model.py:310-323; torchscale VisionEmbedding embedding.py:67-83 + positions 2.. :92-110)."""
+
+    @staticmethod
+    def forward(ctx, image, weight, bias, cls, pos, patch, shift, scale):
+        B = image.shape[0]
+        d = weight.shape[0]
+        kk = weight[0].numel()
+        kpad = ((kk + 63) // 64) * 64
+        patches = ops.patchify(image.contiguous(), patch, kpad, shift, scale)
+        w2 = compute_copy(weight).reshape(d, kk)
+        if kpad != kk:
+            w2 = torch.nn.functional.pad(w2, (0, kpad - kk))
+        tok = ops.gemm(patches, w2.contiguous())
+        G = patches.shape[0] // B
+        x = ops.assemble_tokens(tok, f32(cls).reshape(-1).contiguous(), f32(pos).contiguous() if pos is not None else None,
+                                f32(bias), B, G)
+        ctx.save_for_backward(patches, weight, bias, cls, pos)
+        ctx.dims = (B, G, d, kk, kpad)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        patches, weight, bias, cls, pos = ctx.saved_tensors
+        B, G, d, kk, kpad = ctx.dims
+        dx = dx.contiguous()
+        sink = GradSink()
+        dtok = ops.split_tokens(dx)
+        if weight.requires_grad:
+            dwp = torch.zeros(d, kpad, dtype=torch.float32, device=dx.device)
+            ops.gemm(dtok, patches, out=dwp, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=4)
+            sink.buf(weight).add_(dwp[:, :kk].reshape(weight.shape))
+        _bgrad(sink, bias, dtok)
+        if cls.requires_grad:
+            ops.colsum_(sink.buf(cls).view(-1), dx.view(B, (G + 1) * d)[:, :d])
+        if pos is not None and pos.requires_grad:
+            ops.colsum_(sink.buf(pos).view(-1), dx.view(B, (G + 1) * d))
+        ng = ctx.needs_input_grad
+        return (None, sink.result(weight, ng[1]), sink.result(bias, bias is not None and ng[2]), sink.result(cls, ng[3]),
+                sink.result(pos, pos is not None and ng[4]), None, None, None)
+
+
+def patch_embed(image, weight, bias, cls, pos, patch, shift=0.0, scale=1.0):
+    return _PatchEmbed.apply(image, weight, bias, cls, pos, patch, shift, scale)
+
+
+class _Embed(torch.autograd.Function):
+    """Sum of word / position / token-type lookups -> bf16 (BertEmbeddings clip_text_encoder.py:36-60 before its
+    LayerNorm; torchscale TextEmbedding + PositionalEmbedding with padded rows zeroed, encoder.py:350-386,440)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, type_table, zero_rows, pos_offset):
+        out = ops.embed_gather(ids.contiguous(), f32(word), f32(pos), f32(type_table), None, zero_rows, pos_offset)
+        ctx.save_for_backward(ids, word, pos, type_table, zero_rows)
+        ctx.pos_offset = pos_offset
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        ids, word, pos, type_table, zero_rows = ctx.saved_tensors
+        dx = dx.contiguous()
+        seq = ids.shape[1]
+        sink = GradSink()
+        if word.requires_grad:
+            ops.embed_scatter_add_(sink.buf(word), dx, ids.contiguous(), zero_rows)
+        if pos is not None and pos.requires_grad:
+            ops.embed_scatter_add_(sink.buf(pos), dx, None, zero_rows, seq=seq, offset=ctx.pos_offset)
+        if type_table is not None and type_table.requires_grad:
+            # token-type ids are all zero on this path: row 0 gets the column sum
+            tmp = torch.zeros(dx.shape[-1], dtype=torch.float32, device=dx.device)
+            d2 = dx.view(-1, dx.shape[-1])
+            if zero_rows is not None:
+                d2 = d2 * (1 - zero_rows.view(-1, 1).to(d2.dtype))
+            ops.colsum_(tmp, d2.contiguous())
+            sink.buf(type_table)[0].add_(tmp)
+        ng = ctx.needs_input_grad
+        return (None, sink.result(word, ng[1]), sink.result(pos, pos is not None and ng[2]),
+                sink.result(type_table, type_table is not None and ng[3]), None, None)
+
+
+def embed(ids, word, pos=None, type_table=None, zero_rows=None, pos_offset=0):
+    return _Embed.apply(ids, word, pos, type_table, zero_rows, pos_offset)

@@ -52,7 +52,7 @@ def test_adamw(ops):
 
 def test_gemm(ops):
     kc.case_gemm(ops, DEV)
-    kc.case_gemm(ops, DEV, I=513, J=260, R=328)
+    kc.case_gemm(ops, DEV, I=513, J=264, R=328)
     kc.case_gemm_multitile(ops, DEV)
 
 
