@@ -1,0 +1,122 @@
+"""Flat parameter arena + fused AdamW (MI355X memory layout for the training step).
+
+All parameters of a model live in ONE fp32 master buffer, with a same-shaped fp32 gradient buffer and a
+bf16 compute shadow; `nn.Parameter.data` / `.grad` become views.  Consequences:
+  * the wgrad GEMMs accumulate straight into the gradient arena (antmmf.hip.functional.GradSink);
+  * data-parallel gradient reduction is a handful of large RCCL all-reduces over contiguous memory
+    (sized for xGMI's per-link bandwidth) instead of DDP's per-bucket copies;
+  * the optimizer is one kernel launch per parameter group that also rewrites the bf16 shadow.
+Parameter groups keep the reference's semantics (lr / weight_decay per group:
+prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:482-542); groups are laid out contiguously.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+ALIGN = 64  # elements; keeps every view 16-B aligned in all three buffers
+
+
+class ParamArena:
+    def __init__(self, param_groups, device=None):
+        """param_groups: list of dicts with "params" (as torch optimizers take them)."""
+        seen, self.groups = set(), []
+        total = 0
+        for g in param_groups:
+            ps = []
+            for p in g["params"]:
+                if id(p) in seen or not p.requires_grad:
+                    continue
+                seen.add(id(p))
+                ps.append(p)
+            start = total
+            for p in ps:
+                total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.groups.append(dict(params=ps, start=start, end=total, opts={k: v for k, v in g.items() if k != "params"}))
+        if total == 0:
+            raise ValueError("ParamArena: no trainable parameters")
+        device = device or self.groups[0]["params"][0].device
+        self.master = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(total, dtype=torch.bfloat16, device=device)
+        off = 0
+        for g in self.groups:
+            for p in g["params"]:
+                n = p.numel()
+                view = self.master[off:off + n].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                p._antmmf_main_grad = self.grad[off:off + n].view(p.shape)
+                p._antmmf_bf16 = self.shadow[off:off + n].view(p.shape)
+                p.grad = p._antmmf_main_grad
+                off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.sync_shadow()
+
+    def sync_shadow(self):
+        ops.cast_bf16(self.master, out=self.shadow)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def grad_norm(self):
+        s = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
+        ops.sumsq_(s, self.grad)
+        return s.sqrt()
+
+    def allreduce_grads(self, group=None, bucket_bytes=512 << 20):
+        """SUM all-reduce of the gradient arena in large contiguous buckets (the 1/world average is folded
+        into the optimizer's grad_scale).  Returns the world size."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        world = dist.get_world_size(group)
+        if world == 1:
+            return 1
+        step = bucket_bytes // 4
+        handles = [dist.all_reduce(self.grad[i:i + step], group=group, async_op=True) for i in range(0, self.grad.numel(), step)]
+        for h in handles:
+            h.wait()
+        return world
+
+
+class HipAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) as one fused HIP kernel per
+    parameter group over the flat arena; also refreshes the bf16 compute shadow in the same pass."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.arena = ParamArena(self.param_groups)
+        self.exp_avg = torch.zeros_like(self.arena.master)
+        self.exp_avg_sq = torch.zeros_like(self.arena.master)
+        self._step = 0
+        self.grad_scale = 1.0  # set by the trainer: 1/world x clip coefficient
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._step += 1
+        a = self.arena
+        for g, seg in zip(self.param_groups, a.groups):
+            s, e = seg["start"], seg["end"]
+            if e == s:
+                continue
+            b1, b2 = g["betas"]
+            ops.adamw_step_(a.master[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.shadow[s:e], g["lr"], b1, b2,
+                            g["eps"], g["weight_decay"], self._step, self.grad_scale)
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["antmmf_arena"] = dict(step=self._step, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq)
+        return d
+
+    def load_state_dict(self, state_dict):
+        extra = state_dict.pop("antmmf_arena", None)
+        super().load_state_dict(state_dict)
+        if extra is not None:
+            self._step = extra["step"]
+            self.exp_avg.copy_(extra["exp_avg"])
+            self.exp_avg_sq.copy_(extra["exp_avg_sq"])

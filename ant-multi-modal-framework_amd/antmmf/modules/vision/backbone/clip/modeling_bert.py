@@ -1,0 +1,172 @@
+"""In-repo BERT on the MI355X kernels: same classes / parameter names as the reference's
+antmmf/modules/vision/backbone/clip/modeling_bert.py:66-534 (BertSelfAttention, BertSelfOutput, BertAttention,
+BertIntermediate, BertOutput, BertLayer, BertEncoder, BertPooler, BertModel) so state_dicts map 1:1.  Each
+BertLayer is one fused autograd node (antmmf.hip.functional.transformer_layer, kind "bert": post-LN, erf-GELU,
+additive -10000 key mask).  The sub-modules are parameter holders; their own forward is not on the path.
+
+Dropout: the fused layer implements p = 0 (eval, or *_dropout_prob = 0).  Training with p > 0 raises -- the
+flagship M2 path has p = 0 everywhere (torchscale config.py:14-17); see DESIGN.md "out of scope".
+"""
+import math
+
+import torch
+from torch import nn
+
+from antmmf.hip import functional as HF
+
+BertLayerNorm = torch.nn.LayerNorm
+
+
+def gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("hidden size must be a multiple of the number of attention heads")
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        self.all_head_size = config.hidden_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size // config.num_attention_heads != 64:
+            raise ValueError("the fused attention kernel is specialised for head_dim 64")
+        if config.hidden_act != "gelu":
+            raise NotImplementedError("BERT on this path uses the erf GELU (modeling_bert.py:31-37)")
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self._p_drop = max(config.hidden_dropout_prob, config.attention_probs_dropout_prob)
+        self._spec = HF.LayerSpec(kind="bert", heads=config.num_attention_heads, eps=config.layer_norm_eps, act="gelu", packed_qkv=False)
+
+    def _params(self):
+        a, o = self.attention, self.output
+        return dict(wq=a.self.query.weight, bq=a.self.query.bias, wk=a.self.key.weight, bk=a.self.key.bias,
+                    wv=a.self.value.weight, bv=a.self.value.bias, wo=a.output.dense.weight, bo=a.output.dense.bias,
+                    ln1_w=a.output.LayerNorm.weight, ln1_b=a.output.LayerNorm.bias,
+                    w1=self.intermediate.dense.weight, b1=self.intermediate.dense.bias,
+                    w2=o.dense.weight, b2=o.dense.bias, ln2_w=o.LayerNorm.weight, ln2_b=o.LayerNorm.bias)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        """hidden_states [B, N, d] bf16; attention_mask: additive key bias, [B, N] fp32 or the reference's
+        extended [B, 1, 1, N] form."""
+        if self.training and self._p_drop > 0:
+            raise NotImplementedError("fused BertLayer: dropout p > 0 in training mode is not implemented on the HIP path")
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is not supported on the HIP path")
+        kb = None
+        if attention_mask is not None:
+            kb = attention_mask.reshape(attention_mask.shape[0], -1).float().contiguous()
+        return HF.transformer_layer(hidden_states, self._spec, self._params(), kb)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.output_attentions = config.output_attentions
+        self.output_hidden_states = config.output_hidden_states
+        self.grad_checkpointing = False
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        if self.output_attentions:
+            raise NotImplementedError("attention maps never reach HBM on the fused path (output_attentions=True)")
+        all_hidden = ()
+        for layer in self.layer:
+            if self.output_hidden_states:
+                all_hidden = all_hidden + (hidden_states,)
+            hidden_states = layer(hidden_states, attention_mask, None)
+        outputs = (hidden_states,)
+        if self.output_hidden_states:
+            outputs = outputs + (all_hidden + (hidden_states,),)
+        return outputs
+
+
+class BertPooler(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden_states):
+        return torch.tanh(HF.linear(hidden_states[:, 0].contiguous(), self.dense.weight, self.dense.bias).float())
+
+
+class BertEmbeddings(nn.Module):
+    """word + position + token_type lookup -> LayerNorm (-> dropout)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, input_ids=None, inputs_embeds=None, token_type_ids=None, position_ids=None):
+        if inputs_embeds is not None or position_ids is not None:
+            raise NotImplementedError("the HIP embedding path takes token ids with default positions")
+        if token_type_ids is not None and bool((token_type_ids != 0).any()):
+            raise NotImplementedError("non-zero token_type_ids are only used by the stage-2 cross encoder (out of scope)")
+        x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight)
+        x = HF.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        if self.training and self.dropout.p > 0:
+            x = self.dropout(x)
+        return x
+
+
+class BertModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, BertLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()

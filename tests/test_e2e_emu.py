@@ -1,0 +1,40 @@
+"""End-to-end product model on the CPU lane emulator vs the reference's golden outputs (host logic + kernels)."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+import model_cases as mc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu():
+    from test_kernels_emu import _stale
+
+    if _stale():
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    from antmmf.hip import _lib
+
+    old = os.environ.get("ANTMMF_HIP_LIB")
+    os.environ["ANTMMF_HIP_LIB"] = EMU_LIB
+    _lib.reset_for_tests()
+    yield
+    if old is None:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+    else:
+        os.environ["ANTMMF_HIP_LIB"] = old
+    _lib.reset_for_tests()
+
+
+def test_univl_stage1_vs_reference(golden):
+    r = mc.case_univl_stage1(torch.device("cpu"), golden, "b4n1", 1)
+    print(r)
+
+
+def test_univl_stage1_two_clips(golden):
+    r = mc.case_univl_stage1(torch.device("cpu"), golden, "b3n2", 2)
+    print(r)
