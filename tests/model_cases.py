@@ -84,3 +84,91 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     assert n_checked > 50
     assert worst[0][0] < 0.15, f"gradient norms off: {worst[:5]}"
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
+
+
+# ------------------------------------------------------------------------------ M2
+M2_PRJ = os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder")
+if M2_PRJ not in sys.path:
+    sys.path.insert(0, M2_PRJ)
+
+TINY_M2 = dict(beit_version="base", encoder_embed_dim=128, out_embed_dim=64, encoder_layers=2, beit3_vl_layers=1,
+               image_size=32, patch_size=8, vocab_size=300, max_text_len=12, encoder_attention_heads=2)
+
+
+def build_tiny_m2(dev):
+    from vlmo.config import default_config
+    from vlmo.modules.vlmo_module import VLMo
+
+    cfg = default_config()
+    cfg.update(TINY_M2)
+    model = VLMo(cfg)
+    W.fill_module_(model)
+    return model.to(dev).train()
+
+
+def case_m2_towers(dev, golden, rtol=5e-2):
+    """Product VLMo.infer_image / infer_text + logits (bf16 HIP path) vs the reference's outputs, and gradients of the
+    reference-pinned scalar `pin` (make_golden.gen_e2e_m2)."""
+    g = golden("e2e_m2.pt")
+    model = build_tiny_m2(dev)
+    oi = model.infer_image({"image": [g["image"].to(dev)]})
+    ot = model.infer_text({"text_ids": g["text_ids"].to(dev), "text_masks": g["text_masks"].to(dev)})
+    check("m2.image_feats", oi["image_feats"], g["img.image_feats"], rtol, 5e-2)
+    for k in ("cls_feats", "cls_vlffn_feats"):
+        check(f"m2.img.{k}", oi[k], g[f"img.{k}"], rtol, 4e-2)
+        check(f"m2.txt.{k}", ot[k], g[f"txt.{k}"], rtol, 4e-2)
+    logits = model.logit_scale.exp() * oi["cls_feats"] @ ot["cls_feats"].t()
+    logits_vl = model.logit_vl_scale.exp() * oi["cls_vlffn_feats"] @ ot["cls_vlffn_feats"].t()
+    check("m2.logits", logits, g["logits"], rtol, 4e-2)
+    pin = (logits * W.data_tensor("m2.wl", (3, 3)).to(dev)).sum() + (logits_vl * W.data_tensor("m2.wvl", (3, 3)).to(dev)).sum()
+    pin.backward()
+    worst = []
+    for n, p in model.named_parameters():
+        if f"gnorm.{n}" not in g:
+            continue
+        assert p.grad is not None, f"no grad for {n}"
+        worst.append([abs(float(p.grad.float().norm()) - float(g[f"gnorm.{n}"])), n, float(p.grad.float().norm()), float(g[f"gnorm.{n}"])])
+        if f"grad.{n}" in g:
+            check(f"m2.grad.{n}", p.grad, g[f"grad.{n}"], 1e-1, 1e-1)
+    top = max(w[3] for w in worst)
+    kept = []
+    for w in worst:
+        if w[3] < 1e-6 * top:
+            assert w[2] < 1e-3 * top, f"{w[1]}: gradient should vanish, got norm {w[2]}"
+            continue
+        w[0] /= w[3]
+        kept.append(w)
+    kept.sort(reverse=True)
+    assert len(kept) > 50 and kept[0][0] < 0.15, f"gradient norms off: {kept[:5]}"
+    return dict(pin=float(pin), ref_pin=float(g["pin"]), worst_gnorm=kept[:3])
+
+
+def case_m2_itc_vs_oracle(dev):
+    """Product VLMo training step (sharded ITC, world 1) vs the CPU oracle's M2 ITC step on the same weights."""
+    from oracle import step as ostep
+
+    model = build_tiny_m2(dev)
+    img = (W.data_tensor("m2s.image", (4, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1)
+    ids = W.data_ints("m2s.ids", (4, 12), 1, 300)
+    lengths = torch.tensor([12, 5, 8, 3])
+    mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
+    ids = ids * mask
+    out = model({"image": [img.to(dev)], "text_ids": ids.to(dev), "text_masks": mask.to(dev)})
+    loss = out["losses"]["itc_loss"] + out["losses"]["itc_vl_loss"]
+    P = tiny_models.m2_params(requires_grad=True)
+    ref = ostep.m2_itc(P, img, ids, mask, heads=2, patch=8)
+    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])), (float(loss), float(ref["loss"]))
+    loss.backward()
+    ref["loss"].backward()
+    named = dict(model.named_parameters())
+    rels = []
+    for n, p in P.items():
+        if p.grad is None or n not in named or named[n].grad is None:
+            continue
+        rn = float(p.grad.norm())
+        if rn < 1e-6:
+            continue
+        rels.append((abs(float(named[n].grad.float().norm()) - rn) / rn, n))
+    rels.sort(reverse=True)
+    assert len(rels) > 50 and rels[0][0] < 0.2, rels[:5]
+    return dict(loss=float(loss), ref=float(ref["loss"]), worst=rels[:3])

@@ -35,6 +35,19 @@ def test_univl_stage1_vs_reference(golden):
     print(r)
 
 
+SLOW = pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="set ANTMMF_SLOW_TESTS=1 (each emulated e2e case takes 1-2 min)")
+
+
+@SLOW
 def test_univl_stage1_two_clips(golden):
     r = mc.case_univl_stage1(torch.device("cpu"), golden, "b3n2", 2)
     print(r)
+
+
+@SLOW
+def test_m2_towers_vs_reference(golden):
+    print(mc.case_m2_towers(torch.device("cpu"), golden))
+
+
+def test_m2_itc_step_vs_oracle():
+    print(mc.case_m2_itc_vs_oracle(torch.device("cpu")))
