@@ -215,6 +215,11 @@ def sumsq_(out, x):
 
 
 # ------------------------------------------------------------------------------ GEMM
+# bench.py sets GEMM_TRACE to a list: every launch is then bracketed by HIP events on the launch stream and
+# (start, end, flops, layout-tag) is appended -- the live per-launch timing behind bench.py's `roofline` object.
+GEMM_TRACE = None
+
+
 def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None,
          residual=None, aux=None, gate=None, accumulate=False, split_k=1):
     """out[i, j] = epi(alpha * sum_r P[i, r] Q[j, r]).  P is [I, R] (or [R, I] when p_rmajor), Q likewise.
@@ -239,10 +244,17 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
     for t, n in ((residual, "residual"), (aux, "aux"), (gate, "gate")):
         if t is not None and (t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1 or tuple(t.shape) != (I, J)):
             raise ValueError(f"gemm: bad {n}")
+    ev = None
+    if GEMM_TRACE is not None and _lib.backend() == 1:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _rc(_lib.load().antmmf_gemm_bf16(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0),
                                      int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias), ACT_IDS[act],
                                      _p(residual), ld(residual), _p(aux), ld(aux), _p(gate), ld(gate), int(accumulate),
                                      int(split_k), _stream()), "antmmf_gemm_bf16")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * I * J * R, ("tn" if p_rmajor else ("nn" if q_rmajor else "nt"))))
     return out
 
 

@@ -70,42 +70,10 @@ M2 = dict(d=128, heads=2, layers=2, vl_layers=1, patch=8, res=32, vocab=300, out
 
 
 def m2_shapes(c=M2):
-    d, s = c["d"], {}
-    s["logit_scale"] = ()
-    s["logit_vl_scale"] = ()
-    s["backbone.text_embed.weight"] = (c["vocab"], d)
-    s["backbone.vision_embed.mask_token"] = (1, 1, d)
-    s["backbone.vision_embed.cls_token"] = (1, 1, d)
-    s["backbone.vision_embed.proj.weight"] = (d, 3, c["patch"], c["patch"])
-    s["backbone.vision_embed.proj.bias"] = (d,)
-    s["backbone.encoder.embed_positions.A.weight"] = ((c["res"] // c["patch"]) ** 2 + 1 + 2, d)
-    s["backbone.encoder.embed_positions.B.weight"] = (c["max_src_pos"], d)
+    from oracle.shapes import m2_shapes as _shapes
 
-    def enc(prefix, nl):
-        for i in range(nl):
-            b = prefix + f"layers.{i}."
-            for br in "AB":
-                for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
-                    s[b + f"self_attn.{nm}.{br}.weight"] = (d, d)
-                    s[b + f"self_attn.{nm}.{br}.bias"] = (d,)
-                for ln in ("self_attn.inner_attn_ln", "self_attn_layer_norm", "final_layer_norm"):
-                    s[b + f"{ln}.{br}.weight"] = (d,)
-                    s[b + f"{ln}.{br}.bias"] = (d,)
-                s[b + f"ffn.{br}.fc1.weight"] = (4 * d, d)
-                s[b + f"ffn.{br}.fc1.bias"] = (4 * d,)
-                s[b + f"ffn.{br}.fc2.weight"] = (d, 4 * d)
-                s[b + f"ffn.{br}.fc2.bias"] = (d,)
-                s[b + f"ffn.{br}.ffn_layernorm.weight"] = (4 * d,)
-                s[b + f"ffn.{br}.ffn_layernorm.bias"] = (4 * d,)
-        for br in "AB":
-            s[prefix + f"layer_norm.{br}.weight"] = (d,)
-            s[prefix + f"layer_norm.{br}.bias"] = (d,)
-
-    enc("backbone.encoder.", c["layers"])
-    enc("backbone_vl.", c["vl_layers"])
-    for h in ("itc_text_proj", "itc_image_proj", "itc_vl_text_proj", "itc_vl_image_proj"):
-        s[h + ".fc.weight"] = (c["out"], d)
-    return s
+    return _shapes(d=c["d"], layers=c["layers"], vl_layers=c["vl_layers"], patch=c["patch"], res=c["res"], vocab=c["vocab"],
+                   out=c["out"], max_src_pos=c["max_src_pos"])
 
 
 def m2_params(expected_names=None, requires_grad=False):
