@@ -1,0 +1,256 @@
+"""CPU tests of the host-side mirror of the reference's plugin surface: registries, Configuration, the C-ABI library
+(loads + exports every symbol include/antmmf_hip.h declares; no compute), trainer plumbing, and the multi-process
+(gloo, world 2) communication helpers."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ant-multi-modal-framework_amd")
+
+
+def test_registry_and_module_registry():
+    from antmmf.common.registry import registry
+    from antmmf.modules.encoders import TextEncoder, VisualEncoder
+    from antmmf.modules.module_registry import ModuleRegistry
+
+    @registry.register_model("dummy_model_for_test")
+    class M:
+        pass
+
+    assert registry.get_model_class("dummy_model_for_test") is M
+    assert registry.get_model_class("nope") is None
+    registry.register("a.b.c", 5)
+    assert registry.get("a.b.c") == 5 and registry.get("a.b") == {"c": 5} and registry.get("zz", 7) == 7
+
+    @VisualEncoder.register()
+    class TinyVis(torch.nn.Module):
+        def __init__(self, width=3):
+            super().__init__()
+            self.out_dim = width
+
+    from antmmf.common.configuration import Configuration
+
+    enc = VisualEncoder(Configuration({"type": "TinyVis", "params": {"width": 9}}))
+    assert enc.module.out_dim == 9
+    with pytest.raises(ValueError):
+        TextEncoder.get("TinyVis")  # families keep separate tables
+    with pytest.raises(ValueError):
+        ModuleRegistry.register(3)
+
+
+def test_configuration_includes_overrides_freeze(tmp_path):
+    from antmmf.common.configuration import Configuration
+
+    (tmp_path / "base.yml").write_text("training_parameters:\n  batch_size: 4\n  lr: 0.1\nmodel_attributes:\n  univl:\n    hidden_size: 768\n")
+    (tmp_path / "child.yml").write_text("includes:\n- ./base.yml\ntraining_parameters:\n  batch_size: 8\n  dir: ${HOME}\n")
+    cfg = Configuration.from_file(str(tmp_path / "child.yml"))
+    assert cfg.training_parameters.batch_size == 8 and cfg.training_parameters.lr == 0.1
+    assert cfg.training_parameters.dir == os.environ["HOME"]
+    assert "includes" not in cfg
+    cfg.override_with_cmd_opts(["model_attributes.univl.hidden_size", "1024", "training_parameters.betas", "[0.9, 0.98]", "x.y", "abc"])
+    assert cfg.model_attributes.univl.hidden_size == 1024 and cfg.training_parameters.betas == [0.9, 0.98] and cfg.x.y == "abc"
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.training_parameters.batch_size = 1
+    cfg.defrost()
+    cfg.training_parameters.batch_size = 1
+    assert cfg.to_dict()["training_parameters"]["batch_size"] == 1
+    with pytest.raises(FileNotFoundError):
+        Configuration.from_file(str(tmp_path / "missing.yml"))
+
+
+def test_reference_style_yaml_with_defaults(tmp_path):
+    from antmmf.common.build import build_config
+    from antmmf.common.registry import registry
+
+    y = tmp_path / "c.yml"
+    y.write_text("model_attributes:\n  univl:\n    training_head_type: video_text_retrieval\n    arch_type: clip\n"
+                 "optimizer_attributes:\n  type: AdamW\n  params:\n    lr: 1e-5\n    betas: [0.9, 0.98]\n    weight_decay: 1e-4\n")
+    cfg = build_config(str(y), opts_override=["training_parameters.batch_size", "2"])
+    assert cfg.training_parameters.trainer == "base_trainer" and cfg.training_parameters.batch_size == 2
+    assert registry.get("config") is cfg
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    lib_path = os.path.join(PKG, "lib", "libantmmf_hip.so")
+    assert os.path.isfile(lib_path), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, "include", "antmmf_hip.h")).read()
+    names = re.findall(r"\bint\s+(antmmf_\w+)\s*\(", header)
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/antmmf_hip.h but not exported"
+    lib.antmmf_backend.restype = ctypes.c_int
+    assert lib.antmmf_backend() == 1 and lib.antmmf_abi_version() == 1
+    from antmmf.hip import _lib
+
+    assert set(names) == set(_lib._SIGNATURES), set(names) ^ set(_lib._SIGNATURES)
+
+
+def test_hip_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
+    from antmmf.hip import _lib, ops
+
+    monkeypatch.delenv("ANTMMF_HIP_LIB", raising=False)
+    _lib.reset_for_tests()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        ops.act_fwd(torch.zeros(8), "gelu")  # host tensor into the device library: loud failure, no fallback
+    monkeypatch.setenv("ANTMMF_HIP_LIB", "/nonexistent/libantmmf_hip.so")
+    _lib.reset_for_tests()
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load()
+    monkeypatch.delenv("ANTMMF_HIP_LIB")
+    _lib.reset_for_tests()
+
+
+# ------------------------------------------------------------------------------ multi-process (gloo, world 2)
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, port, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def _gather_case(rank, world):
+    import weightgen as W
+    from antmmf.utils import distributed_utils as du
+    from oracle import losses
+
+    t = W.data_tensor("gather.t", (world * 3, 8))[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    v = W.data_tensor("gather.v", (world * 3, 8))[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    gt = du.gather_tensor(t, method="cat", back_gradient=True, pad_tensors=True)
+    gv = du.gather_tensor(v, method="cat", back_gradient=True, pad_tensors=True)
+    loss = losses.mil_nce(gt @ gv.t(), world * 3, 1)
+    loss.backward()
+    ragged = du.gather_tensor(torch.full((rank + 1, 2), float(rank)), method="cat", pad_tensors=True)
+    stacked = du.gather_tensor(torch.tensor(float(rank)))
+    objs = du.all_gather({"rank": rank})
+    red = du.reduce_dict({"a": torch.tensor(float(rank + 1))})
+    return dict(loss=loss.detach(), dt=t.grad, dv=v.grad, ragged=ragged, stacked=stacked, objs=objs, red=float(red["a"]),
+                world=du.get_world_size(), main=du.is_main_process())
+
+
+def test_gather_tensor_matches_reference_two_ranks(golden):
+    """gather_tensor(back_gradient=True) over 2 gloo ranks == the fixture produced by the reference's GradientAllGather
+    (loss identical on both ranks, local grad = W x single-process grad slice)."""
+    g = golden("gather_w2.pt")
+    out = _spawn(_gather_case, 29641)
+    for r in range(2):
+        torch.testing.assert_close(out[r]["loss"], g[f"rank{r}.loss"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[r]["dt"], g[f"rank{r}.dt"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(out[r]["dv"], g[f"rank{r}.dv"], rtol=1e-4, atol=1e-6)
+        assert out[r]["ragged"].shape == (3, 2) and out[r]["ragged"][0, 0] == 0 and out[r]["ragged"][2, 0] == 1
+        assert out[r]["stacked"].tolist() == [0.0, 1.0]
+        assert out[r]["objs"] == [{"rank": 0}, {"rank": 1}]
+        assert out[r]["world"] == 2 and out[r]["main"] == (r == 0)
+    assert out[0]["red"] == 1.5
+
+
+def _sharded_loss_case(rank, world):
+    """Row-sharded MIL-NCE / ITC through the emulated kernels on 2 ranks."""
+    os.environ["ANTMMF_HIP_LIB"] = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+    import weightgen as W
+    from antmmf.hip import _lib, contrastive
+
+    _lib.reset_for_tests()
+    B, n, D = 3, 2, 16
+    T = torch.nn.functional.normalize(W.data_tensor("shard.t", (world * B, D)), dim=-1)
+    V = torch.nn.functional.normalize(W.data_tensor("shard.v", (world * B * n, D)), dim=-1)
+    t = T[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    v = V[rank * B * n:(rank + 1) * B * n].clone().requires_grad_(True)
+    loss = contrastive.mil_nce_sharded(t, v, n_clips=n)
+    loss.backward()
+    ls = torch.tensor(2.0, requires_grad=True)
+    i2 = T[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    t2 = V[::n][rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    l2 = contrastive.clip_itc_sharded(i2, t2, ls)
+    l2.backward()
+    return dict(loss=loss.detach(), dt=t.grad, dv=v.grad, itc=l2.detach(), di=i2.grad, dt2=t2.grad, dls=ls.grad)
+
+
+def test_sharded_losses_two_ranks_match_oracle():
+    import weightgen as W
+    from oracle import losses
+    from test_kernels_emu import _stale
+
+    if _stale():
+        import subprocess
+
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    world, B, n, D = 2, 3, 2, 16
+    out = _spawn(_sharded_loss_case, 29643)
+    T = torch.nn.functional.normalize(W.data_tensor("shard.t", (world * B, D)), dim=-1).requires_grad_(True)
+    V = torch.nn.functional.normalize(W.data_tensor("shard.v", (world * B * n, D)), dim=-1).requires_grad_(True)
+    simi = torch.matmul(V.view(world * B, n, D), T.t()).permute(2, 0, 1)
+    mil = simi.unsqueeze(1).expand(world * B, n, world * B, n).reshape(world * B * n, world * B * n)
+    ref = losses.mil_nce(mil, world * B, n)
+    ref.backward()
+    I2 = T.detach().clone().requires_grad_(True)
+    T2 = V.detach()[::n].clone().requires_grad_(True)
+    ls = torch.tensor(2.0, requires_grad=True)
+    ref2, _ = losses.clip_itc(I2, T2, ls)
+    ref2.backward()
+    for r in range(world):
+        torch.testing.assert_close(out[r]["loss"], ref.detach(), rtol=1e-5, atol=1e-6)
+        # W x the single-process gradient, as the reference's gradient all-gather yields before DDP's 1/W
+        torch.testing.assert_close(out[r]["dt"], world * T.grad[r * B:(r + 1) * B], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(out[r]["dv"], world * V.grad[r * B * n:(r + 1) * B * n], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(out[r]["itc"], ref2.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[r]["di"], world * I2.grad[r * B:(r + 1) * B], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(out[r]["dt2"], world * T2.grad[r * B:(r + 1) * B], rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(out[0]["dls"] + out[1]["dls"], world * ls.grad, rtol=1e-3, atol=1e-6)
+
+
+def _trainer_case(rank, world):
+    from antmmf.common.configuration import Configuration
+    from antmmf.common.registry import registry
+    from antmmf.models.base_model import BaseModel
+    from antmmf.structures.sample import SampleList
+    from antmmf.trainers.build import build_trainer
+
+    @registry.register_model("toy_contrastive")
+    class Toy(BaseModel):
+        def build(self):
+            self.lin = torch.nn.Linear(4, 4)
+
+        def forward(self, sample_list):
+            y = self.lin(sample_list["image_data"])
+            return {"losses": {"toy_loss": ((y - sample_list["caption_target"]) ** 2).mean()}}
+
+    cfg = Configuration({
+        "training_parameters": {"trainer": "base_trainer", "device": "cpu", "max_iterations": 6, "log_interval": 100, "seed": 3,
+                                "clip_gradients": True, "max_grad_l2_norm": 10.0},
+        "optimizer_attributes": {"type": "SGD", "params": {"lr": 0.1}},
+        "model_attributes": {"toy_contrastive": {}},
+    })
+    g = torch.Generator().manual_seed(100 + rank)
+    batches = [SampleList(image_data=torch.randn(5, 4, generator=g), caption_target=torch.randn(5, 4, generator=g)) for _ in range(8)]
+    tr = build_trainer(cfg, batches)
+    tr.load()
+    meters = tr.train()
+    w = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
+    return dict(iters=tr.current_iteration, w=w, loss=meters["toy_loss"])
+
+
+def test_base_trainer_data_parallel_two_ranks():
+    out = _spawn(_trainer_case, 29645)
+    assert out[0]["iters"] == 6 and out[1]["iters"] == 6  # one increment per batch
+    torch.testing.assert_close(out[0]["w"], out[1]["w"])  # replicas stay in sync (broadcast init + averaged grads)
