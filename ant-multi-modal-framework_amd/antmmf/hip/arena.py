@@ -54,6 +54,9 @@ class ParamArena:
 
     def sync_shadow(self):
         ops.cast_bf16(self.master, out=self.shadow)
+        from .functional import bump_weight_version
+
+        bump_weight_version()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -103,6 +106,9 @@ class HipAdamW(torch.optim.Optimizer):
             b1, b2 = g["betas"]
             ops.adamw_step_(a.master[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.shadow[s:e], g["lr"], b1, b2,
                             g["eps"], g["weight_decay"], self._step, self.grad_scale)
+        from .functional import bump_weight_version
+
+        bump_weight_version()
         return loss
 
     def zero_grad(self, set_to_none=False):

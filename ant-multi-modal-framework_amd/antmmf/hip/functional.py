@@ -41,6 +41,38 @@ def f32(p):
     return None if p is None else p.detach()
 
 
+_T_CACHE_VERSION = [0]
+
+
+def bump_weight_version():
+    """Called by the optimizer after every parameter update: invalidates the cached transposed weight copies."""
+    _T_CACHE_VERSION[0] += 1
+
+
+def compute_copy_t(p):
+    """bf16 TRANSPOSE of a 2-D master weight ([out, in] -> [in, out]); lets dgrad (dX = dY W) run the all-r-contiguous
+    LDS-DMA GEMM.  Cached on the parameter until the next optimizer step (weights are tiny next to activations)."""
+    ver = _T_CACHE_VERSION[0]
+    c = getattr(p, "_antmmf_bf16_t", None)
+    if c is not None and c[0] == ver and getattr(p, "_antmmf_main_grad", None) is not None:
+        return c[1]
+    t = ops.transpose_bf16(compute_copy(p).contiguous())
+    try:
+        p._antmmf_bf16_t = (ver, t)
+    except AttributeError:
+        pass
+    return t
+
+
+def dgrad(dy2d, weight, weight_layout="oi", **epi):
+    """dX = dY W for W stored [out, in] ("oi") or dX = dY W^T for W stored [in, out] ("io")."""
+    if weight_layout == "io":
+        return ops.gemm(dy2d, compute_copy(weight), **epi)          # Q = W [in][out]: already r-contiguous
+    if torch.is_tensor(weight) and isinstance(weight, torch.nn.Parameter):
+        return ops.gemm(dy2d, compute_copy_t(weight), **epi)        # Q = W^T [in][out]
+    return ops.gemm(dy2d, weight, q_rmajor=True, **epi)             # ad-hoc bf16 tensor (e.g. concatenated qkv)
+
+
 class GradSink:
     """Where weight gradients go: the parameter's slice of the fp32 gradient arena (accumulated in
     place, autograd gets None) or a fresh fp32 tensor that is handed back to autograd."""
@@ -141,8 +173,7 @@ class _Linear(torch.autograd.Function):
         _bgrad(sink, bias, du)
         dx = None
         if ctx.needs_input_grad[0]:
-            W = compute_copy(weight)
-            dx = ops.gemm(du, W, q_rmajor=not ctx.io).view(ctx.shp)
+            dx = dgrad(du, weight, "io" if ctx.io else "oi").view(ctx.shp)
         return (dx, sink.result(weight, ctx.needs_input_grad[1]), sink.result(bias, bias is not None and ctx.needs_input_grad[2]),
                 None, dy if ctx.has_res else None, None)
 
@@ -323,9 +354,8 @@ class _TransformerLayer(torch.autograd.Function):
         _wgrad(sink, P["w2"], ds2, g_n)
         _bgrad(sink, P["b2"], ds2)
         del g_n
-        w2 = compute_copy(P["w2"])
         if spec.kind == "m2":
-            dgn = ops.gemm(ds2, w2, q_rmajor=True)
+            dgn = dgrad(ds2, P["w2"])
             dgw, dgb = lnw("ffn")
             dg = ops.layernorm_bwd(dgn, g, mf, rf, f32(P["ffn_w"]), dgw, dgb)
             del dgn, g
@@ -333,19 +363,18 @@ class _TransformerLayer(torch.autograd.Function):
             del dg
         else:
             del g
-            du = ops.gemm(ds2, w2, q_rmajor=True, gate=u, act=spec.act)  # (ds2 W2) * act'(u)
+            du = dgrad(ds2, P["w2"], gate=u, act=spec.act)  # (ds2 W2) * act'(u)
         ln_mid = ("ln2" if pre_ln else "ln1")
         h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
         _wgrad(sink, P["w1"], du, h2)
         _bgrad(sink, P["b1"], du)
         del h2
-        w1 = compute_copy(P["w1"])
         dgw, dgb = lnw(ln_mid)
         if pre_ln:
-            dh2 = ops.gemm(du, w1, q_rmajor=True)
+            dh2 = dgrad(du, P["w1"])
             dmid = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2)  # + residual path
         else:
-            da = ops.gemm(du, w1, q_rmajor=True, residual=ds2)  # bert: a feeds the MLP and the residual
+            da = dgrad(du, P["w1"], residual=ds2)  # bert: a feeds the MLP and the residual
             dmid = ops.layernorm_bwd(da, mid, m2_, r2, f32(P["ln1_w"]), dgw, dgb)
         del du
 
@@ -358,7 +387,7 @@ class _TransformerLayer(torch.autograd.Function):
         _wgrad(sink, P["wo"], dmid, o_n)
         _bgrad(sink, P["bo"], dmid)
         del o_n
-        do = ops.gemm(dmid, compute_copy(P["wo"]), q_rmajor=True)
+        do = dgrad(dmid, P["wo"])
         if spec.kind == "m2":
             dgw, dgb = lnw("inner")
             do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
@@ -381,15 +410,18 @@ class _TransformerLayer(torch.autograd.Function):
                 _wgrad(sink, P["w" + nm], sl, h)
                 _bgrad(sink, P["b" + nm], sl)
         del h
-        wqkv, _ = _packed_qkv_weight(P, spec)
         dx = None
         if ctx.needs_input_grad[0]:
+            if spec.packed_qkv:
+                wqkv_t = compute_copy_t(P["wqkv"])                                   # [d, 3d]
+            else:
+                wqkv_t = torch.cat([compute_copy_t(P["wq"]), compute_copy_t(P["wk"]), compute_copy_t(P["wv"])], dim=1)
             if pre_ln:
-                dh = ops.gemm(dqkv2, wqkv, q_rmajor=True)
+                dh = ops.gemm(dqkv2, wqkv_t)
                 dgw, dgb = lnw("ln1")
                 dx = ops.layernorm_bwd(dh, x2, m1, r1, f32(P["ln1_w"]), dgw, dgb, dres=dmid)
             else:
-                dx = ops.gemm(dqkv2, wqkv, q_rmajor=True, residual=dmid)
+                dx = ops.gemm(dqkv2, wqkv_t, residual=dmid)
             dx = dx.view(B, N, d)
         grads = [sink.result(p, p is not None and ctx.needs_input_grad[3 + i]) for i, p in enumerate(params)]
         return (dx, None, None, *grads)

@@ -76,6 +76,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // Conflict-free for ds_read_b128 MFMA fragment reads (16 consecutive rows x one slot per 16-lane group).
 __device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) ^ (row >> 3)) & 7; }
 
+// Asynchronous 16-B-per-lane global -> LDS copy (global_load_lds_dwordx4, "LDS-DMA"): the wave's 64 x 16 B land
+// CONTIGUOUSLY at lds_wave_base + lane * 16 (the destination is wave-uniform base + lane offset, not a per-lane
+// scatter); the source address is per lane.  Completion is tracked by vmcnt.
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    std::memcpy(lds_wave_base + emu::tls.lane * 16, gsrc, 16);
+}
+__device__ __forceinline__ void glds_wait_all() {}
+#else
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
 // activation ids shared with the host side (include/antmmf_hip.h)
 #define ANTMMF_ACT_NONE 0
 #define ANTMMF_ACT_GELU_ERF 1    // 0.5 x (1 + erf(x/sqrt2))   (BERT, torchscale)

@@ -89,6 +89,53 @@ __device__ __forceinline__ void store_rm(char* lds, const uint4 (&v)[4]) {
     }
 }
 
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[4][4], int i0, int j0, int wi, int wj, int l15, int grp, bool splitk) {
+    // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = i0 + wi * 64 + it * 16 + l15;
+        if (i >= g.I) continue;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = j0 + wj * 64 + jt * 16 + grp * 4;
+            if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
+            float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
+            if (g.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (g.gate) {
+                const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
+                v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
+                v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+            } else if (g.act != ANTMMF_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
+            }
+            if (g.residual) {
+                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                v[0] += bf_lo(u.x); v[1] += bf_hi(u.x); v[2] += bf_lo(u.y); v[3] += bf_hi(u.y);
+            }
+            if (g.c_dtype == ANTMMF_BF16) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (long)i * g.ldc + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            } else {
+                float* cp = reinterpret_cast<float*>(g.C) + (long)i * g.ldc + j;
+                if (splitk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
+                } else if (g.accumulate) {
+                    float4 o = *reinterpret_cast<float4*>(cp);
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
 template <bool PT, bool QT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     ANTMMF_DYN_LDS(char, smem);  // [2 buffers][P tile 16 KiB | Q tile 16 KiB]
@@ -156,51 +203,78 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         cur ^= 1;
     }
 
-    // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt)
-    const bool splitk = gridDim.z > 1;
+    gemm_epilogue(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
+}
+
+// ---- LDS-DMA variant for the all-r-contiguous layout (forward; dgrad against a pre-transposed weight) ----
+// Same tile / fragment / epilogue code; operand tiles reach LDS with global_load_lds_dwordx4 instead of through
+// VGPRs + ds_write_b128 (the VGPR->LDS store path, ~79 B/clk/CU, is what bounds the register-staged kernel: 32 KiB
+// per K-step vs 512 MFMA cycles).  The DMA writes lane-linearly, so the slot swizzle is applied on the SOURCE
+// address: LDS (row, physical slot p) is filled from global (row, p ^ lds_swz(row)) -- same 128-B line, coalescing
+// untouched.  Rows past the matrix edge are clamped (their outputs are never stored); requires R % 64 == 0.
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int r0, char* lds, int wave, int lane) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = i0 + wi * 64 + it * 16 + l15;
-        if (i >= g.I) continue;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = j0 + wj * 64 + jt * 16 + grp * 4;
-            if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
-            float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
-            if (g.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            if (g.gate) {
-                const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
-                v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
-                v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
-            } else if (g.act != ANTMMF_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
-            }
-            if (g.residual) {
-                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
-                v[0] += bf_lo(u.x); v[1] += bf_hi(u.x); v[2] += bf_lo(u.y); v[3] += bf_hi(u.y);
-            }
-            if (g.c_dtype == ANTMMF_BF16) {
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + (long)i * g.ldc + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            } else {
-                float* cp = reinterpret_cast<float*>(g.C) + (long)i * g.ldc + j;
-                if (splitk) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
-                } else if (g.accumulate) {
-                    float4 o = *reinterpret_cast<float4*>(cp);
-                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
-                    *reinterpret_cast<float4*>(cp) = o;
-                } else {
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int chunk = wave * 4 + q;                 // 16 chunks of 8 rows (1 KiB each)
+        const int row = chunk * 8 + (lane >> 3), pslot = lane & 7;
+        int gr = row0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        glds16(base + (long)gr * ld + r0 + ((pslot ^ lds_swz(row)) << 3), lds + chunk * 1024);
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tiles_j = (g.J + 127) >> 7;
+    const int i0 = (wgid / tiles_j) << 7, j0 = (wgid % tiles_j) << 7;
+    const int nk = g.R >> 6;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    dma_tile(g.P, g.ldp, i0, g.I, 0, smem, wave, lane);
+    dma_tile(g.Q, g.ldq, j0, g.J, 0, smem + 16384, wave, lane);
+    glds_wait_all();
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            char* nb = smem + (cur ^ 1) * 32768;
+            dma_tile(g.P, g.ldp, i0, g.I, (kt + 1) << 6, nb, wave, lane);
+            dma_tile(g.Q, g.ldq, j0, g.J, (kt + 1) << 6, nb + 16384, wave, lane);
+        }
+        const char* ps = smem + cur * 32768;
+        const char* qs = ps + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t qa[4], pb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int qrow = wj * 64 + t * 16 + l15;
+                qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + qrow * 128 + (((kk * 4 + grp) ^ lds_swz(qrow)) << 4));
+                const int prow = wi * 64 + t * 16 + l15;
+                pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + prow * 128 + (((kk * 4 + grp) ^ lds_swz(prow)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        }
+        glds_wait_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue(g, acc, i0, j0, wi, wj, l15, grp, false);
 }
 
 // C ABI: see include/antmmf_hip.h for the contract.
@@ -240,9 +314,11 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
+    if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, block, lds, stream, g);
+    else if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
     else if (!p_rmajor && q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, stream, g);
     else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
     return antmmf_check_launch();

@@ -214,6 +214,16 @@ def case_gemm_multitile(ops, dev):
     check("gemm.multitile.tn", dw, dY.t() @ X, 1e-3, 1e-3)
     dx = ops.gemm(dY.to(dev, BF), Wt.to(dev, BF), q_rmajor=True, out_dtype=torch.float32)
     check("gemm.multitile.nn", dx, dY @ Wt, 1e-3, 1e-3)
+    # R % 64 == 0 with both operands r-contiguous takes the LDS-DMA kernel (row clamping at the ragged edges)
+    I, J, R = 150, 136, 192
+    X = q(rnd((I, R), 49))
+    Wt = q(rnd((J, R), 50, R ** -0.5))
+    bias = rnd((J,), 51)
+    res = q(rnd((I, J), 52))
+    y = ops.gemm(X.to(dev, BF), Wt.to(dev, BF), bias=bias.to(dev), act="gelu", residual=res.to(dev, BF))
+    check("gemm.dma.fused", y, oops.gelu_erf(X @ Wt.t() + bias) + res, 2e-2, 1e-2)
+    y = ops.gemm(X.to(dev, BF), Wt.to(dev, BF), out_dtype=torch.float32)
+    check("gemm.dma.f32", y, X @ Wt.t(), 1e-3, 1e-3)
 
 
 # ------------------------------------------------------------------------------ attention
