@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--workload", default="l14", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="pairs in the CPU-oracle sample")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="pairs in the CPU-oracle sample")
     return ap.parse_args()
 
 
@@ -65,8 +65,8 @@ def synthetic_batch(cfg, batch, device, rank):
     return {"image": [img], "text_ids": ids, "text_masks": mask}
 
 
-def cpu_baseline(cfg, pairs):
-    """The CPU oracle's M2 ITC step (fwd + bwd) on `pairs` pairs of the same shapes; returns pairs/s."""
+def _cpu_baseline_worker(cfg, pairs, q):
+    """The CPU oracle's M2 ITC step (fwd + bwd, fp32) on `pairs` pairs of the same shapes; puts pairs/s on `q`."""
     from oracle import step as ostep
     from oracle.shapes import m2_shapes
 
@@ -82,23 +82,35 @@ def cpu_baseline(cfg, pairs):
         elif len(s) == 1:
             t = torch.ones(s) if ("layer_norm" in k or "layernorm" in k or "_ln" in k) and k.endswith("weight") else torch.zeros(s)
         else:
-            t = torch.randn(s, generator=g) * 0.02
+            t = torch.empty(s).uniform_(-0.03, 0.03, generator=g)
         P[k] = t.requires_grad_(True)
     heads = cfg["encoder_embed_dim"] // 64
     img = torch.rand(pairs, 3, cfg["image_size"], cfg["image_size"], generator=g)
     ids = torch.randint(1, cfg["vocab_size"], (pairs, cfg["max_text_len"]), generator=g)
     mask = torch.ones(pairs, cfg["max_text_len"], dtype=torch.long)
-    best = None
-    for it in range(2):  # first pass warms the allocator / thread pool
-        t0 = time.perf_counter()
-        out = ostep.m2_itc(P, img, ids, mask, heads=heads, patch=cfg["patch_size"])
-        out["loss"].backward()
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-        for p in P.values():
-            p.grad = None
-    return dict(value=round(pairs / best, 3), unit="pairs/s", cores=cores, kind="port",
-                sample=f"oracle.step.m2_itc fwd+bwd, fp32, {pairs} pairs of the same shapes, best of 2, {cores} threads")
+    t0 = time.perf_counter()
+    out = ostep.m2_itc(P, img, ids, mask, heads=heads, patch=cfg["patch_size"])
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    q.put(dict(value=round(pairs / dt, 4), unit="pairs/s", cores=cores, kind="port",
+               sample=f"oracle.step.m2_itc fwd+bwd (no optimizer), fp32, {pairs} pairs of the same shapes, one pass of {dt:.1f} s, {cores} threads"))
+
+
+def cpu_baseline(cfg, pairs, limit_s=300):
+    """Runs the CPU sample in a child process with a hard wall-clock limit so the bench line is always printed."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_baseline_worker, args=(cfg, pairs, q))
+    p.start()
+    p.join(limit_s)
+    if p.is_alive():
+        p.terminate()
+        p.join()
+        return dict(value=None, unit="pairs/s", cores=os.cpu_count() or 1, kind="port",
+                    sample=f"oracle.step.m2_itc on {pairs} pairs did not finish within the {limit_s} s bound on this host")
+    return q.get() if not q.empty() else None
 
 
 def main():
@@ -157,7 +169,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3

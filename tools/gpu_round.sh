@@ -12,7 +12,7 @@ timeout 600 python bench.py --batch 256 --steps 3 --warmup 1 --no-cpu-baseline >
 echo "=== bench full (l14, batch 1024) + cpu baseline"
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err; tail -3 gpurun_out/${TAG}_bench_full.err; cat gpurun_out/${TAG}_bench_full.json
 echo "=== rocprof kernel stats (batch 256, 2 steps)"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -o prof -- python $GRAFT_REPO_ROOT/bench.py --batch 256 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -o prof -- python $GRAFT_REPO_ROOT/bench.py --batch 256 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/${TAG}_prof -name "*kernel_stats*" | head -3
 f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
