@@ -292,15 +292,15 @@ class _TransformerLayer(torch.autograd.Function):
             mid = x1  # s1 (pre-LN sum)
             h2, m2_, r2 = ops.layernorm_fwd(mid, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps)
             st2 = (m2_, r2)
-        u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
-        g = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
         st_f = None
         if spec.kind == "m2":
-            g_n, mf, rf = ops.layernorm_fwd(g, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps)
+            # fc1 -> [gelu -> ffn_layernorm] fused: gelu(u) never goes to HBM
+            u = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]))
+            g_n, mf, rf = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, act=spec.act)
             st_f = (mf, rf)
-            del g
         else:
-            g_n = g
+            u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
+            g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
         res = mid if pre_ln else h2
         y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
         del g_n
@@ -346,23 +346,19 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             dgw, dgb = lnw("ln2")
             ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb)
-        g = ops.act_fwd(u, spec.act)
         if spec.kind == "m2":
-            g_n, _, _ = ops.layernorm_fwd(g, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False)
+            g_n, _, _ = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False, act=spec.act)
         else:
-            g_n = g
+            g_n = ops.act_fwd(u, spec.act)
         _wgrad(sink, P["w2"], ds2, g_n)
         _bgrad(sink, P["b2"], ds2)
         del g_n
         if spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
             dgw, dgb = lnw("ffn")
-            dg = ops.layernorm_bwd(dgn, g, mf, rf, f32(P["ffn_w"]), dgw, dgb)
-            del dgn, g
-            du = ops.act_bwd(dg, u, spec.act)
-            del dg
+            du = ops.layernorm_bwd(dgn, u, mf, rf, f32(P["ffn_w"]), dgw, dgb, act=spec.act)  # through LN and gelu at once
+            del dgn
         else:
-            del g
             du = dgrad(ds2, P["w2"], gate=u, act=spec.act)  # (ds2 W2) * act'(u)
         ln_mid = ("ln2" if pre_ln else "ln1")
         h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)

@@ -56,7 +56,8 @@ def _f32(t, name):
 
 
 # ------------------------------------------------------------------------------ LayerNorm
-def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, want_stats=True, act=None):
+    """y = LN(act(x)); act=None is the plain LayerNorm."""
     _dev_ok(x, gamma, beta)
     _c(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
     cols = x.shape[-1]
@@ -64,13 +65,13 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True):
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
-    _rc(_lib.load().antmmf_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, float(eps),
-                                         _dt(x), _stream()), "antmmf_layernorm_fwd")
+    _rc(_lib.load().antmmf_act_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, float(eps),
+                                             ACT_IDS[act], _dt(x), _stream()), "antmmf_act_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None):
-    """dgamma / dbeta (fp32) are accumulated in place when given."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, act=None):
+    """Gradient of y = LN(act(x)) w.r.t. x (+ dres); dgamma / dbeta (fp32) are accumulated in place when given."""
     _dev_ok(dy, x, mean, rstd, gamma, dgamma, dbeta, dres)
     _c(dy, "dy"); _c(x, "x")
     if dres is not None:
@@ -78,8 +79,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None):
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)
-    _rc(_lib.load().antmmf_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
-                                         _p(dbeta), rows, cols, _dt(x), _stream()), "antmmf_layernorm_bwd")
+    _rc(_lib.load().antmmf_act_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
+                                             _p(dbeta), rows, cols, ACT_IDS[act], _dt(x), _stream()), "antmmf_act_layernorm_bwd")
     return dx
 
 

@@ -92,6 +92,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
+// LDS transpose read (ds_read_b64_tr_b16): each lane passes the address of 4 contiguous bf16; within a 16-lane group
+// the 16 x 4 elements form a 4 x 16 block (row = supplying lane >> 2, columns 4 (lane & 3) ..) and lane i receives
+// column i (4 values, one per row).  Two of them build an MFMA fragment out of a tile stored [r][cols].
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) { return emu_ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)p);
+}
+#endif
+
 // activation ids shared with the host side (include/antmmf_hip.h)
 #define ANTMMF_ACT_NONE 0
 #define ANTMMF_ACT_GELU_ERF 1    // 0.5 x (1 + erf(x/sqrt2))   (BERT, torchscale)

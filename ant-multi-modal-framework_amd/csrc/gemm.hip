@@ -30,6 +30,7 @@
 //
 // Roofline: MFMA-bound (2*I*J*R flop).  Algorithmic HBM bytes: 2*(I*R + J*R) + out bytes.
 #include "common.h"
+#include <cstdlib>
 
 #define ANTMMF_GEMM_EINVAL ANTMMF_EINVAL
 
@@ -89,15 +90,16 @@ __device__ __forceinline__ void store_rm(char* lds, const uint4 (&v)[4]) {
     }
 }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[4][4], int i0, int j0, int wi, int wj, int l15, int grp, bool splitk) {
-    // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt)
+template <int TI, int TJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj, int l15, int grp, bool splitk) {
+    // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt); wave tile = (16 TI) x (16 TJ)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = i0 + wi * 64 + it * 16 + l15;
+    for (int it = 0; it < TI; ++it) {
+        const int i = i0 + wi * (16 * TI) + it * 16 + l15;
         if (i >= g.I) continue;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = j0 + wj * 64 + jt * 16 + grp * 4;
+        for (int jt = 0; jt < TJ; ++jt) {
+            const int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
             if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
             float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
             if (g.bias) {
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         cur ^= 1;
     }
 
-    gemm_epilogue(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
+    gemm_epilogue<4, 4>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
 }
 
 // ---- LDS-DMA variant for the all-r-contiguous layout (forward; dgrad against a pre-transposed weight) ----
@@ -212,10 +214,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 // per K-step vs 512 MFMA cycles).  The DMA writes lane-linearly, so the slot swizzle is applied on the SOURCE
 // address: LDS (row, physical slot p) is filled from global (row, p ^ lds_swz(row)) -- same 128-B line, coalescing
 // untouched.  Rows past the matrix edge are clamped (their outputs are never stored); requires R % 64 == 0.
+// Tile shapes: <NWI, NWJ, TI, TJ> = waves along i / j, 16x16 MFMA tiles per wave along i / j.
+//   <2,2,4,4>: 128 x 128, 256 threads, 64 KiB LDS (2 workgroups / CU)      -- small problems
+//   <2,4,8,4>: 256 x 256, 512 threads, 128 KiB LDS (1 workgroup / CU, 2 waves / SIMD): half the LDS fill bytes and
+//              2/3 of the fragment reads per flop of the 128^2 tile                           -- the large GEMMs
+template <int ROWS, int NW>
 __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int r0, char* lds, int wave, int lane) {
+    constexpr int PER_WAVE = ROWS / 8 / NW;  // 1-KiB chunks (8 rows x 128 B) per wave
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int chunk = wave * 4 + q;                 // 16 chunks of 8 rows (1 KiB each)
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int chunk = wave * PER_WAVE + q;
         const int row = chunk * 8 + (lane >> 3), pslot = lane & 7;
         int gr = row0 + row;
         gr = gr < nrows ? gr : nrows - 1;
@@ -223,58 +231,153 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs g) {
+template <int NWI, int NWJ, int TI, int TJ>
+__global__ __launch_bounds__(64 * NWI * NWJ) void gemm_nt_dma_kernel(const GemmArgs g) {
     ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = NWI * TI * 16, BN = NWJ * TJ * 16, NW = NWI * NWJ;
+    constexpr int PBYTES = BM * 128, QBYTES = BN * 128, BUF = PBYTES + QBYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / NWJ, wj = wave % NWJ;
     const int l15 = lane & 15, grp = lane >> 4;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
     const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int tiles_j = (g.J + 127) >> 7;
-    const int i0 = (wgid / tiles_j) << 7, j0 = (wgid % tiles_j) << 7;
+    const int tiles_j = (g.J + BN - 1) / BN;
+    const int i0 = (wgid / tiles_j) * BM, j0 = (wgid % tiles_j) * BN;
     const int nk = g.R >> 6;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[TI][TJ];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    dma_tile(g.P, g.ldp, i0, g.I, 0, smem, wave, lane);
-    dma_tile(g.Q, g.ldq, j0, g.J, 0, smem + 16384, wave, lane);
+    dma_tile<BM, NW>(g.P, g.ldp, i0, g.I, 0, smem, wave, lane);
+    dma_tile<BN, NW>(g.Q, g.ldq, j0, g.J, 0, smem + PBYTES, wave, lane);
     glds_wait_all();
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) {
-            char* nb = smem + (cur ^ 1) * 32768;
-            dma_tile(g.P, g.ldp, i0, g.I, (kt + 1) << 6, nb, wave, lane);
-            dma_tile(g.Q, g.ldq, j0, g.J, (kt + 1) << 6, nb + 16384, wave, lane);
+            char* nb = smem + (cur ^ 1) * BUF;
+            dma_tile<BM, NW>(g.P, g.ldp, i0, g.I, (kt + 1) << 6, nb, wave, lane);
+            dma_tile<BN, NW>(g.Q, g.ldq, j0, g.J, (kt + 1) << 6, nb + PBYTES, wave, lane);
         }
-        const char* ps = smem + cur * 32768;
-        const char* qs = ps + 16384;
+        const char* ps = smem + cur * BUF;
+        const char* qs = ps + PBYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t qa[4], pb[4];
+            bf16x8_t qa[TJ], pb[TI];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int qrow = wj * 64 + t * 16 + l15;
+            for (int t = 0; t < TJ; ++t) {
+                const int qrow = wj * (16 * TJ) + t * 16 + l15;
                 qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + qrow * 128 + (((kk * 4 + grp) ^ lds_swz(qrow)) << 4));
-                const int prow = wi * 64 + t * 16 + l15;
+            }
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int prow = wi * (16 * TI) + t * 16 + l15;
                 pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + prow * 128 + (((kk * 4 + grp) ^ lds_swz(prow)) << 4));
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
+            for (int it = 0; it < TI; ++it)
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                for (int jt = 0; jt < TJ; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
         }
         glds_wait_all();
         __syncthreads();
         cur ^= 1;
     }
-    gemm_epilogue(g, acc, i0, j0, wi, wj, l15, grp, false);
+    gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, false);
+}
+
+// ---- LDS-DMA + transpose-read variant for the all-r-major layout (wgrad dW = dY^T X, reduction over tokens) ----
+// Both operand tiles are DMA'd in their NATURAL layout [64 r][COLS] (rows of 2*COLS bytes) -- no register transpose, no
+// ds_write -- and the MFMA fragments ("16 columns x 32 r, 8 consecutive r per lane") are produced by the hardware
+// transpose read ds_read_b64_tr_b16, two per fragment.  Bank conflicts: a 32-lane half of a transpose read touches
+// 8 rows (r, r+1, r+2, r+3, r+8, ..r+11) x 32 B at the same column; rows are a multiple of 256 B apart, so the 32-B
+// chunk index is XOR-swizzled with ftr(r) = (r & 3) | ((r >> 3) & 1) << 2 (on the DMA source address and on the read).
+// Requires R % 64 == 0, I % BM == 0, J % BN == 0 (otherwise the register-staged kernel runs).
+__device__ __forceinline__ int ftr(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int COLS, int NW>
+__device__ __forceinline__ void dma_tile_rm(const bf16_t* __restrict__ base, long ld, int col0, int r0, char* lds, int wave, int lane) {
+    constexpr int ROWB = COLS * 2, SLOTS = ROWB / 16, PER_WAVE = (64 * ROWB / 1024) / NW;
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int chunk = wave * PER_WAVE + q;
+        const int lin = chunk * 64 + lane;           // 16-B slot index inside the tile
+        const int row = lin / SLOTS, s = lin % SLOTS;
+        const int lc = (s >> 1) ^ ftr(row);          // logical 32-B chunk stored at this physical chunk
+        glds16(base + (long)(r0 + row) * ld + col0 + lc * 16 + (s & 1) * 8, lds + chunk * 1024);
+    }
+}
+// fragment: columns c16*16 .. +15 (lane l15), r = rbase .. rbase+7 with rbase = 32 kk + 8 grp
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int rbase, int c16, int l15) {
+    const int r0 = rbase + (l15 >> 2);
+    const int x = ftr(r0);  // ftr(r0 + 4) == ftr(r0)
+    const char* p = tile + r0 * ROWB + ((c16 ^ x) << 5) + (l15 & 3) * 8;
+    const bf16x4_t lo = lds_read_tr16(p), hi = lds_read_tr16(p + 4 * ROWB);
+    return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NWI, int NWJ, int TI, int TJ>
+__global__ __launch_bounds__(64 * NWI * NWJ) void gemm_tn_dma_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = NWI * TI * 16, BN = NWJ * TJ * 16, NW = NWI * NWJ;
+    constexpr int PBYTES = BM * 128, QBYTES = BN * 128, BUF = PBYTES + QBYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tiles_j = g.J / BN;
+    const int i0 = (wgid / tiles_j) * BM, j0 = (wgid % tiles_j) * BN;
+    const int nk_total = g.R >> 6;
+    const int kbeg = blockIdx.z * g.ksteps_per_split;
+    int kend = kbeg + g.ksteps_per_split;
+    if (kend > nk_total) kend = nk_total;
+    if (kbeg >= kend) return;
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    dma_tile_rm<BM, NW>(g.P, g.ldp, i0, kbeg << 6, smem, wave, lane);
+    dma_tile_rm<BN, NW>(g.Q, g.ldq, j0, kbeg << 6, smem + PBYTES, wave, lane);
+    glds_wait_all();
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kbeg; kt < kend; ++kt) {
+        if (kt + 1 < kend) {
+            char* nb = smem + (cur ^ 1) * BUF;
+            dma_tile_rm<BM, NW>(g.P, g.ldp, i0, (kt + 1) << 6, nb, wave, lane);
+            dma_tile_rm<BN, NW>(g.Q, g.ldq, j0, (kt + 1) << 6, nb + PBYTES, wave, lane);
+        }
+        const char* ps = smem + cur * BUF;
+        const char* qs = ps + PBYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t qa[TJ], pb[TI];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<BN * 2>(qs, 32 * kk + 8 * grp, wj * TJ + t, l15);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) pb[t] = frag_tr<BM * 2>(ps, 32 * kk + 8 * grp, wi * TI + t, l15);
+#pragma unroll
+            for (int it = 0; it < TI; ++it)
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        }
+        glds_wait_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
 }
 
 // C ABI: see include/antmmf_hip.h for the contract.
@@ -314,12 +417,25 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_done = true;
     }
-    if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, block, lds, stream, g);
+    if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) {
+        const long tiles256 = (long)((I + 255) / 256) * ((J + 255) / 256);
+        static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");  // tests only: "256" / "128"
+        const bool big = force ? (force[0] == '2') : tiles256 >= 512;
+        if (big) {
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g);
+        } else {
+            hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4>), grid, block, lds, stream, g);
+        }
+    }
     else if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
     else if (!p_rmajor && q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, stream, g);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
+    else if (p_rmajor && q_rmajor && (R & 63) == 0 && (I & 127) == 0 && (J & 127) == 0) {
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<2, 2, 4, 4>), grid, block, lds, stream, g);
+    } else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
     return antmmf_check_launch();
 }

@@ -70,7 +70,10 @@ def _cpu_baseline_worker(cfg, pairs, q):
     from oracle import step as ostep
     from oracle.shapes import m2_shapes
 
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    # torch's CPU kernels stop scaling (and on a 256-core host collapse) well before one thread per core for this
+    # workload's GEMM shapes ([2*257, 1024] x [1024, 4096]); 32 threads is used, or every core on a smaller host
+    cores = min(ncpu, 32)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(7)
     shapes = m2_shapes(d=cfg["encoder_embed_dim"], layers=cfg["encoder_layers"], vl_layers=cfg["beit3_vl_layers"],

@@ -49,6 +49,14 @@ int antmmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const
                          const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int dtype,
                          antmmf_stream_t stream);
 
+/* ---- activation fused in front of the LayerNorm: y = LN(act(x)); bwd returns d/dx through both.  Replaces the
+ * torchscale FFN's gelu -> ffn_layernorm pair (feedforward_network.py:117-128).  act = ANTMMF_ACT_*. */
+int antmmf_act_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             int64_t rows, int cols, float eps, int act, int dtype, antmmf_stream_t stream);
+int antmmf_act_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                             const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int act,
+                             int dtype, antmmf_stream_t stream);
+
 /* ---- activations (n % 8 == 0): g = act(u);  du = dg * act'(u). */
 int antmmf_act_fwd(const void* u, void* g, int64_t n, int act, int dtype, antmmf_stream_t stream);
 int antmmf_act_bwd(const void* dg, const void* u, void* du, int64_t n, int act, int dtype, antmmf_stream_t stream);

@@ -64,6 +64,29 @@ def case_layernorm(ops, dev, dtype, rows=13, cols=128, eps=1e-5):
     check("ln.dbeta", dbet, br.grad, 1e-4, 1e-4)
 
 
+def case_act_layernorm(ops, dev, dtype, rows=9, cols=512, act="gelu"):
+    """y = LN(act(x)) and its backward (the torchscale FFN's gelu -> ffn_layernorm pair), wide rows included."""
+    fn = {"gelu": oops.gelu_erf, "quick_gelu": oops.quick_gelu}[act]
+    x = rnd((rows, cols), 101, 1.5)
+    g = 1 + 0.1 * rnd((cols,), 102)
+    b = 0.1 * rnd((cols,), 103)
+    dy = rnd((rows, cols), 104)
+    if dtype == BF:
+        x, dy = q(x), q(dy)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = oops.layer_norm(fn(xr), gr, br, 1e-5)
+    yr.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), 1e-5, act=act)
+    dgam, dbet = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, act=act)
+    rt, at = (2e-2, 2e-2) if dtype == BF else (1e-4, 1e-5)
+    check(f"actln.{act}.y", y, yr, rt, at)
+    check(f"actln.{act}.dx", dx, xr.grad, rt, at)
+    check(f"actln.{act}.dgamma", dgam, gr.grad, 2e-2 if dtype == BF else 1e-4, 2e-2 if dtype == BF else 1e-4)
+    check(f"actln.{act}.dbeta", dbet, br.grad, 1e-4, 1e-4)
+
+
 # ------------------------------------------------------------------------------ activations / l2norm / colsum / movers
 def case_activations(ops, dev):
     for act, fn in (("gelu", oops.gelu_erf), ("quick_gelu", oops.quick_gelu), ("relu", torch.relu)):
@@ -224,6 +247,14 @@ def case_gemm_multitile(ops, dev):
     check("gemm.dma.fused", y, oops.gelu_erf(X @ Wt.t() + bias) + res, 2e-2, 1e-2)
     y = ops.gemm(X.to(dev, BF), Wt.to(dev, BF), out_dtype=torch.float32)
     check("gemm.dma.f32", y, X @ Wt.t(), 1e-3, 1e-3)
+    # wgrad with tokens % 64 == 0 and 128-aligned outputs takes the LDS-DMA + transpose-read kernel
+    tokens, n_out, k_in = 192, 128, 256
+    dY = q(rnd((tokens, n_out), 53))
+    Xa = q(rnd((tokens, k_in), 54))
+    for split in (1, 3):
+        dw = torch.full((n_out, k_in), -0.5, device=dev)
+        ops.gemm(dY.to(dev, BF), Xa.to(dev, BF), out=dw, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+        check(f"gemm.tn.dma.split{split}", dw, dY.t() @ Xa - 0.5, 1e-3, 1e-3)
 
 
 # ------------------------------------------------------------------------------ attention

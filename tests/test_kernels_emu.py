@@ -54,6 +54,13 @@ def test_layernorm(ops):
     kc.case_layernorm(ops, DEV, torch.float32, rows=5, cols=1024 + 512, eps=1e-12)
 
 
+def test_act_layernorm(ops):
+    kc.case_act_layernorm(ops, DEV, torch.float32, rows=9, cols=512, act="gelu")
+    kc.case_act_layernorm(ops, DEV, torch.bfloat16, rows=5, cols=2048 + 512, act="gelu")   # workgroup-per-row path, 2 vectors / thread
+    kc.case_act_layernorm(ops, DEV, torch.float32, rows=6, cols=1536, act="quick_gelu")  # workgroup-per-row path, 1 vector / thread
+    kc.case_layernorm(ops, DEV, torch.float32, rows=7, cols=4096)
+
+
 def test_activations(ops):
     kc.case_activations(ops, DEV)
 
@@ -76,6 +83,18 @@ def test_gemm(ops):
 
 def test_gemm_multitile(ops):
     kc.case_gemm_multitile(ops, DEV)
+
+
+def test_gemm_256_tile(ops, monkeypatch):
+    """The 256 x 256 LDS-DMA tile (normally chosen for >= 512 tiles) forced onto a 2 x 2-tile problem."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = '256';"
+            "import kernel_cases as kc; from antmmf.hip import ops; kc.case_gemm_multitile(ops, torch.device('cpu')); print('ok256')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "ok256" in out.stdout, out.stdout + out.stderr
 
 
 def test_attention_self(ops):

@@ -34,6 +34,13 @@ def test_layernorm(ops):
         kc.case_layernorm(ops, DEV, dtype, rows=77, cols=3072)
 
 
+def test_act_layernorm(ops):
+    for dtype in (torch.float32, torch.bfloat16):
+        kc.case_act_layernorm(ops, DEV, dtype, rows=300, cols=4096, act="gelu")
+        kc.case_act_layernorm(ops, DEV, dtype, rows=1500, cols=3072, act="gelu")
+        kc.case_act_layernorm(ops, DEV, dtype, rows=77, cols=512, act="quick_gelu")
+
+
 def test_activations(ops):
     kc.case_activations(ops, DEV)
 
