@@ -84,12 +84,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     std::memcpy(lds_wave_base + emu::tls.lane * 16, gsrc, 16);
 }
 __device__ __forceinline__ void glds_wait_all() {}
+template <int N> __device__ __forceinline__ void glds_wait_le() {}          // DMA is synchronous in the emulator
+__device__ __forceinline__ void wg_barrier_lds_only() { __syncthreads(); }
 #else
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are still in flight
+template <int N> __device__ __forceinline__ void glds_wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain the DMA queue (a plain __syncthreads() waits vmcnt(0) while a glds is pending)
+__device__ __forceinline__ void wg_barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 #endif
 
 // LDS transpose read (ds_read_b64_tr_b16): each lane passes the address of 4 contiguous bf16; within a 16-lane group
@@ -102,6 +111,18 @@ __device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) { return emu_ds
 __device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)p);
 }
+#endif
+
+// Scheduling fence: nothing is moved across it by the compiler's instruction scheduler (keeps a hand-chosen
+// "issue all fragment reads, then the MFMA block" order instead of hipcc's register-saving load->wait->use chains).
+#ifdef ANTMMF_EMULATE
+#define SCHED_FENCE() do {} while (0)
+#define WAVE_LDS_ORDER() emu_wave_barrier()   // lanes are OS threads in the emulator: make the wave's LDS writes visible
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a wave's LDS instructions execute in program order, so a ds_read that follows the wave's own ds_writes sees them;
+// only the compiler has to keep that order
+#define WAVE_LDS_ORDER() __builtin_amdgcn_wave_barrier()
 #endif
 
 // activation ids shared with the host side (include/antmmf_hip.h)

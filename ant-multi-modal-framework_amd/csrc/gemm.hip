@@ -44,6 +44,7 @@ struct GemmArgs {
     int I, J, R;
     int act, c_dtype, accumulate, ksteps_per_split;
     float alpha;
+    int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
 };
 
 
@@ -138,6 +139,74 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
     }
 }
 
+// bf16 outputs: the accumulator fragment layout (a lane owns 4 columns of 16 different rows) would store 16 x 32-B
+// row segments per instruction -- measured on MI355X this scattered store tail costs as much as the whole K loop for the
+// wide outputs (fc1 / qkv: 0.44 ms of 0.94 ms; tools/gemm_ablate.hip).  Instead each wave stages its (16 TI) x (16 TJ)
+// sub-tile through its own LDS region (slot-swizzled, <= 2-way write conflicts) and writes whole 16-B-per-lane,
+// 128-B-per-row segments.  bias / activation / gate / residual are applied on the fp32 accumulators before rounding.
+// EPI: compile-time epilogue shape -- bit 0 bias, bit 1 residual (no alpha / activation / gate / aux); 4 = everything, decided at
+// run time.  (With run-time checks inside the 32-tile unrolled loop hipcc emits ~600 basic blocks and the store tail of a
+// 256 x 256 tile took 3x longer: measured 0.31 ms vs 0.11 ms of a 0.86 ms fc1 GEMM.)
+template <int TI, int TJ, int EPI>
+__device__ __forceinline__ void gemm_epilogue_bf16_staged(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj,
+                                                          int lane, char* wave_lds) {
+    constexpr int ROWB = TJ * 32, SLOTS = ROWB / 16;
+    constexpr bool GENERIC = EPI == 4, BIAS = GENERIC || (EPI & 1), RES = GENERIC || (EPI & 2);
+    const int l15 = lane & 15, grp = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < TI; ++it) {
+        const int row = it * 16 + l15;
+        int i = i0 + wi * (16 * TI) + row;
+        i = i < g.I ? i : g.I - 1;  // clamped rows are computed but never stored
+#pragma unroll
+        for (int jt = 0; jt < TJ; ++jt) {
+            int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
+            j = j < g.J ? j : g.J - 4;
+            float v[4] = {acc[it][jt][0], acc[it][jt][1], acc[it][jt][2], acc[it][jt][3]};
+            if (GENERIC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
+            }
+            if (BIAS && (!GENERIC || g.bias)) {
+                const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (GENERIC) {
+                if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (g.gate) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
+                    v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
+                    v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+                } else if (g.act != ANTMMF_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
+                }
+            }
+            if (RES && (!GENERIC || g.residual)) {
+                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                v[0] += bf_lo(u.x); v[1] += bf_hi(u.x); v[2] += bf_lo(u.y); v[3] += bf_hi(u.y);
+            }
+            const int slot = jt * 2 + (grp >> 1);
+            *reinterpret_cast<uint2*>(wave_lds + row * ROWB + ((slot ^ (row & (SLOTS - 1))) << 4) + (grp & 1) * 8) =
+                make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    }
+    WAVE_LDS_ORDER();  // same-wave LDS write -> read
+    constexpr int ROWS_PER_PASS = 64 / SLOTS;
+    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+    for (int pass = 0; pass < (TI * 16) / ROWS_PER_PASS; ++pass) {
+        const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
+        const uint4 val = *reinterpret_cast<const uint4*>(wave_lds + row * ROWB + ((ls ^ (row & (SLOTS - 1))) << 4));
+        const int gi = i0 + wi * (16 * TI) + row, gj = j0 + wj * (16 * TJ) + ls * 8;
+        if (gi < g.I) {
+            bf16_t* dst = C + (long)gi * g.ldc + gj;
+            if (gj + 8 <= g.J) *reinterpret_cast<uint4*>(dst) = val;
+            else if (gj + 4 <= g.J) *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+        }
+    }
+}
+
 template <bool PT, bool QT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     ANTMMF_DYN_LDS(char, smem);  // [2 buffers][P tile 16 KiB | Q tile 16 KiB]
@@ -194,11 +263,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
                 const int prow = wi * 64 + t * 16 + l15;
                 pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + prow * 128 + (((kk * 4 + grp) ^ lds_swz(prow)) << 4));
             }
+            SCHED_FENCE();
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+            SCHED_FENCE();
         }
         if (more) lstore(cur ^ 1);
         __syncthreads();
@@ -231,7 +302,7 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
     }
 }
 
-template <int NWI, int NWJ, int TI, int TJ>
+template <int NWI, int NWJ, int TI, int TJ, int EPI>
 __global__ __launch_bounds__(64 * NWI * NWJ) void gemm_nt_dma_kernel(const GemmArgs g) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int BM = NWI * TI * 16, BN = NWJ * TJ * 16, NW = NWI * NWJ;
@@ -278,17 +349,144 @@ __global__ __launch_bounds__(64 * NWI * NWJ) void gemm_nt_dma_kernel(const GemmA
                 const int prow = wi * (16 * TI) + t * 16 + l15;
                 pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + prow * 128 + (((kk * 4 + grp) ^ lds_swz(prow)) << 4));
             }
+            SCHED_FENCE();
 #pragma unroll
             for (int it = 0; it < TI; ++it)
 #pragma unroll
                 for (int jt = 0; jt < TJ; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+            SCHED_FENCE();
         }
         glds_wait_all();
         __syncthreads();
         cur ^= 1;
     }
-    gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, false);
+    if (g.c_dtype == ANTMMF_BF16 && !(g.ldc & 7)) gemm_epilogue_bf16_staged<TI, TJ, EPI>(g, acc, i0, j0, wi, wj, lane, smem + wave * (TI * 16 * TJ * 32));
+    else gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, false);
+}
+
+// ---- 4-stage LDS-DMA ring for the large all-r-contiguous GEMMs -------------------------------------------------------
+// Measured on MI355X (profiles/r1_pmc_gemm_*.txt): the 2-buffer kernels above park their waves half of the time
+// (SQ_WAIT_ANY 50 %, MFMA busy 29 %, LDS bank conflicts 0): every K-step issues its whole 64 KiB as one burst and
+// then drains to vmcnt(0) before the barrier, so each step pays the loaded memory latency (~3 us with 27 % L2 misses).
+// Here the tile is 256 x 256 x 32 with FOUR 32-KiB stages: three tiles are always in flight, a wave only waits until
+// its pieces of the OLDEST tile have landed (counted vmcnt, never 0 in steady state) and the barrier is a raw s_barrier
+// that does not drain the DMA queue.  LDS rows are 64 B (32 r); 16-B slot swizzle f(row) = T[(row>>2)&3], T = {0,2,3,1}
+// makes the ds_read_b128 fragment reads conflict-free (each 16-lane group covers 16 rows x 1 slot = all 64 banks once).
+__device__ __forceinline__ int swz32(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }  // {0,2,3,1}
+
+template <int STAGES, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, G = 4;  // G: DMA pieces per wave per tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    // XCD-aware remap; inside an XCD's contiguous range tiles are walked in 4 (i) x 8 (j) groups so that the ~32
+    // workgroups resident on one XCD share 4 P panels and 8 Q panels through its L2
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int tiles_j = (g.J + BN - 1) / BN, tiles_i = (g.I + BM - 1) / BM;
+    int ti, tj;
+    if ((g.raster & 7) == 0) {          // dispatch order: workgroup b runs on XCD b % 8, so each XCD sees every 8th j-panel
+        ti = bid / tiles_j; tj = bid % tiles_j;
+    } else {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+        const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+        if ((g.raster & 7) == 2) { ti = wgid / tiles_j; tj = wgid % tiles_j; }
+        else {
+            const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+            const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+            ti = band * 4 + inb % rows_here; tj = inb / rows_here;
+        }
+    }
+    const int i0 = ti * BM, j0 = tj * BN;
+    const int nk = g.R >> 5;
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // this wave's DMA source rows (clamped at the matrix edge) and slots are loop-invariant
+    const int prow[2] = {wave * 32 + (lane >> 2), wave * 32 + 16 + (lane >> 2)};
+    const bf16_t* psrc[2];
+    const bf16_t* qsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = prow[q], sl = ((lane & 3) ^ swz32(row)) << 3;
+        int gi = i0 + row; gi = gi < g.I ? gi : g.I - 1;
+        int gj2 = j0 + row; gj2 = gj2 < g.J ? gj2 : g.J - 1;
+        psrc[q] = g.P + (long)gi * g.ldp + sl;
+        qsrc[q] = g.Q + (long)gj2 * g.ldq + sl;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024);
+            glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight
+        if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
+        else if (ahead == 1) glds_wait_le<G>();
+        else glds_wait_le<0>();
+        wg_barrier_lds_only();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const char* ps = smem + (kt % STAGES) * 32768;
+        const char* qs = ps + 16384;
+        // fragment reads are issued in two batches AHEAD of the MFMAs that consume them (hipcc otherwise sinks each
+        // read next to its first use and waits lgkmcnt(0) after every one: measured 8 exposed LDS latencies per step)
+        bf16x8_t qa[TJ], pb[TI];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            const int row = wj * 64 + t * 16 + l15;
+            qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + row * 64 + ((grp ^ swz32(row)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < TI / 2; ++t) {
+            const int row = wi * 128 + t * 16 + l15;
+            pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + row * 64 + ((grp ^ swz32(row)) << 4));
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int t = TI / 2; t < TI; ++t) {
+            const int row = wi * 128 + t * 16 + l15;
+            pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + row * 64 + ((grp ^ swz32(row)) << 4));
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int it = 0; it < TI / 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        SCHED_FENCE();
+#pragma unroll
+        for (int it = TI / 2; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        SCHED_FENCE();
+    }
+    if (g.raster & 8) {  // experiment: no store tail
+        float sacc = 0.f;
+#pragma unroll
+        for (int a2 = 0; a2 < TI; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < TJ; ++b2) sacc += acc[a2][b2][0] + acc[a2][b2][1] + acc[a2][b2][2] + acc[a2][b2][3];
+        if (sacc == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = sacc;
+        return;
+    }
+    if (g.c_dtype == ANTMMF_BF16 && !(g.ldc & 7)) {
+        wg_barrier_lds_only();  // every wave is done with the stage buffers (all DMA pieces were waited for above)
+        gemm_epilogue_bf16_staged<TI, TJ, EPI>(g, acc, i0, j0, wi, wj, lane, smem + wave * (TI * 16 * TJ * 32));
+    } else gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, false);
 }
 
 // ---- LDS-DMA + transpose-read variant for the all-r-major layout (wgrad dW = dY^T X, reduction over tokens) ----
@@ -367,15 +565,89 @@ __global__ __launch_bounds__(64 * NWI * NWJ) void gemm_tn_dma_kernel(const GemmA
             for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<BN * 2>(qs, 32 * kk + 8 * grp, wj * TJ + t, l15);
 #pragma unroll
             for (int t = 0; t < TI; ++t) pb[t] = frag_tr<BM * 2>(ps, 32 * kk + 8 * grp, wi * TI + t, l15);
+            SCHED_FENCE();
 #pragma unroll
             for (int it = 0; it < TI; ++it)
 #pragma unroll
                 for (int jt = 0; jt < TJ; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+            SCHED_FENCE();
         }
         glds_wait_all();
         __syncthreads();
         cur ^= 1;
+    }
+    gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
+}
+
+// ---- 4-stage LDS-DMA ring for wgrad (all-r-major): 256 x 256 output tile, 32 tokens per stage, natural [r][cols] LDS
+// image (512-B rows), fragments by ds_read_b64_tr_b16, split over the token range by gridDim.z (fp32 atomics when split).
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int STAGES = 4, BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, G = 4, ROWB = 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int tiles_j = g.J / BN;
+    const int i0 = (blockIdx.x / tiles_j) * BM, j0 = (blockIdx.x % tiles_j) * BN;
+    const int nk_total = g.R >> 5;
+    const int kbeg = blockIdx.z * g.ksteps_per_split;
+    int kend = kbeg + g.ksteps_per_split;
+    if (kend > nk_total) kend = nk_total;
+    if (kbeg >= kend) return;
+    const int nk = kend - kbeg;
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // DMA: a 1-KiB piece = 2 rows x 512 B; wave w moves rows 4w .. 4w+3 of each operand's 32-row stage
+    const bf16_t* psrc[2];
+    const bf16_t* qsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int lin = (wave * 2 + q) * 64 + lane;  // 16-B slot index in the [32][512 B] tile
+        const int row = lin >> 5, sidx = lin & 31;
+        const int col = (((sidx >> 1) ^ ftr(row)) << 4) + ((sidx & 1) << 3);
+        psrc[q] = g.P + (long)row * g.ldp + i0 + col;
+        qsrc[q] = g.Q + (long)row * g.ldq + j0 + col;
+    }
+    auto issue = [&](int t) {  // t: step index relative to kbeg
+        char* buf = smem + (t % STAGES) * 32768;
+        const long roff = (long)(kbeg + t) << 5;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(psrc[q] + roff * g.ldp, buf + (wave * 2 + q) * 1024);
+            glds16(qsrc[q] + roff * g.ldq, buf + 16384 + (wave * 2 + q) * 1024);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;
+        if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
+        else if (ahead == 1) glds_wait_le<G>();
+        else glds_wait_le<0>();
+        wg_barrier_lds_only();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const char* ps = smem + (kt % STAGES) * 32768;
+        const char* qs = ps + 16384;
+        bf16x8_t qa[TJ], pb[TI];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
+#pragma unroll
+        for (int t = 0; t < TI; ++t) pb[t] = frag_tr<ROWB>(ps, 8 * grp, wi * TI + t, l15);
+        SCHED_FENCE();
+#pragma unroll
+        for (int it = 0; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        SCHED_FENCE();
     }
     gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
 }
@@ -407,6 +679,8 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha;
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
+    static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");
+    g.raster = raster_env ? atoi(raster_env) : 1;
     const int splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     const long tiles = (long)((I + 127) / 128) * ((J + 127) / 128);
     if (tiles > 0x7fffffffL) return ANTMMF_EINVAL;
@@ -417,24 +691,50 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_done = true;
     }
     if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) {
         const long tiles256 = (long)((I + 255) / 256) * ((J + 255) / 256);
-        static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");  // tests only: "256" / "128"
-        const bool big = force ? (force[0] == '2') : tiles256 >= 512;
-        if (big) {
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g);
-        } else {
-            hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4>), grid, block, lds, stream, g);
+        static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");  // tests only: "256" / "128" / "ring"
+        const bool big = force ? (force[0] == '2' || force[0] == 'r') : tiles256 >= 512;
+        const int epi = (aux || gate || act != ANTMMF_ACT_NONE || alpha != 1.0f || c_dtype != ANTMMF_BF16) ? 4 : ((bias ? 1 : 0) | (residual ? 2 : 0));
+#define LAUNCH_NT(E)                                                                                                              \
+    do {                                                                                                                          \
+        static bool once = false;                                                                                                 \
+        if (!once) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+            once = true;                                                                                                          \
+        }                                                                                                                         \
+        if (big && !(force && force[0] == '2')) hipLaunchKernelGGL((gemm_nt_ring_kernel<4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
+        else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
+        else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \
+    } while (0)
+        switch (epi) {
+            case 0: LAUNCH_NT(0); break;
+            case 1: LAUNCH_NT(1); break;
+            case 2: LAUNCH_NT(2); break;
+            case 3: LAUNCH_NT(3); break;
+            default: LAUNCH_NT(4); break;
         }
+#undef LAUNCH_NT
     }
     else if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
     else if (!p_rmajor && q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, stream, g);
-    else if (p_rmajor && q_rmajor && (R & 63) == 0 && (I & 127) == 0 && (J & 127) == 0) {
+    else if (p_rmajor && q_rmajor && (R & 31) == 0 && (I & 255) == 0 && (J & 255) == 0 && c_dtype == ANTMMF_F32 && accumulate &&
+             !bias && act == ANTMMF_ACT_NONE && !residual && !aux && !gate && R >= 4096) {
+        // wgrad ring: the host-side split_k hint is replaced by "enough workgroups to fill 256 CUs twice"
+        const int tiles = (I / 256) * (J / 256), nk32 = R / 32;
+        int sp = (512 + tiles - 1) / tiles;
+        if (sp > nk32 / 8) sp = nk32 / 8 > 0 ? nk32 / 8 : 1;
+        g.ksteps_per_split = (nk32 + sp - 1) / sp;
+        const int zs = (nk32 + g.ksteps_per_split - 1) / g.ksteps_per_split;
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
+        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3((unsigned)tiles, 1, (unsigned)zs), dim3(512), 131072, stream, g);
+    } else if (p_rmajor && q_rmajor && (R & 63) == 0 && (I & 127) == 0 && (J & 127) == 0) {
         hipLaunchKernelGGL((gemm_tn_dma_kernel<2, 2, 4, 4>), grid, block, lds, stream, g);
     } else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
     return antmmf_check_launch();

@@ -100,6 +100,7 @@ inline char* dyn_smem() {
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch([&] { kernel(__VA_ARGS__); }, grid, block, lds)
 
 static inline void __syncthreads() { emu::tls.blk->bar->arrive_and_wait(); }
+static inline void emu_wave_barrier() { emu::tls.wave->bar.arrive_and_wait(); }
 static inline float __shfl_xor(float v, int mask, int = 64) {
     auto* w = emu::tls.wave;
     w->fbuf[emu::tls.lane] = v;

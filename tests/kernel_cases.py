@@ -257,6 +257,15 @@ def case_gemm_multitile(ops, dev):
         check(f"gemm.tn.dma.split{split}", dw, dY.t() @ Xa - 0.5, 1e-3, 1e-3)
 
 
+def case_gemm_wgrad_ring(ops, dev, tokens=4096, n_out=256, k_in=256):
+    """wgrad through the 4-stage DMA ring + transpose reads (256-aligned outputs, >= 4096 tokens), split over tokens."""
+    dY = q(rnd((tokens, n_out), 55, 0.5))
+    Xa = q(rnd((tokens, k_in), 56, 0.5))
+    dw = torch.full((n_out, k_in), 0.75, device=dev)
+    ops.gemm(dY.to(dev, BF), Xa.to(dev, BF), out=dw, p_rmajor=True, q_rmajor=True, accumulate=True)
+    check("gemm.tn.ring", dw, dY.t() @ Xa + 0.75, 2e-3, 2e-3)
+
+
 # ------------------------------------------------------------------------------ attention
 def _attn_ref(qh, kh, vh, scale, key_bias):
     return oops.attention_core(qh, kh, vh, scale, key_bias)

@@ -85,16 +85,22 @@ def test_gemm_multitile(ops):
     kc.case_gemm_multitile(ops, DEV)
 
 
-def test_gemm_256_tile(ops, monkeypatch):
-    """The 256 x 256 LDS-DMA tile (normally chosen for >= 512 tiles) forced onto a 2 x 2-tile problem."""
+@pytest.mark.parametrize("variant", ["256", "ring"])
+def test_gemm_large_tile_variants(ops, variant):
+    """The 256 x 256 kernels (2-buffer DMA; 4-stage DMA ring -- normally chosen for >= 512 tiles) forced onto a
+    2 x 2-tile problem with ragged edges."""
     import subprocess
     import sys
 
-    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = '256';"
-            "import kernel_cases as kc; from antmmf.hip import ops; kc.case_gemm_multitile(ops, torch.device('cpu')); print('ok256')"
-            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = %r;"
+            "import kernel_cases as kc; from antmmf.hip import ops; kc.case_gemm_multitile(ops, torch.device('cpu')); print('okbig')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
-    assert "ok256" in out.stdout, out.stdout + out.stderr
+    assert "okbig" in out.stdout, out.stdout + out.stderr
+
+
+def test_gemm_wgrad_ring(ops):
+    kc.case_gemm_wgrad_ring(ops, DEV)
 
 
 def test_attention_self(ops):

@@ -63,6 +63,11 @@ def test_gemm(ops):
     kc.case_gemm_multitile(ops, DEV)
 
 
+def test_gemm_wgrad_ring(ops):
+    kc.case_gemm_wgrad_ring(ops, DEV)
+    kc.case_gemm_wgrad_ring(ops, DEV, tokens=257 * 64, n_out=1024, k_in=512)
+
+
 def test_gemm_large_linearity(ops):
     """Full-size property check (BASELINE sizes; the oracle would take minutes): the GEMM is linear in P,
     and agrees with an fp32 matmul of the same bf16 operands on a random sample of rows."""

@@ -1,0 +1,127 @@
+// gemm_ablate.hip -- ablation of the 256x256x32 4-stage ring GEMM inner loop on gfx950: which component
+// (MFMA issue, LDS fragment reads, workgroup barrier, LDS-DMA stream) bounds it?  Standalone: prints TFLOP/s per variant.
+// Build: hipcc --offload-arch=gfx950 -O3 gemm_ablate.hip -o gemm_ablate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__device__ __forceinline__ int swz32(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// MODE bits: 1 = LDS fragment reads, 2 = barrier per step, 4 = DMA ring, 8 = use 32x32x16 MFMA instead (same flops)
+template <int MODE>
+__global__ __launch_bounds__(512) void k(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, TI = 8, TJ = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 2, wj = wave & 3, l15 = lane & 15, grp = lane >> 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[TI][TJ];
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* psrc[2]; const uint16_t* qsrc[2];
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        psrc[q] = P + (long)(i0 + row) * ld + sl; qsrc[q] = Q + (long)(j0 + row) * ld + sl;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 2; ++q) { glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024); glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024); }
+    };
+    if (MODE & 4) { for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t); }
+    else { for (int i = threadIdx.x; i < 32768 * STAGES / 4; i += 512) ((float*)smem)[i] = 0.001f * (i & 255); __syncthreads(); }
+    bf16x8_t qa[TJ], pb[TI];
+    for (int t = 0; t < TJ; ++t) qa[t] = (bf16x8_t){(short)(0x3c00 + lane), 1, 2, 3, 4, 5, 6, (short)t};
+    for (int t = 0; t < TI; ++t) pb[t] = (bf16x8_t){(short)(0x3c00 + lane), 1, 2, 3, 4, 5, 6, (short)t};
+    for (int kt = 0; kt < nk; ++kt) {
+        if (MODE & 4) {
+            const int ahead = nk - 1 - kt;
+            if (ahead >= 2) wait_le<8>(); else if (ahead == 1) wait_le<4>(); else wait_le<0>();
+        }
+        if (MODE & 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        if ((MODE & 4) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        if (MODE & 1) {
+            const char* ps = smem + (kt % STAGES) * 32768; const char* qs = ps + 16384;
+            for (int t = 0; t < TJ; ++t) { const int row = wj * 64 + t * 16 + l15; qa[t] = *(const bf16x8_t*)(qs + row * 64 + ((grp ^ swz32(row)) << 4)); }
+            for (int t = 0; t < TI; ++t) { const int row = wi * 128 + t * 16 + l15; pb[t] = *(const bf16x8_t*)(ps + row * 64 + ((grp ^ swz32(row)) << 4)); }
+        } else {
+            for (int t = 0; t < TJ; ++t) asm volatile("" : "+v"(qa[t]));
+            for (int t = 0; t < TI; ++t) asm volatile("" : "+v"(pb[t]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE & 16) {  // scattered 8-B stores straight from the accumulator layout
+        uint16_t* C = (uint16_t*)out; const long ldc = (long)ntiles_j * 256;
+        for (int it = 0; it < TI; ++it) for (int jt = 0; jt < TJ; ++jt) {
+            const long i = i0 + wi * 128 + it * 16 + l15, j = j0 + wj * 64 + jt * 16 + grp * 4;
+            uint2 v; v.x = __float_as_uint(acc[it][jt][0]) >> 16 | (__float_as_uint(acc[it][jt][1]) & 0xffff0000u);
+            v.y = __float_as_uint(acc[it][jt][2]) >> 16 | (__float_as_uint(acc[it][jt][3]) & 0xffff0000u);
+            *(uint2*)(C + i * ldc + j) = v;
+        }
+    } else if (MODE & 32) {  // staged through LDS, 16-B / lane row-contiguous stores
+        uint16_t* C = (uint16_t*)out; const long ldc = (long)ntiles_j * 256;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+        char* wl = smem + wave * 16384;
+        for (int it = 0; it < TI; ++it) for (int jt = 0; jt < TJ; ++jt) {
+            const int row = it * 16 + l15, slot = jt * 2 + (grp >> 1);
+            uint2 v; v.x = __float_as_uint(acc[it][jt][0]) >> 16 | (__float_as_uint(acc[it][jt][1]) & 0xffff0000u);
+            v.y = __float_as_uint(acc[it][jt][2]) >> 16 | (__float_as_uint(acc[it][jt][3]) & 0xffff0000u);
+            *(uint2*)(wl + row * 128 + ((slot ^ (row & 7)) << 4) + (grp & 1) * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 8 + (lane >> 3), ls = lane & 7;
+            const uint4 val = *(const uint4*)(wl + row * 128 + ((ls ^ (row & 7)) << 4));
+            *(uint4*)(C + (long)(i0 + wi * 128 + row) * ldc + j0 + wj * 64 + ls * 8) = val;
+        }
+    } else {
+        float s = 0;
+        for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (s == 123.456f) out[blockIdx.x * 512 + threadIdx.x] = s;
+    }
+}
+
+template <int MODE>
+void run(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const int I = 257 * 256, J = 4096, R = 1024;
+    uint16_t *P, *Q; float* out;
+    hipMalloc(&P, (size_t)I * 4096 * 2); hipMalloc(&Q, (size_t)4096 * 4096 * 2); hipMalloc(&out, (size_t)I * 4096 * 2);
+    std::vector<uint16_t> h((size_t)4096 * 4096);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x3c00 + (i * 2654435761u >> 20 & 0x3ff));
+    hipMemcpy(Q, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (size_t off = 0; off < (size_t)I * 4096; off += h.size()) hipMemcpy(P + off, h.data(), (off + h.size() <= (size_t)I * 4096 ? h.size() : (size_t)I * 4096 - off) * 2, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        const int J2 = rep ? 1024 : 4096, R2 = rep ? 4096 : 1024;
+        run<0>("mfma only", P, Q, out, I, J2, R2);
+        run<1>("mfma + lds fragment reads", P, Q, out, I, J2, R2);
+        run<3>("mfma + lds reads + barrier", P, Q, out, I, J2, R2);
+        run<4>("mfma + dma ring (no reads, no barrier)", P, Q, out, I, J2, R2);
+        run<6>("mfma + dma ring + barrier (no reads)", P, Q, out, I, J2, R2);
+        run<7>("full loop: dma ring + barrier + lds reads", P, Q, out, I, J2, R2);
+        run<7 + 16>("full loop + scattered 8-B store tail", P, Q, out, I, J2, R2);
+        run<7 + 32>("full loop + LDS-staged 16-B store tail", P, Q, out, I, J2, R2);
+        run<0 + 32>("mfma only + LDS-staged store tail", P, Q, out, I, J2, R2);
+    }
+    return 0;
+}
