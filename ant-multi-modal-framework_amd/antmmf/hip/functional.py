@@ -107,9 +107,9 @@ def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
     if tiles < 256 and tokens >= 4096:
         split = min(8, max(1, 512 // tiles), tokens // 2048)
     if w_is_in_out:
-        ops.gemm(x2d, dy2d, out=out, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+        ops.gemm_wgrad_(out, x2d, dy2d, split)
     else:
-        ops.gemm(dy2d, x2d, out=out, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=split)
+        ops.gemm_wgrad_(out, dy2d, x2d, split)
 
 
 def _bgrad(sink, b, dy2d):

@@ -259,6 +259,38 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
     return out
 
 
+_WGRAD_WS = {}
+
+
+def gemm_wgrad_(dW, dY, X, split_k_hint=1):
+    """dW[n_out, k_in] += dY[tokens, n_out]^T X[tokens, k_in]   (fp32 accumulate in place; bf16 token-major operands,
+    row-strided views allowed).  A per-device fp32 workspace for the token-split partial sums is kept and reused."""
+    _dev_ok(dW, dY, X); _f32(dW, "dW")
+    for t, n in ((dY, "dY"), (X, "X")):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
+            raise ValueError(f"gemm_wgrad_: {n} must be a 2-D bf16 tensor with unit inner stride")
+    tokens, n_out = dY.shape
+    k_in = X.shape[1]
+    if X.shape[0] != tokens or tuple(dW.shape) != (n_out, k_in) or dW.stride(1) != 1:
+        raise ValueError("gemm_wgrad_: shape mismatch")
+    need = 16 * n_out * k_in
+    key = dW.device
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dW.device)
+        _WGRAD_WS[key] = ws
+    ev = None
+    if GEMM_TRACE is not None and _lib.backend() == 1:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _rc(_lib.load().antmmf_gemm_wgrad_bf16(_p(dY), _p(X), _p(dW), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
+                                           int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_out * k_in, "tn"))
+    return dW
+
+
 # ------------------------------------------------------------------------------ attention
 def _tok_ld(t, name):
     if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.dtype != torch.bfloat16:

@@ -122,6 +122,15 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
                      const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
                      int accumulate, int split_k, antmmf_stream_t stream);
 
+/* ---- wgrad: dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in] (fp32 accumulate; both operands token-major bf16).
+ * Large 256-aligned problems run a 4-stage LDS-DMA ring with hardware transpose reads, split over the token range;
+ * the per-split partial sums go to the caller-owned fp32 `workspace` (>= 16 * n_out * k_in * 4 bytes always suffices;
+ * NULL -> fp32 atomics) and are reduced into dW by a second launch on the same stream.  Replaces the cuBLAS wgrad
+ * GEMMs autograd issues for every nn.Linear / in_proj on the path. */
+int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tokens, int n_out, int k_in, int64_t ld_dy,
+                           int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes,
+                           antmmf_stream_t stream);
+
 /* ---- fused multi-head attention, head_dim = 64, bf16, Nk <= 288 (whole key row in LDS):
  *   O[b,q,h,:] = softmax_k( scale * <Q[b,q,h,:], K[b,k,h,:]> + key_bias[b,k] ) V[b,k,h,:]
  * element (b, n, h, e) of Q lives at q + (b*Nq + n)*ldq + h*64 + e (K, V with Nk / ldk / ldv; O with ldo), so a packed

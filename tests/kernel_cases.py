@@ -262,8 +262,15 @@ def case_gemm_wgrad_ring(ops, dev, tokens=4096, n_out=256, k_in=256):
     dY = q(rnd((tokens, n_out), 55, 0.5))
     Xa = q(rnd((tokens, k_in), 56, 0.5))
     dw = torch.full((n_out, k_in), 0.75, device=dev)
-    ops.gemm(dY.to(dev, BF), Xa.to(dev, BF), out=dw, p_rmajor=True, q_rmajor=True, accumulate=True)
-    check("gemm.tn.ring", dw, dY.t() @ Xa + 0.75, 2e-3, 2e-3)
+    ops.gemm(dY.to(dev, BF), Xa.to(dev, BF), out=dw, p_rmajor=True, q_rmajor=True, accumulate=True)   # no workspace: fp32 atomics
+    check("gemm.tn.ring.atomic", dw, dY.t() @ Xa + 0.75, 2e-3, 2e-3)
+    dw = torch.full((n_out, k_in), 0.75, device=dev)
+    ops.gemm_wgrad_(dw, dY.to(dev, BF), Xa.to(dev, BF))                                             # workspace + reduce launch
+    check("gemm.tn.ring.ws", dw, dY.t() @ Xa + 0.75, 2e-3, 2e-3)
+    big = torch.zeros(n_out, k_in + 64, device=dev)
+    ops.gemm_wgrad_(big[:, :k_in], dY.to(dev, BF), Xa.to(dev, BF))                                  # strided destination
+    check("gemm.tn.ring.ws.ld", big[:, :k_in], dY.t() @ Xa, 2e-3, 2e-3)
+    assert float(big[:, k_in:].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------ attention

@@ -56,8 +56,9 @@ def main():
         report(f"gemm.dgrad.{tag}", timeit(lambda: ops.gemm(dY, W, out=dX, q_rmajor=True)), flops=2.0 * tokens * n * k)
         dW = torch.zeros(n, k, device=DEV)
         sk = 1 if (n // 128) * (k // 128) >= 256 else 4
-        report(f"gemm.wgrad.{tag}", timeit(lambda: ops.gemm(dY, A, out=dW, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=sk)),
-               flops=2.0 * tokens * n * k, split_k=sk)
+        report(f"gemm.wgrad.{tag}", timeit(lambda: ops.gemm_wgrad_(dW, dY, A, sk)), flops=2.0 * tokens * n * k)
+        Wt_ = W.t().contiguous()
+        report(f"gemm.dgrad_pretransposed.{tag}", timeit(lambda: ops.gemm(dY, Wt_, out=dX)), flops=2.0 * tokens * n * k)
         report(f"torch.wgrad.{tag}", timeit(lambda: torch.matmul(dY.t(), A)), flops=2.0 * tokens * n * k)
     g, b = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
     y, mean, rstd = ops.layernorm_fwd(X, g, b, 1e-5)
