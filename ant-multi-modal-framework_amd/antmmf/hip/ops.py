@@ -56,6 +56,9 @@ def _f32(t, name):
 
 
 # ------------------------------------------------------------------------------ LayerNorm
+_LN_SCRATCH = {}
+
+
 def layernorm_fwd(x, gamma, beta, eps, want_stats=True, act=None):
     """y = LN(act(x)); act=None is the plain LayerNorm."""
     _dev_ok(x, gamma, beta)
@@ -79,8 +82,15 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, 
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)
+    scratch = None
+    if cols > 1024 and (dgamma is not None or dbeta is not None):
+        scratch = _LN_SCRATCH.get(x.device)
+        if scratch is None or scratch.numel() < 2048 * cols:
+            scratch = torch.empty(2048 * 4096, dtype=torch.float32, device=x.device)
+            _LN_SCRATCH[x.device] = scratch
     _rc(_lib.load().antmmf_act_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
-                                             _p(dbeta), rows, cols, ACT_IDS[act], _dt(x), _stream()), "antmmf_act_layernorm_bwd")
+                                             _p(dbeta), rows, cols, ACT_IDS[act], _dt(x), _p(scratch),
+                                             0 if scratch is None else scratch.numel(), _stream()), "antmmf_act_layernorm_bwd")
     return dx
 
 

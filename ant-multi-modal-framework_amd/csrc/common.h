@@ -155,5 +155,22 @@ __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
     }
 }
 
+// erf-GELU value and derivative from ONE exponential: with t = 1 / (1 + p |x|/sqrt2) and e = exp(-x^2 / 2),
+// erf(|x|/sqrt2) = 1 - poly5(t) e  (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7), cdf = 0.5 (1 + sign(x) erf), pdf = e / sqrt(2 pi).
+__device__ __forceinline__ void gelu_erf_fwd_grad(float x, float& z, float& dz) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = 1.0f / (1.0f + 0.3275911f * ax);
+    const float e = __expf(-0.5f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    const float cdf = 0.5f * (1.0f + (x >= 0.f ? erf_abs : -erf_abs));
+    z = x * cdf;
+    dz = cdf + x * 0.39894228040143268f * e;
+}
+__device__ __forceinline__ void act_fwd_grad(float x, int act, float& z, float& dz) {
+    if (act == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad(x, z, dz);
+    else { z = act_fwd(x, act); dz = act_grad(x, act); }
+}
+
 static inline int antmmf_check_launch() { return hipGetLastError() == hipSuccess ? ANTMMF_OK : ANTMMF_ELAUNCH; }
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

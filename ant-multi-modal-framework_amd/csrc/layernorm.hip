@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             if (vi < nvec) {
                 ld8<T>(xr + vi * 8, v[i]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[i][e] = act_fwd(v[i][e], act); s += v[i][e]; }
+                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, long rows, int cols, int act) {
+                                                     float* __restrict__ dbeta, long rows, int cols, int act, float* __restrict__ partials) {
     ANTMMF_DYN_LDS(float, red);  // wave-per-row: [2][cols] cross-wave column sums; workgroup-per-row: unused
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 ld8<T>(dy + row * cols + vi * 8, dv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float z = act_fwd(xv[e], act);
-                    da[i][e] = act_grad(xv[e], act);
+                    float z;
+                    act_fwd_grad(xv[e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
                     g[i][e] = dv[e] * gm[i][e];
                     s1 += g[i][e];
@@ -153,6 +153,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 st8<T>(dx + row * cols + vi * 8, o);
             }
         }
+    }
+    if (BLOCK && partials) {  // per-workgroup partial column sums [grid][2][cols], reduced by ln_partials_reduce_kernel
+        float* pg = partials + (long)blockIdx.x * 2 * cols;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = v0 + vstep * i;
+            if (vi < nvec) { st8<float>(pg + vi * 8, ag[i]); st8<float>(pg + cols + vi * 8, ab[i]); }
+        }
+        return;
     }
     if (BLOCK) {  // a thread owns its columns within the workgroup: straight to global
 #pragma unroll
@@ -187,6 +196,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+// dgamma[c] += sum_b partials[b][0][c];  dbeta[c] += sum_b partials[b][1][c]
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partials, int nblocks, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * 2 * cols + c];
+    float* dst = c < cols ? dgamma : dbeta;
+    if (dst) dst[c < cols ? c : c - cols] += s;
+}
+
 template <typename T>
 static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
                          int cols, float eps, int act, hipStream_t s) {
@@ -204,18 +223,24 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
 
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
-                         const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, int act, hipStream_t s) {
+                         const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, int act, float* partials,
+                         long partial_elems, hipStream_t s) {
     const int nvec = cols / 8;
     const long want = (rows + 3) / 4;
-    const int gw = (int)(want < 512 ? want : 512), gb = (int)(rows < 1024 ? rows : 1024);
+    const int gw = (int)(want < 512 ? want : 512);
+    int gb = (int)(rows < 1024 ? rows : 1024);
+    const bool wide = nvec > 128;
+    if (wide && partials && partial_elems >= (long)gb * 2 * cols) { /* keep gb */ } else partials = nullptr;
     const size_t lds = (size_t)2 * cols * sizeof(float);
-#define LN_BWD(V, BLK, GRID, LDS) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols, act)
+#define LN_BWD(V, BLK, GRID, LDS) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols, act, partials)
     if (nvec <= 64) LN_BWD(1, false, gw, lds);
     else if (nvec <= 128) LN_BWD(2, false, gw, lds);
     else if (nvec <= 256) LN_BWD(1, true, gb, 16);
     else if (nvec <= 512) LN_BWD(2, true, gb, 16);
     else return ANTMMF_EINVAL;
 #undef LN_BWD
+    if (wide && partials && (dgamma || dbeta))
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, partials, gb, cols, dgamma, dbeta);
     return antmmf_check_launch();
 }
 
@@ -232,11 +257,11 @@ extern "C" int antmmf_act_layernorm_fwd(const void* x, const float* gamma, const
 
 extern "C" int antmmf_act_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                         const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, int act,
-                                        int dtype, hipStream_t stream) {
+                                        int dtype, float* partials, long partial_elems, hipStream_t stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !ln_args_ok(rows, cols)) return ANTMMF_EINVAL;
     if (rows == 0) return ANTMMF_OK;
-    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, stream)
-         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, stream)
+    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, partials, partial_elems, stream)
+         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, partials, partial_elems, stream)
                                 : ANTMMF_EINVAL;
 }
 
@@ -248,5 +273,5 @@ extern "C" int antmmf_layernorm_fwd(const void* x, const float* gamma, const flo
 extern "C" int antmmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                     const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                                     long rows, int cols, int dtype, hipStream_t stream) {
-    return antmmf_act_layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, ANTMMF_ACT_NONE, dtype, stream);
+    return antmmf_act_layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, ANTMMF_ACT_NONE, dtype, nullptr, 0, stream);
 }

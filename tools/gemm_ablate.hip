@@ -89,6 +89,70 @@ __global__ __launch_bounds__(512) void k(const uint16_t* __restrict__ P, const u
     }
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int MODE>
+__global__ __launch_bounds__(512) void k32(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, TI = 4, TJ = 2;  // wave tile 128 x 64 as 4 x 2 tiles of 32 x 32
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 2, wj = wave & 3, l31 = lane & 31, hi = lane >> 5;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x16_t acc[TI][TJ];
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const uint16_t* psrc[2]; const uint16_t* qsrc[2];
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        psrc[q] = P + (long)(i0 + row) * ld + sl; qsrc[q] = Q + (long)(j0 + row) * ld + sl;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 2; ++q) { glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024); glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024); }
+    };
+    if (MODE & 4) { for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t); }
+    else { for (int i = threadIdx.x; i < 32768 * STAGES / 4; i += 512) ((float*)smem)[i] = 0.001f * (i & 255); __syncthreads(); }
+    bf16x8_t qa[2][TJ], pb[2][TI];
+    for (int s2 = 0; s2 < 2; ++s2) { for (int t = 0; t < TJ; ++t) qa[s2][t] = (bf16x8_t){(short)(0x3c00 + lane), 1, 2, 3, 4, 5, 6, (short)t};
+        for (int t = 0; t < TI; ++t) pb[s2][t] = (bf16x8_t){(short)(0x3c00 + lane), 1, 2, 3, 4, 5, 6, (short)t}; }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (MODE & 4) { const int ahead = nk - 1 - kt; if (ahead >= 2) wait_le<8>(); else if (ahead == 1) wait_le<4>(); else wait_le<0>(); }
+        if (MODE & 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        if ((MODE & 4) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        if (MODE & 1) {
+            const char* ps = smem + (kt % STAGES) * 32768; const char* qs = ps + 16384;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                for (int t = 0; t < TJ; ++t) { const int row = wj * 64 + t * 32 + l31; qa[s2][t] = *(const bf16x8_t*)(qs + row * 64 + (((2 * s2 + hi) ^ swz32(row)) << 4)); }
+                for (int t = 0; t < TI; ++t) { const int row = wi * 128 + t * 32 + l31; pb[s2][t] = *(const bf16x8_t*)(ps + row * 64 + (((2 * s2 + hi) ^ swz32(row)) << 4)); }
+            }
+        } else {
+            for (int s2 = 0; s2 < 2; ++s2) { for (int t = 0; t < TJ; ++t) asm volatile("" : "+v"(qa[s2][t])); for (int t = 0; t < TI; ++t) asm volatile("" : "+v"(pb[s2][t])); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int it = 0; it < TI; ++it)
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s2][jt], pb[s2][it], acc[it][jt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0;
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) for (int e = 0; e < 16; ++e) s += acc[a][b][e];
+    if (s == 123.456f) out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run32(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k32<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k32<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k32<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+}
+
 template <int MODE>
 void run(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
     const int tiles = (I / 256) * (J / 256), nk = R / 32;
@@ -122,6 +186,9 @@ int main() {
         run<7 + 16>("full loop + scattered 8-B store tail", P, Q, out, I, J2, R2);
         run<7 + 32>("full loop + LDS-staged 16-B store tail", P, Q, out, I, J2, R2);
         run<0 + 32>("mfma only + LDS-staged store tail", P, Q, out, I, J2, R2);
+        run32<0>("32x32x16: mfma only", P, Q, out, I, J2, R2);
+        run32<1>("32x32x16: mfma + lds fragment reads", P, Q, out, I, J2, R2);
+        run32<7>("32x32x16: full loop (ring + barrier + reads)", P, Q, out, I, J2, R2);
     }
     return 0;
 }
