@@ -432,18 +432,27 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) issue(t);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;  // tiles issued after tile kt that may stay in flight
-        if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
+    int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;  // last tile this wave has issued
+    // wait until this wave's pieces of tile kt have landed (later tiles may stay in flight: counted vmcnt)
+    auto wait_tile = [&](int kt) {
+        const int ahead = issued - kt;
+        if (ahead >= 2) glds_wait_le<2 * G>();
         else if (ahead == 1) glds_wait_le<G>();
         else glds_wait_le<0>();
+    };
+    // Two-group staggered schedule (measured +21 % on the bare loop, tools/gemm_ablate.hip): waves 0-3 (group A) and waves
+    // 4-7 (group B) sit pairwise on the same SIMDs; B runs half a K-step behind A, so while one group issues its DMA pieces
+    // and reads its fragments the other group's 32 MFMAs keep the matrix pipe busy.  Phases are separated by workgroup
+    // barriers (two per K-step); A: [wait kt | bar | issue, read kt | bar | mfma kt], B: the same one phase later, with its
+    // wait for tile kt+1 pulled in front of the barrier that lets A start reading tile kt+1.
+    const bool late = wave >= 4;
+    if (late) { wait_tile(0); wg_barrier_lds_only(); }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!late) wait_tile(kt);
         wg_barrier_lds_only();
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
         const char* ps = smem + (kt % STAGES) * 32768;
         const char* qs = ps + 16384;
-        // fragment reads are issued in two batches AHEAD of the MFMAs that consume them (hipcc otherwise sinks each
-        // read next to its first use and waits lgkmcnt(0) after every one: measured 8 exposed LDS latencies per step)
         bf16x8_t qa[TJ], pb[TI];
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
@@ -451,30 +460,21 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmArgs g) {
             qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + row * 64 + ((grp ^ swz32(row)) << 4));
         }
 #pragma unroll
-        for (int t = 0; t < TI / 2; ++t) {
+        for (int t = 0; t < TI; ++t) {
             const int row = wi * 128 + t * 16 + l15;
             pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + row * 64 + ((grp ^ swz32(row)) << 4));
         }
+        if (late && kt + 1 < nk) wait_tile(kt + 1);
+        wg_barrier_lds_only();
         SCHED_FENCE();
 #pragma unroll
-        for (int t = TI / 2; t < TI; ++t) {
-            const int row = wi * 128 + t * 16 + l15;
-            pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + row * 64 + ((grp ^ swz32(row)) << 4));
-        }
-        SCHED_FENCE();
-#pragma unroll
-        for (int it = 0; it < TI / 2; ++it)
-#pragma unroll
-            for (int jt = 0; jt < TJ; ++jt)
-                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
-        SCHED_FENCE();
-#pragma unroll
-        for (int it = TI / 2; it < TI; ++it)
+        for (int it = 0; it < TI; ++it)
 #pragma unroll
             for (int jt = 0; jt < TJ; ++jt)
                 acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
         SCHED_FENCE();
     }
+    if (!late) wg_barrier_lds_only();  // balance group B's extra leading barrier
     if (g.raster & 8) {  // experiment: no store tail
         float sacc = 0.f;
 #pragma unroll
@@ -681,14 +681,19 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) issue(t);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;
-        if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
+    int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
+    auto wait_tile = [&](int kt) {
+        const int ahead = issued - kt;
+        if (ahead >= 2) glds_wait_le<2 * G>();
         else if (ahead == 1) glds_wait_le<G>();
         else glds_wait_le<0>();
+    };
+    const bool late = wave >= 4;  // staggered two-group schedule, see gemm_nt_ring_kernel
+    if (late) { wait_tile(0); wg_barrier_lds_only(); }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!late) wait_tile(kt);
         wg_barrier_lds_only();
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
         const char* ps = smem + (kt % STAGES) * 32768;
         const char* qs = ps + 16384;
         bf16x8_t qa[TJ], pb[TI];
@@ -696,6 +701,8 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
         for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
 #pragma unroll
         for (int t = 0; t < TI; ++t) pb[t] = frag_tr<ROWB>(ps, 8 * grp, wi * TI + t, l15);
+        if (late && kt + 1 < nk) wait_tile(kt + 1);
+        wg_barrier_lds_only();
         SCHED_FENCE();
 #pragma unroll
         for (int it = 0; it < TI; ++it)
@@ -704,6 +711,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
                 acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
         SCHED_FENCE();
     }
+    if (!late) wg_barrier_lds_only();
     if (g.raster & 8) {  // experiment: no store tail
         float sacc = 0.f;
 #pragma unroll

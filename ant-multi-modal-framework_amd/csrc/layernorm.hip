@@ -196,14 +196,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-// dgamma[c] += sum_b partials[b][0][c];  dbeta[c] += sum_b partials[b][1][c]
+// dgamma[c] += sum_b partials[b][0][c];  dbeta[c] += sum_b partials[b][1][c].   grid (2*cols/256, 8): a workgroup sums 1/8 of the
+// partial rows for 256 columns (4 row-slices x 64 float4 lanes), then one atomic per column.
 __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partials, int nblocks, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * cols) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * 2 * cols + c];
-    float* dst = c < cols ? dgamma : dbeta;
-    if (dst) dst[c < cols ? c : c - cols] += s;
+    __shared__ float4 red[4][64];
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lx * 4;            // column in the concatenated [2*cols] row
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < 2 * cols) {
+        for (int b = b0 + ly; b < b1; b += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (long)b * 2 * cols + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[ly][lx] = s;
+    __syncthreads();
+    if (ly == 0 && c < 2 * cols) {
+        const float4 a = red[0][lx], b = red[1][lx], d = red[2][lx], e = red[3][lx];
+        const float v[4] = {a.x + b.x + d.x + e.x, a.y + b.y + d.y + e.y, a.z + b.z + d.z + e.z, a.w + b.w + d.w + e.w};
+        float* dst = c < cols ? dgamma : dbeta;
+        const int cc = c < cols ? c : c - cols;
+        if (dst) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(dst + cc + k, v[k]);
+        }
+    }
 }
 
 template <typename T>
@@ -240,7 +259,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
     else return ANTMMF_EINVAL;
 #undef LN_BWD
     if (wide && partials && (dgamma || dbeta))
-        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, s, partials, gb, cols, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb, cols, dgamma, dbeta);
     return antmmf_check_launch();
 }
 

@@ -89,6 +89,93 @@ __global__ __launch_bounds__(512) void k(const uint16_t* __restrict__ P, const u
     }
 }
 
+// staggered two-group schedule: waves 0-3 (group A) and 4-7 (group B, one per SIMD each) run half a K-step apart, so that one
+// group's MFMA block overlaps the other's DMA issue + fragment reads.  Two barriers per K-step.
+template <int WITH_STORE>
+__global__ __launch_bounds__(512) void kstag(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, TI = 8, TJ = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 2, wj = wave & 3, l15 = lane & 15, grp = lane >> 4;
+    const bool late = wave >= 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[TI][TJ];
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* psrc[2]; const uint16_t* qsrc[2];
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        psrc[q] = P + (long)(i0 + row) * ld + sl; qsrc[q] = Q + (long)(j0 + row) * ld + sl;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 2; ++q) { glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024); glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024); }
+    };
+    auto wait_tile = [&](int kt) {  // this wave's pieces of tile kt have landed; `issued` = last tile this wave has issued
+        // tiles issued after kt that may stay in flight
+        return kt;
+    };
+    (void)wait_tile;
+    for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t);
+    int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;  // index of the last tile issued by this wave
+    auto W = [&](int kt) {
+        const int ahead = issued - kt;
+        if (ahead >= 2) wait_le<8>(); else if (ahead == 1) wait_le<4>(); else wait_le<0>();
+    };
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    if (late) { W(0); bar(); }
+    bf16x8_t qa[TJ], pb[TI];
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!late) W(kt);
+        bar();
+        if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
+        const char* ps = smem + (kt % STAGES) * 32768; const char* qs = ps + 16384;
+        for (int t = 0; t < TJ; ++t) { const int row = wj * 64 + t * 16 + l15; qa[t] = *(const bf16x8_t*)(qs + row * 64 + ((grp ^ swz32(row)) << 4)); }
+        for (int t = 0; t < TI; ++t) { const int row = wi * 128 + t * 16 + l15; pb[t] = *(const bf16x8_t*)(ps + row * 64 + ((grp ^ swz32(row)) << 4)); }
+        if (late && kt + 1 < nk) W(kt + 1);
+        bar();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) bar();
+    if (WITH_STORE) {
+        uint16_t* C = (uint16_t*)out; const long ldc = (long)ntiles_j * 256;
+        bar();
+        char* wl = smem + wave * 16384;
+        for (int it = 0; it < TI; ++it) for (int jt = 0; jt < TJ; ++jt) {
+            const int row = it * 16 + l15, slot = jt * 2 + (grp >> 1);
+            uint2 v; v.x = __float_as_uint(acc[it][jt][0]) >> 16 | (__float_as_uint(acc[it][jt][1]) & 0xffff0000u);
+            v.y = __float_as_uint(acc[it][jt][2]) >> 16 | (__float_as_uint(acc[it][jt][3]) & 0xffff0000u);
+            *(uint2*)(wl + row * 128 + ((slot ^ (row & 7)) << 4) + (grp & 1) * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 8 + (lane >> 3), ls = lane & 7;
+            const uint4 val = *(const uint4*)(wl + row * 128 + ((ls ^ (row & 7)) << 4));
+            *(uint4*)(C + (long)(i0 + wi * 128 + row) * ldc + j0 + wj * 64 + ls * 8) = val;
+        }
+    } else {
+        float s = 0;
+        for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (s == 123.456f) out[blockIdx.x * 512 + threadIdx.x] = s;
+    }
+}
+template <int WITH_STORE>
+void runstag(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&kstag<WITH_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kstag<WITH_STORE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(kstag<WITH_STORE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+}
+
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <int MODE>
 __global__ __launch_bounds__(512) void k32(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
@@ -186,6 +273,8 @@ int main() {
         run<7 + 16>("full loop + scattered 8-B store tail", P, Q, out, I, J2, R2);
         run<7 + 32>("full loop + LDS-staged 16-B store tail", P, Q, out, I, J2, R2);
         run<0 + 32>("mfma only + LDS-staged store tail", P, Q, out, I, J2, R2);
+        runstag<0>("STAGGERED two-group loop (no store)", P, Q, out, I, J2, R2);
+        runstag<1>("STAGGERED two-group loop + staged store", P, Q, out, I, J2, R2);
         run32<0>("32x32x16: mfma only", P, Q, out, I, J2, R2);
         run32<1>("32x32x16: mfma + lds fragment reads", P, Q, out, I, J2, R2);
         run32<7>("32x32x16: full loop (ring + barrier + reads)", P, Q, out, I, J2, R2);
