@@ -14,30 +14,40 @@
 //   * the k-order inside an MFMA is free as long as A and B agree, so the 32 key slots of one P.V MFMA are
 //     DEFINED as slot 8g+e -> key 4g+e of the even tile (e < 4) / key 4g+e-4 of the odd tile (e >= 4): the
 //     probabilities a lane already holds ARE its B fragment -- no LDS round trip, no cross-lane traffic;
-//   * V is stored transposed in LDS ([64 dh][keys]) so the matching A fragment is two 8-B reads; the
-//     transpose happens in registers on the way in (two key rows -> eight packed (k, k+1) words);
+//   * the matching A fragment (V^T, K^T, Q^T, dO^T: "16 head-dim rows x those 32 token slots") comes straight out of
+//     the ROW-MAJOR token tile with two ds_read_b64_tr_b16 (the gfx950 transposing LDS read: a 16-lane group reads a
+//     4-token x 16-dh block and lane i receives column i) -- no transposed copies in LDS, which halves the LDS footprint
+//     (2 workgroups per CU instead of 1 in the backward kernels) and removes the 8-ds_write_b32-per-row-pair staging;
 //   * every output fragment is "4 consecutive head-dim values of one token": 8-B stores.
-// LDS layouts: row tiles [tokens][64] with 128-B rows and the 16-B slot XOR-swizzled by lds_swz(row)
-// (conflict-free ds_read_b128 fragment reads); transposed tiles [64][tokens] with row stride 2*tokens+16 B
-// (odd multiple of 16 B: the 16 rows of a fragment read hit 16 distinct bank quads) and the word index
-// XOR-ed with (dh>>3)<<1 (keeps the transposing ds_write_b32 at <= 2-way).
+// LDS layout: token tiles [tokens][64] with 128-B rows, 16-B slot XOR-swizzled by attn_swz(row): conflict-free both for
+// the ds_read_b128 fragment reads (16 consecutive rows x one slot) and for the transposing reads (8 consecutive rows x
+// one 32-B slot pair per half-wave).
+// Softmax runs in the exp2 domain (scale and bias pre-multiplied by log2 e): one v_exp_f32 per score, no extra multiply.
 //
 // Replaces (reference): CLIP nn.MultiheadAttention core clip/model.py:245-251; BertSelfAttention
 // modeling_bert.py:144-161 (additive -10000 key mask); torchscale MultiheadAttention
 // multihead_attention.py:120-145 (-inf key padding, fp32 softmax); ViLBERT co-attention vilbert.py:360-400
 // (two calls with the streams swapped); DMAE TransformerClip dmae_utils.py:589-619.
 //
-// Roofline: MFMA-bound, 4*Nq*Nk*64 flop per (b, h) forward, 10*Nq*Nk*64 backward as written (scores and dP
-// are recomputed in both backward kernels).  Algorithmic HBM bytes per (b, h): fwd 2*64*(2Nq + 2Nk) + 4Nq.
+// Roofline: MFMA-bound on paper (4*Nq*Nk*64 flop per (b, h) forward, 14*Nq*Nk*64 backward as written: scores and dP
+// are recomputed in both backward kernels), in practice bounded by the softmax VALU work (~10 VALU slots per score).
+// Algorithmic HBM bytes per (b, h): fwd 2*64*(2Nq + 2Nk) + 4Nq.
 #include "common.h"
 
 // Compiler-level fence: keeps hipcc from hoisting every LDS fragment read of a fully unrolled tile loop to the
 // top (which costs > 256 VGPRs and spills); a few tiles' worth of reads stay in flight between fences.
 #ifdef ANTMMF_EMULATE
 #define LDS_FENCE() do {} while (0)
+#define EXP2F(x) exp2f(x)
+#define LOG2F(x) log2f(x)
 #else
 #define LDS_FENCE() asm volatile("" ::: "memory")
+#define EXP2F(x) __builtin_amdgcn_exp2f(x)
+#define LOG2F(x) __builtin_amdgcn_logf(x)
 #endif
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define ATTN_THREADS 384  // 6 waves: 18 key / 17 query tiles of the 257-token image tower split 3-3-3-3-3-3
 
 struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const float* key_bias;
@@ -48,44 +58,28 @@ struct AttnArgs {
     float scale;
 };
 
-// ---- staging helpers (256 threads) ------------------------------------------------------------------
-// rows [0, n_pad) x 64 bf16 -> swizzled row tile; rows >= n_valid are zero
+__device__ __forceinline__ int attn_swz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
+
+// rows [0, n_pad) x 64 bf16 -> swizzled token tile; rows >= n_valid are zero
 __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* __restrict__ src, long ld, int n_valid, int n_pad) {
-    for (int id = threadIdx.x; id < n_pad * 8; id += 256) {
+    for (int id = threadIdx.x; id < n_pad * 8; id += ATTN_THREADS) {
         const int row = id >> 3, slot = id & 7;
         const uint4 v = row < n_valid ? *reinterpret_cast<const uint4*>(src + (long)row * ld + slot * 8) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + row * 128 + ((slot ^ lds_swz(row)) << 4)) = v;
+        *reinterpret_cast<uint4*>(dst + row * 128 + ((slot ^ attn_swz(row)) << 4)) = v;
     }
 }
-// transposed tile: dst[dh][token], row stride S bytes, word (token pair) index XOR (dh>>3)<<1
-__device__ __forceinline__ void stage_transposed(char* dst, int S, const bf16_t* __restrict__ src, long ld, int n_valid, int n_pad) {
-    for (int u = threadIdx.x; u < (n_pad >> 1) * 8; u += 256) {
-        const int c = u & 7, tp = u >> 3, r0 = 2 * tp;
-        const uint4 a4 = r0 < n_valid ? *reinterpret_cast<const uint4*>(src + (long)r0 * ld + c * 8) : make_uint4(0, 0, 0, 0);
-        const uint4 b4 = r0 + 1 < n_valid ? *reinterpret_cast<const uint4*>(src + (long)(r0 + 1) * ld + c * 8) : make_uint4(0, 0, 0, 0);
-        const uint32_t a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
-        const int w = tp ^ (c << 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t lo = (e & 1) ? (a[e >> 1] >> 16) : (a[e >> 1] & 0xffffu);
-            const uint32_t hi = (e & 1) ? (b[e >> 1] & 0xffff0000u) : (b[e >> 1] << 16);
-            *reinterpret_cast<uint32_t*>(dst + (c * 8 + e) * S + w * 4) = lo | hi;
-        }
-    }
-}
-// A fragment of a row tile: row `row`, logical 16-B slot `slot`
+// fragment "token `row`, head-dim 8 slot .. 8 slot + 7" (A or B operand with the head dim as the contraction)
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int slot) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((slot ^ lds_swz(row)) << 4));
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((slot ^ attn_swz(row)) << 4));
 }
-// A fragment of a transposed tile for 32-token chunk c: tokens {32c+4g..+3, 32c+16+4g..+3} of row `dh`
-__device__ __forceinline__ bf16x8_t frag_transposed(const char* tile, int S, int dh, int c, int grp) {
-    const int x = ((dh >> 3) & 7) << 1;
-    const int w0 = (16 * c + 2 * grp) ^ x, w1 = (16 * c + 8 + 2 * grp) ^ x;
-    const uint2 lo = *reinterpret_cast<const uint2*>(tile + dh * S + w0 * 4);
-    const uint2 hi = *reinterpret_cast<const uint2*>(tile + dh * S + w1 * 4);
-    union { uint4 u; bf16x8_t f; } cv;
-    cv.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    return cv.f;
+// A fragment "head-dim row 16 dt + l15, token slots of 32-token chunk c" (tokens {32c+4g..+3, 32c+16+4g..+3}): the
+// transposed view of the row-major tile, two transposing reads
+__device__ __forceinline__ bf16x8_t frag_tokens(const char* tile, int c, int dt, int grp, int l15) {
+    const int row = 32 * c + 4 * grp + (l15 >> 2);           // row this lane supplies to the 4 x 16 block
+    const int slot = 2 * dt + ((l15 >> 1) & 1), sub = (l15 & 1) << 3;
+    const bf16x4_t lo = lds_read_tr16(tile + row * 128 + ((slot ^ attn_swz(row)) << 4) + sub);
+    const bf16x4_t hi = lds_read_tr16(tile + (row + 16) * 128 + ((slot ^ attn_swz(row + 16)) << 4) + sub);
+    return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8_t pack_frag(const float (&lo)[4], const float (&hi)[4]) {
     union { uint4 u; bf16x8_t f; } cv;
@@ -99,24 +93,30 @@ __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* p) {
 }
 __device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// key bias in the exp2 domain; padding keys get -inf
+__device__ __forceinline__ void stage_key_bias(float* kb, const AttnArgs& a, int b, int n_pad) {
+    for (int i = threadIdx.x; i < n_pad; i += ATTN_THREADS)
+        kb[i] = i < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + i] * LOG2E : 0.f) : -INFINITY;
+}
 
 // ---- forward ----------------------------------------------------------------------------------------
 template <int NCH>  // keys padded to 32 * NCH
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
-    constexpr int NKP = 32 * NCH, NT = 2 * NCH, VS = NKP * 2 + 16;
+    constexpr int NKP = 32 * NCH, NT = 2 * NCH;
     char* Ks = smem;
-    char* Vt = smem + NKP * 128;
-    float* kb = reinterpret_cast<float*>(Vt + 64 * VS);
+    char* Vs = smem + NKP * 128;
+    float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     stage_rows(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
-    stage_transposed(Vt, VS, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
-    for (int i = threadIdx.x; i < NKP; i += 256) kb[i] = i < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + i] : 0.f) : -INFINITY;
+    stage_rows(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
+    stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
+    const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
         const bf16_t* qp = a.q + ((long)b * a.Nq + qrow) * a.ldq + h * 64 + grp * 8;
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, grp), qf0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, 4 + grp), qf1, acc, 0, 0, 0);
             const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
-            s[t][0] = acc[0] * a.scale + bias.x; s[t][1] = acc[1] * a.scale + bias.y;
-            s[t][2] = acc[2] * a.scale + bias.z; s[t][3] = acc[3] * a.scale + bias.w;
+            s[t][0] = acc[0] * scale2 + bias.x; s[t][1] = acc[1] * scale2 + bias.y;
+            s[t][2] = acc[2] * scale2 + bias.z; s[t][3] = acc[3] * scale2 + bias.w;
             m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
         }
         m = grp_max(m);
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - m); sum += s[t][r]; }
+            for (int r = 0; r < 4; ++r) { s[t][r] = EXP2F(s[t][r] - m); sum += s[t][r]; }
         sum = grp_sum(sum);
-        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
         bf16x8_t pf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -156,35 +156,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_transposed(Vt, VS, 16 * dt + l15, c, grp), pf[c], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
             if (qi < a.Nq)
                 *reinterpret_cast<uint2*>(a.o + ((long)b * a.Nq + qi) * a.ldo + h * 64 + 16 * dt + 4 * grp) =
                     make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
         }
-        if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? m + __logf(sum) : -INFINITY;
+        if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
     }
 }
 
-// ---- backward 1: dQ (one workgroup per (b, h); K rows, V rows and K^T in LDS; waves walk query tiles) ----
+// ---- backward 1: dQ (one workgroup per (b, h); K and V token tiles in LDS; waves walk query tiles) ----
 template <int NCH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
-    constexpr int NKP = 32 * NCH, NT = 2 * NCH, TS = NKP * 2 + 16;
+    constexpr int NKP = 32 * NCH;
     char* Ks = smem;
     char* Vs = smem + NKP * 128;
-    char* Kt = Vs + NKP * 128;
-    float* kb = reinterpret_cast<float*>(Kt + 64 * TS);
+    float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const bf16_t* kbase = a.k + (long)b * a.Nk * a.ldk + h * 64;
-    stage_rows(Ks, kbase, a.ldk, a.Nk, NKP);
+    stage_rows(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
     stage_rows(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
-    stage_transposed(Kt, TS, kbase, a.ldk, a.Nk, NKP);
-    for (int i = threadIdx.x; i < NKP; i += 256) kb[i] = i < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + i] : 0.f) : -INFINITY;
+    stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
+    const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
         const long tok = (long)b * a.Nq + qrow;
@@ -206,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         }
         dsum = grp_sum(dsum);
         const float lse = a.lse[((long)b * a.heads + h) * a.Nq + qrow];
+        const float lse2 = lse * LOG2E;  // -inf for a fully masked query: exp2(z - (-inf)) is guarded below
         bf16x8_t dsf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -223,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = sa[r] * a.scale + bb[r] - lse;
-                    const float p = (lse == -INFINITY || z == -INFINITY) ? 0.f : __expf(z);
+                    const float z = sa[r] * scale2 + bb[r] - lse2;
+                    const float p = (lse == -INFINITY || z == -INFINITY) ? 0.f : EXP2F(z);
                     ds[hh][r] = p * (da[r] - dsum);
                 }
             }
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             f32x4_t g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_transposed(Kt, TS, 16 * dt + l15, c, grp), dsf[c], g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
             if (qi < a.Nq)
                 *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * 64 + 16 * dt + 4 * grp) =
                     make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
@@ -244,15 +243,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
 }
 
-// ---- backward 2: dK, dV (one workgroup per (b, h); Q rows, dO rows, Q^T, dO^T, lse, D in LDS; waves own key tiles) ----
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a, int NQP) {
+// ---- backward 2: dK, dV (one workgroup per (b, h); Q and dO token tiles, lse, D in LDS; waves own key tiles) ----
+__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const AttnArgs a, int NQP) {
     ANTMMF_DYN_LDS(char, smem);
-    const int TS = NQP * 2 + 16;
     char* Qs = smem;
     char* Ds = Qs + NQP * 128;
-    char* Qt = Ds + NQP * 128;
-    char* Dt = Qt + 64 * TS;
-    float* lse_s = reinterpret_cast<float*>(Dt + 64 * TS);
+    float* lse_s = reinterpret_cast<float*>(Ds + NQP * 128);
     float* dsum_s = lse_s + NQP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -261,12 +257,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a, int
     const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
     stage_rows(Qs, qbase, a.ldq, a.Nq, NQP);
     stage_rows(Ds, dobase, a.lddo, a.Nq, NQP);
-    stage_transposed(Qt, TS, qbase, a.ldq, a.Nq, NQP);
-    stage_transposed(Dt, TS, dobase, a.lddo, a.Nq, NQP);
-    for (int i = threadIdx.x; i < NQP; i += 256) {
+    for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {
         float d = 0.f, l = -INFINITY;
         if (i < a.Nq) {
-            l = a.lse[((long)b * a.heads + h) * a.Nq + i];
+            l = a.lse[((long)b * a.heads + h) * a.Nq + i] * LOG2E;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 float x[8], y[8];
@@ -281,15 +275,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a, int
     }
     __syncthreads();
 
+    const float scale2 = a.scale * LOG2E;
     const int nkt = (a.Nk + 15) >> 4, nqc = NQP >> 5;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += ATTN_THREADS / 64) {
         const int ki = kt * 16 + l15;
         const int krow = ki < a.Nk ? ki : a.Nk - 1;
         const bf16_t* kp = a.k + ((long)b * a.Nk + krow) * a.ldk + h * 64 + grp * 8;
         const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
         const bf16x8_t kf0 = load_frag_global(kp), kf1 = load_frag_global(kp + 32);
         const bf16x8_t vf0 = load_frag_global(vp), vf1 = load_frag_global(vp + 32);
-        const float kbias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] : 0.f) : -INFINITY;
+        const float kbias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
         f32x4_t dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -309,8 +304,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a, int
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = sa[r] * a.scale + kbias - ll[r];
-                    const float pr = (ll[r] == -INFINITY || kbias == -INFINITY) ? 0.f : __expf(z);
+                    const float z = sa[r] * scale2 + kbias - ll[r];
+                    const float pr = (ll[r] == -INFINITY || kbias == -INFINITY) ? 0.f : EXP2F(z);
                     p[hh][r] = pr;
                     ds[hh][r] = pr * (da[r] - dd[r]);
                 }
@@ -318,8 +313,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a, int
             const bf16x8_t pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_transposed(Dt, TS, 16 * dt + l15, c, grp), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_transposed(Qt, TS, 16 * dt + l15, c, grp), dsf, dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Ds, c, dt, grp, l15), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Qs, c, dt, grp, l15), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (ki < a.Nk) {
@@ -350,8 +345,8 @@ extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v,
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (!q || !k || !v || !o || !lse || !attn_args_ok(a)) return ANTMMF_EINVAL;
     const int nch = (Nk + 31) / 32;
-    const dim3 grid((unsigned)(B * heads)), block(256);
-#define FWD(N) do { const size_t lds = (size_t)(32 * N) * 128 + 64 * ((32 * N) * 2 + 16) + (32 * N) * 4; \
+    const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
+#define FWD(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
         set_lds(attn_fwd_kernel<N>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N>), grid, block, lds, stream, a); } while (0)
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
@@ -369,15 +364,15 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
     if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !attn_args_ok(a) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))
         return ANTMMF_EINVAL;
     const int nch = (Nk + 31) / 32;
-    const dim3 grid((unsigned)(B * heads)), block(256);
-#define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * 256 + 64 * ((32 * N) * 2 + 16) + (32 * N) * 4; \
+    const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
+#define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
         set_lds(attn_bwd_dq_kernel<N>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N>), grid, block, lds, stream, a); } while (0)
     if (nch <= 1) BWDQ(1); else if (nch <= 3) BWDQ(3); else if (nch <= 7) BWDQ(7); else BWDQ(9);
 #undef BWDQ
     int rc = antmmf_check_launch();
     if (rc) return rc;
     const int nqp = ((Nq + 31) / 32) * 32;
-    const size_t lds2 = (size_t)nqp * 256 + 2 * 64 * (nqp * 2 + 16) + (size_t)nqp * 8;
+    const size_t lds2 = (size_t)nqp * 256 + (size_t)nqp * 8;
     set_lds(attn_bwd_dkv_kernel, lds2);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, lds2, stream, a, nqp);
     return antmmf_check_launch();

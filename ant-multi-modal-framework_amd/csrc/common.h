@@ -28,7 +28,20 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
     return (bf16_t)(u >> 16);
 }
+#ifdef ANTMMF_EMULATE
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+#else
+// v_cvt_pk_bf16_f32 (gfx950): two fp32 -> packed bf16, round to nearest even, in ONE VALU op (the software rounding above is ~6)
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const hw_bf16x2_t b = __builtin_convertvector((hw_f32x2_t){lo, hi}, hw_bf16x2_t);
+    return __builtin_bit_cast(uint32_t, b);
+}
+// v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division sequence
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -131,44 +144,43 @@ __device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) {
 #define ANTMMF_ACT_QUICK_GELU 2  // x sigmoid(1.702 x)         (CLIP)
 #define ANTMMF_ACT_RELU 3
 
+// erf-GELU value and derivative from ONE exponential and ONE reciprocal: with t = 1 / (1 + p |x|/sqrt2) and e = exp(-x^2 / 2),
+// erf(|x|/sqrt2) = 1 - poly5(t) e  (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7 -- far below bf16 resolution),
+// cdf = 0.5 (1 + sign(x) erf), pdf = e / sqrt(2 pi).  ~23 VALU slots per element (libm erff + IEEE division: ~40; these kernels are
+// VALU-bound, not HBM-bound, with the library versions: measured 3.8 TB/s for a plain GELU pass).
+__device__ __forceinline__ void gelu_erf_fwd_grad(float x, float& z, float& dz) {
+    const float t = fast_rcp(1.0f + 0.23164189f * fabsf(x));  // 0.3275911 / sqrt2
+    const float e = __expf(-0.5f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erf = 0.5f - 0.5f * poly * e;  // 0.5 erf(|x|/sqrt2)
+    const float cdf = 0.5f + (x >= 0.f ? half_erf : -half_erf);
+    z = x * cdf;
+    dz = cdf + x * 0.39894228040143268f * e;
+}
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
-        case ANTMMF_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-        case ANTMMF_ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ANTMMF_ACT_GELU_ERF: { float z, dz; gelu_erf_fwd_grad(x, z, dz); return z; }
+        case ANTMMF_ACT_QUICK_GELU: return x * fast_rcp(1.0f + __expf(-1.702f * x));
         case ANTMMF_ACT_RELU: return fmaxf(x, 0.0f);
         default: return x;
     }
 }
 __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
     switch (act) {
-        case ANTMMF_ACT_GELU_ERF: {
-            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-            const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-            return cdf + x * pdf;
-        }
+        case ANTMMF_ACT_GELU_ERF: { float z, dz; gelu_erf_fwd_grad(x, z, dz); return dz; }
         case ANTMMF_ACT_QUICK_GELU: {
-            const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+            const float s = fast_rcp(1.0f + __expf(-1.702f * x));
             return s * (1.0f + 1.702f * x * (1.0f - s));
         }
         case ANTMMF_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
         default: return 1.0f;
     }
 }
-
-// erf-GELU value and derivative from ONE exponential: with t = 1 / (1 + p |x|/sqrt2) and e = exp(-x^2 / 2),
-// erf(|x|/sqrt2) = 1 - poly5(t) e  (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7), cdf = 0.5 (1 + sign(x) erf), pdf = e / sqrt(2 pi).
-__device__ __forceinline__ void gelu_erf_fwd_grad(float x, float& z, float& dz) {
-    const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = 1.0f / (1.0f + 0.3275911f * ax);
-    const float e = __expf(-0.5f * x * x);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    const float cdf = 0.5f * (1.0f + (x >= 0.f ? erf_abs : -erf_abs));
-    z = x * cdf;
-    dz = cdf + x * 0.39894228040143268f * e;
-}
+// ACT is a compile-time activation id, or -1 for "look at the run-time id"
+template <int ACT>
 __device__ __forceinline__ void act_fwd_grad(float x, int act, float& z, float& dz) {
-    if (act == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad(x, z, dz);
+    if (ACT == ANTMMF_ACT_NONE) { z = x; dz = 1.0f; }
+    else if (ACT == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad(x, z, dz);
     else { z = act_fwd(x, act); dz = act_grad(x, act); }
 }
 

@@ -681,19 +681,14 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) issue(t);
-    int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
-    auto wait_tile = [&](int kt) {
-        const int ahead = issued - kt;
-        if (ahead >= 2) glds_wait_le<2 * G>();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;
+        if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
         else if (ahead == 1) glds_wait_le<G>();
         else glds_wait_le<0>();
-    };
-    const bool late = wave >= 4;  // staggered two-group schedule, see gemm_nt_ring_kernel
-    if (late) { wait_tile(0); wg_barrier_lds_only(); }
-    for (int kt = 0; kt < nk; ++kt) {
-        if (!late) wait_tile(kt);
         wg_barrier_lds_only();
-        if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
         const char* ps = smem + (kt % STAGES) * 32768;
         const char* qs = ps + 16384;
         bf16x8_t qa[TJ], pb[TI];
@@ -701,8 +696,6 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
         for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
 #pragma unroll
         for (int t = 0; t < TI; ++t) pb[t] = frag_tr<ROWB>(ps, 8 * grp, wi * TI + t, l15);
-        if (late && kt + 1 < nk) wait_tile(kt + 1);
-        wg_barrier_lds_only();
         SCHED_FENCE();
 #pragma unroll
         for (int it = 0; it < TI; ++it)
@@ -711,7 +704,6 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
                 acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
         SCHED_FENCE();
     }
-    if (!late) wg_barrier_lds_only();
     if (g.raster & 8) {  // experiment: no store tail
         float sacc = 0.f;
 #pragma unroll

@@ -29,7 +29,7 @@ __device__ __forceinline__ float row_sum(float v, float* sh) {
 }
 
 // BLOCK = false: wave per row, lane handles vectors lane + 64 i.  BLOCK = true: workgroup per row, thread handles vectors tid + 256 i.
-template <typename T, int VPL, bool BLOCK>
+template <typename T, int VPL, bool BLOCK, int ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             if (vi < nvec) {
                 ld8<T>(xr + vi * 8, v[i]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
+                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad<ACT>(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // z = act(x);  dz = rstd * (g*dy - mean(g*dy) - zhat * mean(g*dy*zhat));  dx = dz * act'(x) [+ dres];
 // dgamma += sum_rows dy*zhat;  dbeta += sum_rows dy
-template <typename T, int VPL, bool BLOCK>
+template <typename T, int VPL, bool BLOCK, int ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float z;
-                    act_fwd_grad(xv[e], act, z, da[i][e]);
+                    act_fwd_grad<ACT>(xv[e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
                     g[i][e] = dv[e] * gm[i][e];
                     s1 += g[i][e];
@@ -190,6 +190,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
     }
     __syncthreads();
+    if (partials) {  // [grid][2][cols], reduced by ln_partials_reduce_kernel (no global atomics from 1000+ workgroups)
+        float* pg = partials + (long)blockIdx.x * 2 * cols;
+        for (int i = threadIdx.x; i < 2 * cols; i += 256) pg[i] = red[i];
+        return;
+    }
     for (int i = threadIdx.x; i < cols; i += 256) {
         if (dgamma) atomicAdd(&dgamma[i], red[i]);
         if (dbeta) atomicAdd(&dbeta[i], red[cols + i]);
@@ -229,7 +234,8 @@ template <typename T>
 static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
                          int cols, float eps, int act, hipStream_t s) {
     const int nvec = cols / 8;
-#define LN_FWD(V, BLK, GRID) hipLaunchKernelGGL((ln_fwd_kernel<T, V, BLK>), dim3(GRID), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, cols, eps, act)
+#define LN_FWD_A(V, BLK, GRID, A) hipLaunchKernelGGL((ln_fwd_kernel<T, V, BLK, A>), dim3(GRID), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, cols, eps, act)
+#define LN_FWD(V, BLK, GRID) do { if (act == ANTMMF_ACT_NONE) LN_FWD_A(V, BLK, GRID, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_FWD_A(V, BLK, GRID, ANTMMF_ACT_GELU_ERF); else LN_FWD_A(V, BLK, GRID, -1); } while (0)
     const int gw = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096), gb = (int)(rows < 4096 ? rows : 4096);
     if (nvec <= 64) LN_FWD(1, false, gw);
     else if (nvec <= 128) LN_FWD(2, false, gw);
@@ -237,6 +243,7 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
     else if (nvec <= 512) LN_FWD(2, true, gb);
     else return ANTMMF_EINVAL;
 #undef LN_FWD
+#undef LN_FWD_A
     return antmmf_check_launch();
 }
 
@@ -246,20 +253,30 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
                          long partial_elems, hipStream_t s) {
     const int nvec = cols / 8;
     const long want = (rows + 3) / 4;
-    const int gw = (int)(want < 512 ? want : 512);
-    int gb = (int)(rows < 1024 ? rows : 1024);
     const bool wide = nvec > 128;
-    if (wide && partials && partial_elems >= (long)gb * 2 * cols) { /* keep gb */ } else partials = nullptr;
+    // wave-per-row kernels: 2048 workgroups (8 waves / SIMD in flight) when the column sums can go through the partials
+    // scratch, otherwise 512 so that the closing global atomics (2 * cols per workgroup) stay cheap
+    int gw = (int)(want < 512 ? want : 512);
+    int gb = (int)(rows < 1024 ? rows : 1024);
+    if (wide) {
+        if (!(partials && partial_elems >= (long)gb * 2 * cols)) partials = nullptr;
+    } else {
+        const int gw_big = (int)(want < 2048 ? want : 2048);
+        if (partials && gw_big > 512 && partial_elems >= (long)gw_big * 2 * cols) gw = gw_big; else partials = nullptr;
+    }
+    const int gp = wide ? gb : gw;
     const size_t lds = (size_t)2 * cols * sizeof(float);
-#define LN_BWD(V, BLK, GRID, LDS) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols, act, partials)
+#define LN_BWD_A(V, BLK, GRID, LDS, A) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols, act, partials)
+#define LN_BWD(V, BLK, GRID, LDS) do { if (act == ANTMMF_ACT_NONE) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_GELU_ERF); else LN_BWD_A(V, BLK, GRID, LDS, -1); } while (0)
     if (nvec <= 64) LN_BWD(1, false, gw, lds);
     else if (nvec <= 128) LN_BWD(2, false, gw, lds);
     else if (nvec <= 256) LN_BWD(1, true, gb, 16);
     else if (nvec <= 512) LN_BWD(2, true, gb, 16);
     else return ANTMMF_EINVAL;
 #undef LN_BWD
-    if (wide && partials && (dgamma || dbeta))
-        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb, cols, dgamma, dbeta);
+#undef LN_BWD_A
+    if (partials && (dgamma || dbeta))
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256, 8), dim3(256), 0, s, partials, gp, cols, dgamma, dbeta);
     return antmmf_check_launch();
 }
 

@@ -30,6 +30,7 @@ def test_layernorm(ops):
         kc.case_layernorm(ops, DEV, dtype)
         kc.case_layernorm(ops, DEV, dtype, rows=1031, cols=768, eps=1e-12)
         kc.case_layernorm(ops, DEV, dtype, rows=517, cols=1024)
+        kc.case_layernorm(ops, DEV, dtype, rows=9001, cols=1024)  # partials path of the wave-per-row backward
         kc.case_layernorm(ops, DEV, dtype, rows=130, cols=4096)
         kc.case_layernorm(ops, DEV, dtype, rows=77, cols=3072)
 
