@@ -356,22 +356,28 @@ class _TransformerLayer(torch.autograd.Function):
         if spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
             dgw, dgb = lnw("ffn")
-            du = ops.layernorm_bwd(dgn, u, mf, rf, f32(P["ffn_w"]), dgw, dgb, act=spec.act)  # through LN and gelu at once
+            # through LN and gelu at once; the fc1 bias gradient (column sums of du) falls out of the same pass
+            b1_fused = P["b1"] is not None and P["b1"].requires_grad
+            du = ops.layernorm_bwd(dgn, u, mf, rf, f32(P["ffn_w"]), dgw, dgb, act=spec.act, dxsum=sink.buf(P["b1"]) if b1_fused else None)
             del dgn
         else:
+            b1_fused = False
             du = dgrad(ds2, P["w2"], gate=u, act=spec.act)  # (ds2 W2) * act'(u)
         ln_mid = ("ln2" if pre_ln else "ln1")
         h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
         _wgrad(sink, P["w1"], du, h2)
-        _bgrad(sink, P["b1"], du)
+        if not b1_fused:
+            _bgrad(sink, P["b1"], du)
         del h2
         dgw, dgb = lnw(ln_mid)
+        bo_fused = P["bo"] is not None and P["bo"].requires_grad  # out-projection bias gradient = column sums of dmid
+        bo_sum = sink.buf(P["bo"]) if bo_fused else None
         if pre_ln:
             dh2 = dgrad(du, P["w1"])
-            dmid = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2)  # + residual path
+            dmid = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2, dxsum=bo_sum)  # + residual path
         else:
             da = dgrad(du, P["w1"], residual=ds2)  # bert: a feeds the MLP and the residual
-            dmid = ops.layernorm_bwd(da, mid, m2_, r2, f32(P["ln1_w"]), dgw, dgb)
+            dmid = ops.layernorm_bwd(da, mid, m2_, r2, f32(P["ln1_w"]), dgw, dgb, dxsum=bo_sum)
         del du
 
         # ---- attention half
@@ -381,7 +387,8 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             o_n = o2
         _wgrad(sink, P["wo"], dmid, o_n)
-        _bgrad(sink, P["bo"], dmid)
+        if not bo_fused:
+            _bgrad(sink, P["bo"], dmid)
         del o_n
         do = dgrad(dmid, P["wo"])
         if spec.kind == "m2":

@@ -73,9 +73,12 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats=True, act=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, act=None):
-    """Gradient of y = LN(act(x)) w.r.t. x (+ dres); dgamma / dbeta (fp32) are accumulated in place when given."""
-    _dev_ok(dy, x, mean, rstd, gamma, dgamma, dbeta, dres)
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, act=None, dxsum=None):
+    """Gradient of y = LN(act(x)) w.r.t. x (+ dres); dgamma / dbeta (fp32) are accumulated in place when given, and so is
+    dxsum += column sums of the returned dx (the bias gradient of the Linear that produced x)."""
+    _dev_ok(dy, x, mean, rstd, gamma, dgamma, dbeta, dres, dxsum)
+    if dxsum is not None:
+        _f32(dxsum, "dxsum")
     _c(dy, "dy"); _c(x, "x")
     if dres is not None:
         _c(dres, "dres")
@@ -83,13 +86,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, 
     rows = x.numel() // cols
     dx = torch.empty_like(x)
     scratch = None
-    if dgamma is not None or dbeta is not None:  # per-workgroup column-sum partials (the library falls back to atomics without it)
+    if dgamma is not None or dbeta is not None or dxsum is not None:  # per-workgroup column-sum partials (the library falls back to atomics without it)
         scratch = _LN_SCRATCH.get(x.device)
-        if scratch is None or scratch.numel() < 2048 * cols:
-            scratch = torch.empty(2048 * 4096, dtype=torch.float32, device=x.device)
+        if scratch is None or scratch.numel() < 1024 * 3 * cols:
+            scratch = torch.empty(1024 * 3 * 4096, dtype=torch.float32, device=x.device)
             _LN_SCRATCH[x.device] = scratch
     _rc(_lib.load().antmmf_act_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
-                                             _p(dbeta), rows, cols, ACT_IDS[act], _dt(x), _p(scratch),
+                                             _p(dbeta), _p(dxsum), rows, cols, ACT_IDS[act], _dt(x), _p(scratch),
                                              0 if scratch is None else scratch.numel(), _stream()), "antmmf_act_layernorm_bwd")
     return dx
 

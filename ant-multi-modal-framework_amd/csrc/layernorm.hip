@@ -28,7 +28,26 @@ __device__ __forceinline__ float row_sum(float v, float* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// raw (still packed) 8-element vector of a row: lets the NEXT row's loads be issued before the current row is touched
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+        f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+    }
+};
+template <> struct raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+
 // BLOCK = false: wave per row, lane handles vectors lane + 64 i.  BLOCK = true: workgroup per row, thread handles vectors tid + 256 i.
+// Both walk rows with a grid stride and keep the next row's loads in flight while the current one is reduced.
 template <typename T, int VPL, bool BLOCK, int ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -40,20 +59,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int v0 = BLOCK ? threadIdx.x : lane, vstep = BLOCK ? 256 : 64;
     const float inv_n = 1.0f / (float)cols;
     const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
-    for (long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave; row < rows; row += rstep) {
-        const T* xr = x + row * cols;
+    long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
+    raw8<T> nx[VPL];
+    auto fetch = [&](long r) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            if (v0 + vstep * i < nvec) nx[i].load(x + r * cols + (v0 + vstep * i) * 8);
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += rstep) {
         float v[VPL][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int vi = v0 + vstep * i;
-            if (vi < nvec) {
-                ld8<T>(xr + vi * 8, v[i]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad<ACT>(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
+            if (v0 + vstep * i < nvec) {
+                nx[i].unpack(v[i]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+            }
+        }
+        if (row + rstep < rows) fetch(row + rstep);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            if (v0 + vstep * i < nvec) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad<ACT>(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
             }
         }
         const float mean = row_sum<BLOCK>(s, sh) * inv_n;
@@ -87,52 +118,79 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // z = act(x);  dz = rstd * (g*dy - mean(g*dy) - zhat * mean(g*dy*zhat));  dx = dz * act'(x) [+ dres];
-// dgamma += sum_rows dy*zhat;  dbeta += sum_rows dy
-template <typename T, int VPL, bool BLOCK, int ACT>
+// dgamma += sum_rows dy*zhat;  dbeta += sum_rows dy;  DXSUM: dxsum += sum_rows dx -- the bias gradient of the Linear whose
+// output this LayerNorm reads (fc1 for the fused gelu + ffn_layernorm; the attention out-projection for ln2 with the
+// residual gradient added), which would otherwise be a separate full read of dx.
+// Column sums leave through `partials` ([grid][NS][cols], reduced by ln_partials_reduce_kernel) or, without it, atomics.
+template <typename T, int VPL, bool BLOCK, int ACT, bool DXSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, long rows, int cols, int act, float* __restrict__ partials) {
-    ANTMMF_DYN_LDS(float, red);  // wave-per-row: [2][cols] cross-wave column sums; workgroup-per-row: unused
+                                                     float* __restrict__ dbeta, float* __restrict__ dxsum, long rows, int cols, int act,
+                                                     float* __restrict__ partials) {
+    constexpr int NS = DXSUM ? 3 : 2;
+    ANTMMF_DYN_LDS(float, red);  // wave-per-row: [NS][cols] cross-wave column sums; workgroup-per-row: unused
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = cols >> 3;
     const int v0 = BLOCK ? threadIdx.x : lane, vstep = BLOCK ? 256 : 64;
     const float inv_n = 1.0f / (float)cols;
     if (!BLOCK) {
-        for (int i = threadIdx.x; i < 2 * cols; i += 256) red[i] = 0.f;
+        for (int i = threadIdx.x; i < NS * cols; i += 256) red[i] = 0.f;
     }
-    float ag[VPL][8], ab[VPL][8], gm[VPL][8];
+    float ag[VPL][8], ab[VPL][8], ad[DXSUM ? VPL : 1][8], gm[VPL][8];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int vi = v0 + vstep * i;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; gm[i][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; gm[i][e] = 0.f; if (DXSUM) ad[i][e] = 0.f; }
         if (vi < nvec) ld8<float>(gamma + vi * 8, gm[i]);
     }
     const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
-    for (long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave; row < rows; row += rstep) {
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float zh[VPL][8], g[VPL][8], da[VPL][8];
-        float s1 = 0.f, s2 = 0.f;
+    long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
+    raw8<T> nx[VPL], nd[VPL], nr[VPL];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](long r) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
             if (vi < nvec) {
-                float xv[8], dv[8];
-                ld8<T>(x + row * cols + vi * 8, xv);
-                ld8<T>(dy + row * cols + vi * 8, dv);
+                nx[i].load(x + r * cols + vi * 8);
+                nd[i].load(dy + r * cols + vi * 8);
+                if (dres) nr[i].load(dres + r * cols + vi * 8);
+            }
+        }
+        nmean = mean_in[r]; nrstd = rstd_in[r];
+    };
+    if (row < rows) fetch(row);
+    for (; row < rows; row += rstep) {
+        const float mean = nmean, rstd = nrstd;
+        float zh[VPL][8], g[VPL][8], da[VPL][8], rs[VPL][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            if (v0 + vstep * i < nvec) {
+                nx[i].unpack(zh[i]);   // x for now
+                nd[i].unpack(g[i]);    // dy for now
+                if (dres) nr[i].unpack(rs[i]);
+            }
+        }
+        if (row + rstep < rows) fetch(row + rstep);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            if (v0 + vstep * i < nvec) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float z;
-                    act_fwd_grad<ACT>(xv[e], act, z, da[i][e]);
+                    const float dv = g[i][e];
+                    act_fwd_grad<ACT>(zh[i][e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
-                    g[i][e] = dv[e] * gm[i][e];
+                    g[i][e] = dv * gm[i][e];
                     s1 += g[i][e];
                     s2 += g[i][e] * zh[i][e];
-                    ag[i][e] += dv[e] * zh[i][e];
-                    ab[i][e] += dv[e];
+                    ag[i][e] += dv * zh[i][e];
+                    ab[i][e] += dv;
                 }
             }
         }
@@ -143,23 +201,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (vi < nvec) {
                 float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - c1 - zh[i][e] * c2) * da[i][e];
-                if (dres) {
-                    float r[8];
-                    ld8<T>(dres + row * cols + vi * 8, r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = rstd * (g[i][e] - c1 - zh[i][e] * c2);
+                    if (ACT != ANTMMF_ACT_NONE) o[e] *= da[i][e];
+                    if (dres) o[e] += rs[i][e];
+                    if (DXSUM) ad[i][e] += o[e];
                 }
                 st8<T>(dx + row * cols + vi * 8, o);
             }
         }
     }
-    if (BLOCK && partials) {  // per-workgroup partial column sums [grid][2][cols], reduced by ln_partials_reduce_kernel
-        float* pg = partials + (long)blockIdx.x * 2 * cols;
+    if (BLOCK && partials) {  // per-workgroup partial column sums [grid][NS][cols]
+        float* pg = partials + (long)blockIdx.x * NS * cols;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
-            if (vi < nvec) { st8<float>(pg + vi * 8, ag[i]); st8<float>(pg + cols + vi * 8, ab[i]); }
+            if (vi < nvec) {
+                st8<float>(pg + vi * 8, ag[i]); st8<float>(pg + cols + vi * 8, ab[i]);
+                if (DXSUM) st8<float>(pg + 2 * cols + vi * 8, ad[i]);
+            }
         }
         return;
     }
@@ -172,6 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 for (int e = 0; e < 8; ++e) {
                     if (dgamma) atomicAdd(&dgamma[vi * 8 + e], ag[i][e]);
                     if (dbeta) atomicAdd(&dbeta[vi * 8 + e], ab[i][e]);
+                    if (DXSUM) atomicAdd(&dxsum[vi * 8 + e], ad[i][e]);
                 }
             }
         }
@@ -186,46 +247,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             for (int e = 0; e < 8; ++e) {
                 atomicAdd(&red[vi * 8 + e], ag[i][e]);
                 atomicAdd(&red[cols + vi * 8 + e], ab[i][e]);
+                if (DXSUM) atomicAdd(&red[2 * cols + vi * 8 + e], ad[i][e]);
             }
         }
     }
     __syncthreads();
-    if (partials) {  // [grid][2][cols], reduced by ln_partials_reduce_kernel (no global atomics from 1000+ workgroups)
-        float* pg = partials + (long)blockIdx.x * 2 * cols;
-        for (int i = threadIdx.x; i < 2 * cols; i += 256) pg[i] = red[i];
+    if (partials) {
+        float* pg = partials + (long)blockIdx.x * NS * cols;
+        for (int i = threadIdx.x; i < NS * cols; i += 256) pg[i] = red[i];
         return;
     }
     for (int i = threadIdx.x; i < cols; i += 256) {
         if (dgamma) atomicAdd(&dgamma[i], red[i]);
         if (dbeta) atomicAdd(&dbeta[i], red[cols + i]);
+        if (DXSUM) atomicAdd(&dxsum[i], red[2 * cols + i]);
     }
 }
 
-// dgamma[c] += sum_b partials[b][0][c];  dbeta[c] += sum_b partials[b][1][c].   grid (2*cols/256, 8): a workgroup sums 1/8 of the
+// out_k[c] += sum_b partials[b][k][c]  (k = 0 dgamma, 1 dbeta, 2 dxsum).  grid (ns*cols/256, 8): a workgroup sums 1/8 of the
 // partial rows for 256 columns (4 row-slices x 64 float4 lanes), then one atomic per column.
-__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partials, int nblocks, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partials, int nblocks, int cols, int ns,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum) {
     __shared__ float4 red[4][64];
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int c = blockIdx.x * 256 + lx * 4;            // column in the concatenated [2*cols] row
+    const int c = blockIdx.x * 256 + lx * 4;            // column in the concatenated [ns*cols] row
     const int per = (nblocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < 2 * cols) {
+    if (c < ns * cols) {
         for (int b = b0 + ly; b < b1; b += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(partials + (long)b * 2 * cols + c);
+            const float4 v = *reinterpret_cast<const float4*>(partials + (long)b * ns * cols + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
     red[ly][lx] = s;
     __syncthreads();
-    if (ly == 0 && c < 2 * cols) {
+    if (ly == 0 && c < ns * cols) {
         const float4 a = red[0][lx], b = red[1][lx], d = red[2][lx], e = red[3][lx];
         const float v[4] = {a.x + b.x + d.x + e.x, a.y + b.y + d.y + e.y, a.z + b.z + d.z + e.z, a.w + b.w + d.w + e.w};
-        float* dst = c < cols ? dgamma : dbeta;
-        const int cc = c < cols ? c : c - cols;
+        const int k = c / cols;                          // cols % 8 == 0: the 4 columns stay inside one sum
+        float* dst = k == 0 ? dgamma : k == 1 ? dbeta : dxsum;
+        const int cc = c - k * cols;
         if (dst) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(dst + cc + k, v[k]);
+            for (int j = 0; j < 4; ++j) atomicAdd(dst + cc + j, v[j]);
         }
     }
 }
@@ -249,24 +314,20 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
 
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
-                         const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, int act, float* partials,
-                         long partial_elems, hipStream_t s) {
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, long rows, int cols, int act,
+                         float* partials, long partial_elems, hipStream_t s) {
     const int nvec = cols / 8;
     const long want = (rows + 3) / 4;
     const bool wide = nvec > 128;
-    // wave-per-row kernels: 2048 workgroups (8 waves / SIMD in flight) when the column sums can go through the partials
-    // scratch, otherwise 512 so that the closing global atomics (2 * cols per workgroup) stay cheap
-    int gw = (int)(want < 512 ? want : 512);
-    int gb = (int)(rows < 1024 ? rows : 1024);
-    if (wide) {
-        if (!(partials && partial_elems >= (long)gb * 2 * cols)) partials = nullptr;
-    } else {
-        const int gw_big = (int)(want < 2048 ? want : 2048);
-        if (partials && gw_big > 512 && partial_elems >= (long)gw_big * 2 * cols) gw = gw_big; else partials = nullptr;
-    }
-    const int gp = wide ? gb : gw;
-    const size_t lds = (size_t)2 * cols * sizeof(float);
-#define LN_BWD_A(V, BLK, GRID, LDS, A) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, rows, cols, act, partials)
+    const int ns = dxsum ? 3 : 2;
+    // wave-per-row: 512 workgroups, closing LDS reduce + 2-3 * cols global atomics each (a bigger grid through the partials
+    // scratch was measured SLOWER: the per-workgroup closing phase dominates).  workgroup-per-row: 1024 workgroups, partials.
+    const int gw = (int)(want < 512 ? want : 512);
+    const int gb = (int)(rows < 1024 ? rows : 1024);
+    if (!(wide && partials && partial_elems >= (long)gb * ns * cols)) partials = nullptr;
+    const size_t lds = (size_t)ns * cols * sizeof(float);
+#define LN_BWD_D(V, BLK, GRID, LDS, A, D) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials)
+#define LN_BWD_A(V, BLK, GRID, LDS, A) do { if (dxsum) LN_BWD_D(V, BLK, GRID, LDS, A, true); else LN_BWD_D(V, BLK, GRID, LDS, A, false); } while (0)
 #define LN_BWD(V, BLK, GRID, LDS) do { if (act == ANTMMF_ACT_NONE) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_GELU_ERF); else LN_BWD_A(V, BLK, GRID, LDS, -1); } while (0)
     if (nvec <= 64) LN_BWD(1, false, gw, lds);
     else if (nvec <= 128) LN_BWD(2, false, gw, lds);
@@ -275,8 +336,9 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
     else return ANTMMF_EINVAL;
 #undef LN_BWD
 #undef LN_BWD_A
-    if (partials && (dgamma || dbeta))
-        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((2 * cols + 255) / 256, 8), dim3(256), 0, s, partials, gp, cols, dgamma, dbeta);
+#undef LN_BWD_D
+    if (partials && (dgamma || dbeta || dxsum))
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((ns * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb, cols, ns, dgamma, dbeta, dxsum);
     return antmmf_check_launch();
 }
 
@@ -292,12 +354,12 @@ extern "C" int antmmf_act_layernorm_fwd(const void* x, const float* gamma, const
 }
 
 extern "C" int antmmf_act_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                        const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, int act,
+                                        const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, long rows, int cols, int act,
                                         int dtype, float* partials, long partial_elems, hipStream_t stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !ln_args_ok(rows, cols)) return ANTMMF_EINVAL;
     if (rows == 0) return ANTMMF_OK;
-    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, partials, partial_elems, stream)
-         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, act, partials, partial_elems, stream)
+    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, stream)
+         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, stream)
                                 : ANTMMF_EINVAL;
 }
 
@@ -309,5 +371,5 @@ extern "C" int antmmf_layernorm_fwd(const void* x, const float* gamma, const flo
 extern "C" int antmmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                     const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                                     long rows, int cols, int dtype, hipStream_t stream) {
-    return antmmf_act_layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, rows, cols, ANTMMF_ACT_NONE, dtype, nullptr, 0, stream);
+    return antmmf_act_layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, nullptr, rows, cols, ANTMMF_ACT_NONE, dtype, nullptr, 0, stream);
 }

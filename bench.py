@@ -194,7 +194,8 @@ def main():
             "config": {"workload": f"M2_Encoder {'ViT-L/14 (beit large, patch 14, 21+3 layers)' if a.workload == 'l14' else 'ViT-B/16 (beit base, 9+3 layers)'} ITC train step, 224x224x3 + 77 tokens",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "loss": round(final_loss, 5), "step_tflops_per_gpu": round(step_tflops, 1),
-                       "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4)},
+                       "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4),
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),

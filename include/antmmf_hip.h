@@ -53,11 +53,14 @@ int antmmf_layernorm_bwd(const void* dy, const void* x, const float* mean, const
  * torchscale FFN's gelu -> ffn_layernorm pair (feedforward_network.py:117-128).  act = ANTMMF_ACT_*. */
 int antmmf_act_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                              int64_t rows, int cols, float eps, int act, int dtype, antmmf_stream_t stream);
-/* `partials` (nullable fp32 scratch of >= 2048 * cols elements) lets the wide-row variant (cols > 1024) write per-workgroup
- * column sums and reduce them in a second launch instead of issuing ~8 M fp32 atomics per call. */
+/* `dxsum` (nullable, fp32 [cols], accumulated): column sums of the returned dx = the bias gradient of the Linear that
+ * produced x (fc1 for the fused gelu + ffn_layernorm pair; the attention out-projection for the LayerNorm behind it, with
+ * the residual gradient in `dres`) -- saves a separate full read of dx.
+ * `partials` (nullable fp32 scratch of >= 1024 * 3 * cols elements) lets the wide-row variant (cols > 1024) write
+ * per-workgroup column sums and reduce them in a second launch instead of issuing ~8 M fp32 atomics per call. */
 int antmmf_act_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                             const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, int act,
-                             int dtype, float* partials, int64_t partial_elems, antmmf_stream_t stream);
+                             const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int cols,
+                             int act, int dtype, float* partials, int64_t partial_elems, antmmf_stream_t stream);
 
 /* ---- activations (n % 8 == 0): g = act(u);  du = dg * act'(u). */
 int antmmf_act_fwd(const void* u, void* g, int64_t n, int act, int dtype, antmmf_stream_t stream);

@@ -55,8 +55,10 @@ def case_layernorm(ops, dev, dtype, rows=13, cols=128, eps=1e-5):
     y, mean, rstd = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), eps)
     dgam = torch.zeros(cols, device=dev)
     dbet = torch.zeros(cols, device=dev)
-    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, dres.to(dev, dtype))
+    dxs = torch.zeros(cols, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, dres.to(dev, dtype), dxsum=dxs)
     rt, at = (2e-2, 2e-2) if dtype == BF else (1e-5, 1e-5)
+    check("ln.dxsum", dxs, (xr.grad + dres).sum(0), 1e-3, (2e-2 if dtype == BF else 1e-4) * max(1.0, rows ** 0.5))
     check("ln.y", y, yr, rt, at)
     check("ln.mean", mean, x.mean(-1), 1e-5, 1e-5)
     check("ln.dx", dx, xr.grad + dres, rt, at)
@@ -79,8 +81,10 @@ def case_act_layernorm(ops, dev, dtype, rows=9, cols=512, act="gelu"):
     yr.backward(dy)
     y, mean, rstd = ops.layernorm_fwd(x.to(dev, dtype), g.to(dev), b.to(dev), 1e-5, act=act)
     dgam, dbet = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
-    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, act=act)
+    dxs = torch.zeros(cols, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), dgam, dbet, act=act, dxsum=dxs)
     rt, at = (2e-2, 2e-2) if dtype == BF else (1e-4, 1e-5)
+    check(f"actln.{act}.dxsum", dxs, xr.grad.sum(0), 1e-3, (2e-2 if dtype == BF else 1e-4) * max(1.0, rows ** 0.5))
     check(f"actln.{act}.y", y, yr, rt, at)
     check(f"actln.{act}.dx", dx, xr.grad, rt, at)
     check(f"actln.{act}.dgamma", dgam, gr.grad, 2e-2 if dtype == BF else 1e-4, 2e-2 if dtype == BF else 1e-4)
