@@ -252,6 +252,18 @@ def _packed_qkv_weight(P, spec):
     return w, b
 
 
+# Activation-memory policy.  By default a layer saves 20 B per token-channel (x, qkv, o, mid, u) and recomputes every
+# normalised tensor in backward.  KEEP_FFN_NORM additionally keeps g_n = ffn_layernorm(gelu(u)) (+8 B per token-channel, the
+# widest recompute: one full pass over the 4d-wide tensor per layer) -- worth it when HBM allows (288 GB on MI355X: the
+# ViT-L/14 step at 1024 pairs/GPU peaks at ~175 GiB without it).  Set through set_keep_ffn_norm().
+KEEP_FFN_NORM = False
+
+
+def set_keep_ffn_norm(flag):
+    global KEEP_FFN_NORM
+    KEEP_FFN_NORM = bool(flag)
+
+
 class _TransformerLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, key_bias, spec, *params):
@@ -303,6 +315,7 @@ class _TransformerLayer(torch.autograd.Function):
             g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
         res = mid if pre_ln else h2
         y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
+        kept_gn = g_n if (KEEP_FFN_NORM and spec.kind == "m2") else None
         del g_n
         st_y = None
         s2 = None
@@ -314,6 +327,7 @@ class _TransformerLayer(torch.autograd.Function):
         for st in (st1, st_in, st2, st_f, st_y):
             saved += list(st) if st is not None else [None, None]
         saved.append(s2)
+        saved.append(kept_gn)
         ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.shape, ctx.nsaved = spec, (B, N, d), len(saved)
         return y.view(B, N, d)
@@ -326,7 +340,7 @@ class _TransformerLayer(torch.autograd.Function):
         sv = ctx.saved_tensors
         x2, qkv, o, lse, mid, u, key_bias = sv[:7]
         (m1, r1, mi, ri, m2_, r2, mf, rf, my, ry) = sv[7:17]
-        s2 = sv[17]
+        s2, kept_gn = sv[17], sv[18]
         params = sv[ctx.nsaved:]
         P = dict(zip(SLOTS, params))
         sink = GradSink()
@@ -346,7 +360,9 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             dgw, dgb = lnw("ln2")
             ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb)
-        if spec.kind == "m2":
+        if kept_gn is not None:
+            g_n = kept_gn
+        elif spec.kind == "m2":
             g_n, _, _ = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False, act=spec.act)
         else:
             g_n = ops.act_fwd(u, spec.act)

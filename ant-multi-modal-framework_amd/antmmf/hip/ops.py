@@ -268,7 +268,8 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
                                      int(split_k), _stream()), "antmmf_gemm_bf16")
     if ev is not None:
         ev[1].record()
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * I * J * R, ("tn" if p_rmajor else ("nn" if q_rmajor else "nt"))))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * I * J * R, ("tn" if p_rmajor else ("nn" if q_rmajor else "nt")),
+                           (I, J, R, ("b" if bias is not None else "") + ("r" if residual is not None else "") + (act or "") + ("g" if gate is not None else ""))))
     return out
 
 
@@ -300,7 +301,7 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1):
                                            int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
     if ev is not None:
         ev[1].record()
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_out * k_in, "tn"))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_out * k_in, "tn", (n_out, k_in, tokens, "wgrad")))
     return dW
 
 

@@ -796,7 +796,9 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
              !bias && act == ANTMMF_ACT_NONE && !residual && !aux && !gate && R >= 4096) {
         // wgrad ring: the host-side split_k hint is replaced by "enough workgroups to fill 256 CUs twice"
         const int tiles = (I / 256) * (J / 256), nk32 = R / 32;
-        int sp = (512 + tiles - 1) / tiles;
+        static const char* wgs_env = getenv("ANTMMF_WGRAD_WGS");  // experiments only
+        const int want_wgs = wgs_env ? atoi(wgs_env) : 512;
+        int sp = (want_wgs + tiles - 1) / tiles;
         if (sp > 16) sp = 16;
         if (sp > nk32 / 8) sp = nk32 / 8 > 0 ? nk32 / 8 : 1;
         g.ksteps_per_split = (nk32 + sp - 1) / sp;

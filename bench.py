@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--workload", default="l14", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--recompute-ffn-norm", action="store_true", help="do not keep ffn_layernorm(gelu(u)) for backward (saves ~65 GiB at 1024 pairs/GPU, costs ~3 %%)")
+    ap.add_argument("--gemm-table", default=None, help="write per-shape GEMM timing (from the live HIP-event trace) to this file")
     ap.add_argument("--cpu-sample", type=int, default=2, help="pairs in the CPU-oracle sample")
     return ap.parse_args()
 
@@ -130,12 +132,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from antmmf.hip import _lib, ops
+    from antmmf.hip import _lib, functional, ops
     from antmmf.hip.arena import HipAdamW
     from vlmo.config import default_config
     from vlmo.modules.vlmo_module import VLMo
 
     assert _lib.backend() == 1, "bench.py must run on the gfx950 library"
+    # activation-memory policy: keep the 4d-wide normalised FFN activation when the device has the HBM for it
+    keep_ffn = (not a.recompute_ffn_norm) and torch.cuda.get_device_properties(device).total_memory >= 250 * 2 ** 30 and a.batch <= 1024
+    functional.set_keep_ffn_norm(keep_ffn)
     cfg = default_config()
     cfg.update(WORKLOADS[a.workload])
     torch.manual_seed(1234)  # identical replicas on every rank
@@ -153,8 +158,11 @@ def main():
         opt.zero_grad()
         return loss
 
+    loss0 = None
     for _ in range(a.warmup):
         loss = step()
+        if loss0 is None:
+            loss0 = float(loss.detach())  # loss of the untouched random init: depends on the forward numerics only
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -177,14 +185,23 @@ def main():
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         pairs_per_s = a.batch * world * a.steps / elapsed
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in trace)
-        gemm_flops = sum(f for _, _, f, _ in trace)
+        gemm_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
+        gemm_flops = sum(t[2] for t in trace)
         n = max(1, len(trace))
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         per_layout = {}
-        for e0, e1, f, tag in trace:
+        for e0, e1, f, tag, _shape in trace:
             d = per_layout.setdefault(tag, [0.0, 0.0, 0])
             d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+        if a.gemm_table:
+            shapes = {}
+            for e0, e1, f, tag, shp in trace:
+                d = shapes.setdefault((tag,) + tuple(shp), [0.0, 0.0, 0])
+                d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+            with open(a.gemm_table, "w") as fh:
+                fh.write("layout I J R epilogue calls_per_step ms_per_step avg_us tflops\n")
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(" ".join(str(x) for x in k) + f" {v[2] / a.steps:.0f} {v[1] / a.steps:.3f} {v[1] / v[2] * 1e3:.1f} {v[0] / (v[1] * 1e-3) / 1e12:.1f}\n")
         step_tflops = pairs_per_s / world * TRAIN_GFLOP_PER_PAIR[a.workload] / 1e3
         out = {
             "metric": "image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192",
@@ -195,7 +212,9 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "loss": round(final_loss, 5), "step_tflops_per_gpu": round(step_tflops, 1),
                        "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4),
-                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+                       "loss_step0": None if loss0 is None else round(loss0, 5), "keep_ffn_norm": keep_ffn,
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),

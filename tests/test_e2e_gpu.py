@@ -35,6 +35,17 @@ def test_m2_itc_step_vs_oracle():
     print(mc.case_m2_itc_vs_oracle(DEV))
 
 
+def test_m2_itc_step_vs_oracle_keep_ffn_norm():
+    """Same step with the 4d-wide normalised FFN activation kept for backward instead of recomputed."""
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    try:
+        print(mc.case_m2_itc_vs_oracle(DEV))
+    finally:
+        functional.set_keep_ffn_norm(False)
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
 
