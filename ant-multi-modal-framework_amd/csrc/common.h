@@ -126,6 +126,21 @@ __device__ __forceinline__ bf16x4_t lds_read_tr16(const char* p) {
 }
 #endif
 
+// Same read as inline asm, for loops that keep LDS-DMA pieces in flight: hipcc's waitcnt pass puts an `s_waitcnt vmcnt(0)` in front
+// of the builtin form whenever a global_load_lds is outstanding (it cannot tell that the ring slots differ), which serialises
+// the whole DMA pipeline behind every K-step.  The asm form is invisible to that pass, so the caller must order it by hand:
+// lds_tr_fence(frags...) = s_waitcnt lgkmcnt(0) tied to the fragment registers.
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ bf16x4_t lds_read_tr16_raw(const char* p) { return emu_ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ bf16x4_t lds_read_tr16_raw(const char* p) {
+    bf16x4_t r;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+#endif
+
 // Scheduling fence: nothing is moved across it by the compiler's instruction scheduler (keeps a hand-chosen
 // "issue all fragment reads, then the MFMA block" order instead of hipcc's register-saving load->wait->use chains).
 #ifdef ANTMMF_EMULATE

@@ -513,6 +513,22 @@ __device__ __forceinline__ void dma_tile_rm(const bf16_t* __restrict__ base, lon
 }
 // fragment: columns c16*16 .. +15 (lane l15), r = rbase .. rbase+7 with rbase = 32 kk + 8 grp
 template <int ROWB>
+__device__ __forceinline__ bf16x8_t frag_tr_raw(const char* tile, int rbase, int c16, int l15) {
+    const int r0 = rbase + (l15 >> 2);
+    const int x = ftr(r0);
+    const char* p = tile + r0 * ROWB + ((c16 ^ x) << 5) + (l15 & 3) * 8;
+    const bf16x4_t lo = lds_read_tr16_raw(p), hi = lds_read_tr16_raw(p + 4 * ROWB);
+    return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// s_waitcnt lgkmcnt(0) that the compiler cannot move the consumers of q[0..3], p[0..7] across
+__device__ __forceinline__ void lds_tr_fence(bf16x8_t (&q)[4], bf16x8_t (&p)[8]) {
+#ifndef ANTMMF_EMULATE
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]),
+                   "+v"(p[6]), "+v"(p[7]));
+#endif
+}
+template <int ROWB>
 __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int rbase, int c16, int l15) {
     const int r0 = rbase + (l15 >> 2);
     const int x = ftr(r0);  // ftr(r0 + 4) == ftr(r0)
@@ -630,6 +646,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // ---- 4-stage LDS-DMA ring for wgrad (all-r-major): 256 x 256 output tile, 32 tokens per stage, natural [r][cols] LDS
 // image (512-B rows), fragments by ds_read_b64_tr_b16, split over the token range by gridDim.z (fp32 atomics when split).
+// STAGGER = true (product): the two-group schedule of gemm_nt_ring_kernel; false: one barrier per K-step (kept for A/B runs,
+// ANTMMF_GEMM_RASTER bit 4).  Measured on the ViT-L/14 wgrad shapes: 898 / 1014 / 921 vs 878 / 978 / 902 TFLOP/s.
+template <bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int STAGES = 4, BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, G = 4, ROWB = 512;
@@ -682,6 +701,40 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) issue(t);
 
+    if (STAGGER) {  // two-group schedule (see gemm_nt_ring_kernel)
+        int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
+        auto wait_tile = [&](int kt) {
+            const int ahead = issued - kt;
+            if (ahead >= 2) glds_wait_le<2 * G>();
+            else if (ahead == 1) glds_wait_le<G>();
+            else glds_wait_le<0>();
+        };
+        const bool late = wave >= 4;
+        if (late) { wait_tile(0); wg_barrier_lds_only(); }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!late) wait_tile(kt);
+            wg_barrier_lds_only();
+            if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
+            const char* ps = smem + (kt % STAGES) * 32768;
+            const char* qs = ps + 16384;
+            bf16x8_t qa[TJ], pb[TI];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) qa[t] = frag_tr_raw<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) pb[t] = frag_tr_raw<ROWB>(ps, 8 * grp, wi * TI + t, l15);
+            if (late && kt + 1 < nk) wait_tile(kt + 1);
+            lds_tr_fence(qa, pb);
+            wg_barrier_lds_only();
+            SCHED_FENCE();
+#pragma unroll
+            for (int it = 0; it < TI; ++it)
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+            SCHED_FENCE();
+        }
+        if (!late) wg_barrier_lds_only();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;
         if (ahead >= STAGES - 2) glds_wait_le<(STAGES - 2) * G>();
@@ -693,9 +746,12 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
         const char* qs = ps + 16384;
         bf16x8_t qa[TJ], pb[TI];
 #pragma unroll
-        for (int t = 0; t < TJ; ++t) qa[t] = frag_tr<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
+        for (int t = 0; t < TJ; ++t)
+            qa[t] = frag_tr_raw<ROWB>(qs, 8 * grp, wj * TJ + t, l15);
 #pragma unroll
-        for (int t = 0; t < TI; ++t) pb[t] = frag_tr<ROWB>(ps, 8 * grp, wi * TI + t, l15);
+        for (int t = 0; t < TI; ++t)
+            pb[t] = frag_tr_raw<ROWB>(ps, 8 * grp, wi * TI + t, l15);
+        lds_tr_fence(qa, pb);
         SCHED_FENCE();
 #pragma unroll
         for (int it = 0; it < TI; ++it)
@@ -797,7 +853,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         // wgrad ring: the host-side split_k hint is replaced by "enough workgroups to fill 256 CUs twice"
         const int tiles = (I / 256) * (J / 256), nk32 = R / 32;
         static const char* wgs_env = getenv("ANTMMF_WGRAD_WGS");  // experiments only
-        const int want_wgs = wgs_env ? atoi(wgs_env) : 512;
+        const int want_wgs = wgs_env ? atoi(wgs_env) : 256;
         int sp = (want_wgs + tiles - 1) / tiles;
         if (sp > 16) sp = 16;
         if (sp > nk32 / 8) sp = nk32 / 8 > 0 ? nk32 / 8 : 1;
@@ -806,8 +862,13 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         const bool use_ws = zs > 1 && workspace && workspace_bytes >= (long)zs * I * J * 4;
         if (use_ws) g.ws = workspace;
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
-        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            once = true;
+        }
+        if (g.raster & 16) hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
+        else hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
         if (use_ws) {
             const long nvec = (long)I * J / 4;
             const int rg = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
