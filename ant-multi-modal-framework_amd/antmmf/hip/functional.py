@@ -412,8 +412,19 @@ class _TransformerLayer(torch.autograd.Function):
             do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
+        # q / k / v projection bias gradients (column sums of dqkv) come out of the attention backward kernels
+        if spec.packed_qkv:
+            bsl = None
+            if P["bqkv"] is not None and P["bqkv"].requires_grad:
+                bb = sink.buf(P["bqkv"]).view(-1)
+                bsl = (bb[:d], bb[d:2 * d], bb[2 * d:])
+        else:
+            bsl = tuple(sink.buf(P["b" + nm]).view(-1) if (P["b" + nm] is not None and P["b" + nm].requires_grad) else None for nm in "qkv")
+            if all(t is None for t in bsl):
+                bsl = None
+        dbq, dbk, dbv = bsl if bsl is not None else (None, None, None)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
-                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dbq=dbq, dbk=dbk, dbv=dbv)
         del do
         dqkv2 = dqkv.view(T, 3 * d)
         if pre_ln:
@@ -422,12 +433,10 @@ class _TransformerLayer(torch.autograd.Function):
             h = x2
         if spec.packed_qkv:
             _wgrad(sink, P["wqkv"], dqkv2, h)
-            _bgrad(sink, P["bqkv"], dqkv2)
         else:
             for i, nm in enumerate("qkv"):
                 sl = dqkv2[:, i * d:(i + 1) * d]
                 _wgrad(sink, P["w" + nm], sl, h)
-                _bgrad(sink, P["b" + nm], sl)
         del h
         dx = None
         if ctx.needs_input_grad[0]:

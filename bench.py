@@ -202,6 +202,13 @@ def main():
                 fh.write("layout I J R epilogue calls_per_step ms_per_step avg_us tflops\n")
                 for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     fh.write(" ".join(str(x) for x in k) + f" {v[2] / a.steps:.0f} {v[1] / a.steps:.3f} {v[1] / v[2] * 1e3:.1f} {v[0] / (v[1] * 1e-3) / 1e12:.1f}\n")
+        # HBM-side traffic per GEMM launch: measured in separate rocprofv3 --pmc passes over this same command
+        # (tools/gpu_traffic.sh) and committed under profiles/; null when no measurement matches the configuration
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{a.workload}_b{a.batch}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)["traffic_bytes_per_launch"] / 1e9, 3)  # GB per launch
         step_tflops = pairs_per_s / world * TRAIN_GFLOP_PER_PAIR[a.workload] / 1e3
         out = {
             "metric": "image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192",
@@ -216,7 +223,7 @@ def main():
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
-                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2-miss bytes, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; profiles/gemm_traffic_*.json)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),
                          "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
                          "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0}},
