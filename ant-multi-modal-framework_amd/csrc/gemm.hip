@@ -148,16 +148,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
 // EPI: compile-time epilogue shape -- bit 0 bias, bit 1 residual (no alpha / activation / gate / aux); 4 = everything, decided at
 // run time.  (With run-time checks inside the 32-tile unrolled loop hipcc emits ~600 basic blocks and the store tail of a
 // 256 x 256 tile took 3x longer: measured 0.31 ms vs 0.11 ms of a 0.86 ms fc1 GEMM.)
-template <int TI, int TJ, int EPI>
+// PASSES: the wave's (16 TI) x (16 TJ) tile goes through its LDS staging area in PASSES row blocks (staging bytes per wave =
+// TI * 16 * TJ * 32 / PASSES)
+template <int TI, int TJ, int EPI, int PASSES = 1>
 __device__ __forceinline__ void gemm_epilogue_bf16_staged(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj,
                                                           int lane, char* wave_lds) {
-    constexpr int ROWB = TJ * 32, SLOTS = ROWB / 16;
+    constexpr int ROWB = TJ * 32, SLOTS = ROWB / 16, TIP = TI / PASSES;
     constexpr bool GENERIC = EPI == 4, BIAS = GENERIC || (EPI & 1), RES = GENERIC || (EPI & 2);
     const int l15 = lane & 15, grp = lane >> 4;
 #pragma unroll
-    for (int it = 0; it < TI; ++it) {
-        const int row = it * 16 + l15;
-        int i = i0 + wi * (16 * TI) + row;
+  for (int ps = 0; ps < PASSES; ++ps) {
+    if (ps) WAVE_LDS_ORDER();  // the previous block's staged rows have been read back
+#pragma unroll
+    for (int itp = 0; itp < TIP; ++itp) {
+        const int it = ps * TIP + itp;
+        const int row = itp * 16 + l15;
+        int i = i0 + wi * (16 * TI) + it * 16 + l15;
         i = i < g.I ? i : g.I - 1;  // clamped rows are computed but never stored
 #pragma unroll
         for (int jt = 0; jt < TJ; ++jt) {
@@ -196,16 +202,17 @@ __device__ __forceinline__ void gemm_epilogue_bf16_staged(const GemmArgs& g, f32
     constexpr int ROWS_PER_PASS = 64 / SLOTS;
     bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
 #pragma unroll
-    for (int pass = 0; pass < (TI * 16) / ROWS_PER_PASS; ++pass) {
+    for (int pass = 0; pass < (TIP * 16) / ROWS_PER_PASS; ++pass) {
         const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
         const uint4 val = *reinterpret_cast<const uint4*>(wave_lds + row * ROWB + ((ls ^ (row & (SLOTS - 1))) << 4));
-        const int gi = i0 + wi * (16 * TI) + row, gj = j0 + wj * (16 * TJ) + ls * 8;
+        const int gi = i0 + wi * (16 * TI) + ps * TIP * 16 + row, gj = j0 + wj * (16 * TJ) + ls * 8;
         if (gi < g.I) {
             bf16_t* dst = C + (long)gi * g.ldc + gj;
             if (gj + 8 <= g.J) *reinterpret_cast<uint4*>(dst) = val;
             else if (gj + 4 <= g.J) *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
         }
     }
+  }
 }
 
 template <bool PT, bool QT>
@@ -597,6 +604,222 @@ __global__ __launch_bounds__(64 * NWI * NWJ) void gemm_tn_dma_kernel(const GemmA
     gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
 }
 
+// acc += bias (+ residual) in place, in the fragment layout -- done BEFORE the next tile's DMA prologue is issued: loads return
+// in order, so an epilogue that fetched its operands after the prologue would wait for the whole prologue to land first.
+template <int TI, int TJ, int EPI>
+__device__ __forceinline__ void epilogue_apply_operands(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj, int lane) {
+    const int l15 = lane & 15, grp = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < TJ; ++jt) {
+        int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
+        j = j < g.J ? j : g.J - 4;
+        if (EPI & 1) {
+            const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+#pragma unroll
+            for (int it = 0; it < TI; ++it) { acc[it][jt][0] += b.x; acc[it][jt][1] += b.y; acc[it][jt][2] += b.z; acc[it][jt][3] += b.w; }
+        }
+        if (EPI & 2) {
+#ifndef ANTMMF_EMULATE
+            if (!(jt & 1)) asm volatile("" ::: "memory");  // two jt columns (16 loads) at a time: all 32 in flight would spill
+#endif
+#pragma unroll
+            for (int it = 0; it < TI; ++it) {
+                int i = i0 + wi * (16 * TI) + it * 16 + l15;
+                i = i < g.I ? i : g.I - 1;
+                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                acc[it][jt][0] += bf_lo(u.x); acc[it][jt][1] += bf_hi(u.x); acc[it][jt][2] += bf_lo(u.y); acc[it][jt][3] += bf_hi(u.y);
+            }
+        }
+    }
+}
+
+// bf16 tile store staged through LDS with the LDS traffic as inline asm: with LDS-DMA pieces of the next tile in flight hipcc
+// guards every compiler-visible LDS access with `s_waitcnt vmcnt(0)` (see lds_read_tr16_raw), which would drain the prologue
+// before the first staged row.  A wave's LDS instructions execute in order, so write -> read-back needs no wait; the read-back
+// data is fenced with lgkmcnt(0) tied to the registers.  Operands (bias, residual) are already in acc.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <int TI, int TJ, int PASSES>
+__device__ __forceinline__ void epilogue_store_bf16_staged_raw(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj,
+                                                               int lane, char* wave_lds) {
+    constexpr int ROWB = TJ * 32, SLOTS = ROWB / 16, TIP = TI / PASSES, ROWS_PER_PASS = 64 / SLOTS, NRD = (TIP * 16) / ROWS_PER_PASS;
+    const int l15 = lane & 15, grp = lane >> 4;
+    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+        for (int itp = 0; itp < TIP; ++itp) {
+            const int it = ps * TIP + itp, row = itp * 16 + l15;
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) {
+                const int slot = jt * 2 + (grp >> 1);
+                char* dst = wave_lds + row * ROWB + ((slot ^ (row & (SLOTS - 1))) << 4) + (grp & 1) * 8;
+                const u32x2_t v = {pack_bf2(acc[it][jt][0], acc[it][jt][1]), pack_bf2(acc[it][jt][2], acc[it][jt][3])};
+#ifdef ANTMMF_EMULATE
+                *reinterpret_cast<u32x2_t*>(dst) = v;
+#else
+                asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst), "v"(v) : "memory");
+#endif
+            }
+        }
+        WAVE_LDS_ORDER();
+        u32x4_t val[NRD];
+#pragma unroll
+        for (int pass = 0; pass < NRD; ++pass) {
+            const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
+            const char* src = wave_lds + row * ROWB + ((ls ^ (row & (SLOTS - 1))) << 4);
+#ifdef ANTMMF_EMULATE
+            val[pass] = *reinterpret_cast<const u32x4_t*>(src);
+#else
+            asm volatile("ds_read_b128 %0, %1" : "=v"(val[pass]) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)src) : "memory");
+#endif
+        }
+#ifndef ANTMMF_EMULATE
+        static_assert(NRD == 4, "fence below lists four registers");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3])::"memory");
+#endif
+        WAVE_LDS_ORDER();
+#pragma unroll
+        for (int pass = 0; pass < NRD; ++pass) {
+            const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
+            const int gi = i0 + wi * (16 * TI) + ps * TIP * 16 + row, gj = j0 + wj * (16 * TJ) + ls * 8;
+            if (gi < g.I) {
+                bf16_t* dst = C + (long)gi * g.ldc + gj;
+                if (gj + 8 <= g.J) *reinterpret_cast<u32x4_t*>(dst) = val[pass];
+                else if (gj + 4 <= g.J) *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){val[pass][0], val[pass][1]};
+            }
+        }
+    }
+}
+
+// Persistent variant of gemm_nt_ring_kernel: one workgroup per CU walks its XCD's tile range; at a tile boundary the first three
+// K-stages of the NEXT tile are issued before the epilogue of the current one (which stages through the one ring slot the
+// prologue does not touch, 4 KiB per wave, four row blocks), so the DMA fill and most of the store drain overlap instead of
+// leaving the CU idle between workgroups (one 128-KiB workgroup per CU: nothing else can hide them).  Ring slots follow a
+// step counter that runs across tiles.  Same tile order as the non-persistent kernel (4 x 8 patches per XCD).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, int ntiles) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int STAGES = 4, BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, G = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int tiles_j = (g.J + BN - 1) / BN, tiles_i = (g.I + BM - 1) / BM;
+    const int nk = g.R >> 5;
+    // XCD x owns the contiguous tile-id range [xbase, xbase + xcount); this workgroup takes ids lx, lx + per_xcd, ...
+    const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int qd = ntiles >> 3, rm = ntiles & 7;
+    const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
+    auto tile_origin = [&](int local, int& i0, int& j0) {
+        const int wgid = xbase + local;
+        const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+        const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+        i0 = (band * 4 + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
+    };
+    const int prow[2] = {wave * 32 + (lane >> 2), wave * 32 + 16 + (lane >> 2)};
+    const bf16_t* psrc[2];
+    const bf16_t* qsrc[2];
+    auto set_sources = [&](int i0, int j0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = prow[q], sl = ((lane & 3) ^ swz32(row)) << 3;
+            int gi = i0 + row; gi = gi < g.I ? gi : g.I - 1;
+            int gj2 = j0 + row; gj2 = gj2 < g.J ? gj2 : g.J - 1;
+            psrc[q] = g.P + (long)gi * g.ldp + sl;
+            qsrc[q] = g.Q + (long)gj2 * g.ldq + sl;
+        }
+    };
+    int gs = 0;  // ring step counter at the start of the current tile
+    auto issue = [&](int kt) {
+        char* buf = smem + ((gs + kt) & (STAGES - 1)) * 32768;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024);
+            glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024);
+        }
+    };
+    int local = lx;
+    if (local >= xcount) return;
+    int i0, j0;
+    tile_origin(local, i0, j0);
+    set_sources(i0, j0);
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t);
+    const bool late = wave >= 4;
+    for (;;) {
+        f32x4_t acc[TI][TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
+        // counted vmcnt: conservative when epilogue stores of the previous tile are still in flight (they are younger than the
+        // prologue pieces, so "at most N outstanding" still implies the awaited pieces have landed)
+        auto wait_tile = [&](int kt) {
+            const int ahead = issued - kt;
+            if (ahead >= 2) glds_wait_le<2 * G>();
+            else if (ahead == 1) glds_wait_le<G>();
+            else glds_wait_le<0>();
+        };
+        if (late) { wait_tile(0); wg_barrier_lds_only(); }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!late) wait_tile(kt);
+            wg_barrier_lds_only();
+            if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
+            const char* ps = smem + ((gs + kt) & (STAGES - 1)) * 32768;
+            const char* qs = ps + 16384;
+            bf16x8_t qa[TJ], pb[TI];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) {
+                const int row = wj * 64 + t * 16 + l15;
+                qa[t] = *reinterpret_cast<const bf16x8_t*>(qs + row * 64 + ((grp ^ swz32(row)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int row = wi * 128 + t * 16 + l15;
+                pb[t] = *reinterpret_cast<const bf16x8_t*>(ps + row * 64 + ((grp ^ swz32(row)) << 4));
+            }
+            if (late && kt + 1 < nk) wait_tile(kt + 1);
+            wg_barrier_lds_only();
+            SCHED_FENCE();
+#pragma unroll
+            for (int it = 0; it < TI; ++it)
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
+            SCHED_FENCE();
+        }
+        if (!late) wg_barrier_lds_only();  // every wave has read its last fragments: all four ring slots are free
+        const int ci0 = i0, cj0 = j0;
+        if (EPI > 0) epilogue_apply_operands<TI, TJ, EPI>(g, acc, ci0, cj0, wi, wj, lane);
+        // the operand loads must be CONSUMED before any DMA piece is issued (else their wait would cover the pieces): an empty asm
+        // that "modifies" the accumulators pins the adds here (LLVM otherwise sinks them below the prologue)
+#ifndef ANTMMF_EMULATE
+        if (EPI > 0) {
+#define ACC4(i) "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])
+            asm volatile("" : ACC4(0), ACC4(1), ACC4(2), ACC4(3));
+            asm volatile("" : ACC4(4), ACC4(5), ACC4(6), ACC4(7));
+#undef ACC4
+        }
+#endif
+        SCHED_FENCE();
+        gs += nk;
+        local += per_xcd;
+        const bool more = local < xcount;
+        if (more) {
+            tile_origin(local, i0, j0);
+            set_sources(i0, j0);
+#pragma unroll
+            for (int t = 0; t < STAGES - 1; ++t)
+                if (t < nk) issue(t);  // slots gs .. gs+2; the epilogue below stages through slot gs+3
+        }
+        char* stage = smem + ((gs + STAGES - 1) & (STAGES - 1)) * 32768 + wave * 4096;
+        epilogue_store_bf16_staged_raw<TI, TJ, 4>(g, acc, ci0, cj0, wi, wj, lane, stage);
+        if (!more) return;
+    }
+}
+
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
 // instruction writes whole 256-B row segments (fp32 atomics straight from the fragment layout measured ~90 G adds / s:
 // 0.37 ms for the 33 M adds of one fc1 wgrad, as long as its whole K loop).
@@ -822,18 +1045,25 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) {
         const long tiles256 = (long)((I + 255) / 256) * ((J + 255) / 256);
         static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");  // tests only: "256" / "128" / "ring"
-        const bool big = force ? (force[0] == '2' || force[0] == 'r') : tiles256 >= 512;
+        const bool big = force ? (force[0] == '2' || force[0] == 'r' || force[0] == 'p') : tiles256 >= 512;
+        static const char* persist_env = getenv("ANTMMF_GEMM_PERSIST");  // A/B knob: "0" = one workgroup per tile
+        const bool persist = force ? force[0] == 'p' : !(persist_env && persist_env[0] == '0');
+        static const char* pwgs_env = getenv("ANTMMF_GEMM_PERSIST_WGS");  // tests only: a small grid makes every workgroup walk several tiles
+        const unsigned pwgs = pwgs_env ? (unsigned)atoi(pwgs_env) : 256u;
         const int epi = (aux || gate || act != ANTMMF_ACT_NONE || alpha != 1.0f || c_dtype != ANTMMF_BF16) ? 4 : ((bias ? 1 : 0) | (residual ? 2 : 0));
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
         if (!once) {                                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
             once = true;                                                                                                          \
         }                                                                                                                         \
-        if (big && !(force && force[0] == '2')) hipLaunchKernelGGL((gemm_nt_ring_kernel<4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
+        if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0)                                     \
+            hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0)>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);  \
+        else if (big && !(force && force[0] == '2')) hipLaunchKernelGGL((gemm_nt_ring_kernel<4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \
     } while (0)

@@ -208,7 +208,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{a.workload}_b{a.batch}.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = round(json.load(fh)["traffic_bytes_per_launch"] / 1e9, 3)  # GB per launch
+                traffic = int(json.load(fh)["traffic_bytes_per_launch"])  # bytes per launch, like `achieved`
         step_tflops = pairs_per_s / world * TRAIN_GFLOP_PER_PAIR[a.workload] / 1e3
         out = {
             "metric": "image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192",
@@ -223,7 +223,7 @@ def main():
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
-                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (L2-miss bytes, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE; profiles/gemm_traffic_*.json)",
+                         "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gemm_traffic_*.json); algorithmic bytes per launch = 2(I R + J R + I J)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),
                          "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
                          "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0}},

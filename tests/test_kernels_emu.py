@@ -99,6 +99,20 @@ def test_gemm_large_tile_variants(ops, variant):
     assert "okbig" in out.stdout, out.stdout + out.stderr
 
 
+def test_gemm_persistent_ring():
+    """The persistent 256 x 256 ring kernel on a 3 x 3-tile problem with an 8-workgroup grid: one workgroup walks two tiles
+    (next-tile prologue issued before the epilogue, epilogue staged through the free ring slot)."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'p';"
+            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '8';"
+            "import kernel_cases as kc; from antmmf.hip import ops; kc.case_gemm_persistent(ops, torch.device('cpu')); print('okpersist')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert "okpersist" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV)
 

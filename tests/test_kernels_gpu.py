@@ -64,6 +64,11 @@ def test_gemm(ops):
     kc.case_gemm_multitile(ops, DEV)
 
 
+def test_gemm_persistent_ring(ops):
+    """530 tiles of 256 x 256 on 256 persistent workgroups: every workgroup walks 2-3 tiles (ragged edges, all epilogues)."""
+    kc.case_gemm_persistent(ops, DEV, I=13412, J=2560, R=256)
+
+
 def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV)
     kc.case_gemm_wgrad_ring(ops, DEV, tokens=257 * 64, n_out=1024, k_in=512)
