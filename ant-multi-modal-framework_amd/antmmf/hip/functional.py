@@ -412,19 +412,26 @@ class _TransformerLayer(torch.autograd.Function):
             do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
-        # q / k / v projection bias gradients (column sums of dqkv) come out of the attention backward kernels
+        # q / k / v projection bias gradients: the attention backward kernels emit per-batch-row column sums of dq / dk / dv
+        # ([3, B, d] fp32), one small column sum folds them into the bias gradients
         if spec.packed_qkv:
-            bsl = None
+            btargets = None
             if P["bqkv"] is not None and P["bqkv"].requires_grad:
                 bb = sink.buf(P["bqkv"]).view(-1)
-                bsl = (bb[:d], bb[d:2 * d], bb[2 * d:])
+                btargets = (bb[:d], bb[d:2 * d], bb[2 * d:])
         else:
-            bsl = tuple(sink.buf(P["b" + nm]).view(-1) if (P["b" + nm] is not None and P["b" + nm].requires_grad) else None for nm in "qkv")
-            if all(t is None for t in bsl):
-                bsl = None
-        dbq, dbk, dbv = bsl if bsl is not None else (None, None, None)
+            btargets = tuple(sink.buf(P["b" + nm]).view(-1) if (P["b" + nm] is not None and P["b" + nm].requires_grad) else None for nm in "qkv")
+            if all(t is None for t in btargets):
+                btargets = None
+        bpart = torch.empty(3, B, d, dtype=torch.float32, device=qkv.device) if btargets is not None else None
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
-                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dbq=dbq, dbk=dbk, dbv=dbv)
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:],
+                          dbq=None if bpart is None else bpart[0], dbk=None if bpart is None else bpart[1],
+                          dbv=None if bpart is None else bpart[2])
+        if btargets is not None:
+            for i, tgt in enumerate(btargets):
+                if tgt is not None:
+                    ops.colsum_(tgt, bpart[i])
         del do
         dqkv2 = dqkv.view(T, 3 * d)
         if pre_ln:

@@ -329,13 +329,14 @@ def attention_fwd(q, k, v, heads, scale, key_bias=None):
 
 
 def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dbq=None, dbk=None, dbv=None):
-    """dbq / dbk / dbv: optional fp32 [heads*64] buffers that receive += column sums of dq / dk / dv (projection bias grads)."""
+    """dbq / dbk / dbv: optional fp32 [B, heads*64] buffers that receive the per-batch-row column sums of dq / dk / dv
+    (summing them over B gives the projection bias gradients)."""
     _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv, dbq, dbk, dbv)
     for t, n in ((dbq, "dbq"), (dbk, "dbk"), (dbv, "dbv")):
         if t is not None:
             _f32(t, n); _c(t, n)
-            if t.numel() != heads * 64:
-                raise ValueError(f"attention_bwd: {n} must have heads*64 elements")
+            if tuple(t.shape) != (q.shape[0], heads * 64):
+                raise ValueError(f"attention_bwd: {n} must be [B, heads*64]")
     B, Nq, D = q.shape
     Nk = k.shape[1]
     _c(o, "o"); _c(d_o, "d_o")

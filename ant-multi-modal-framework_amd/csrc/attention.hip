@@ -53,7 +53,7 @@ struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const float* key_bias;
     bf16_t* o; float* lse;
     const bf16_t* d_o; bf16_t* dq; bf16_t* dk; bf16_t* dv;
-    float* dbq; float* dbk; float* dbv;  // optional [heads*64] fp32 accumulators: column sums of dq / dk / dv (projection bias grads)
+    float* dbq; float* dbk; float* dbv;  // optional [B][heads*64] fp32: per-batch-row column sums of dq / dk / dv (projection bias grads)
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, heads, Nq, Nk;
     float scale;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
     if (a.dbq) {  // workgroup-uniform
         bias_grad_to_lds(bq, bsum, l15, grp);
         __syncthreads();
-        if (threadIdx.x < 64) atomicAdd(&a.dbq[h * 64 + threadIdx.x], bsum[threadIdx.x]);
+        if (threadIdx.x < 64) a.dbq[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[threadIdx.x];
     }
 }
 
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
         bias_grad_to_lds(bv, bsum + 64, l15, grp);
         __syncthreads();
         if (threadIdx.x < 64) {
-            if (a.dbk) atomicAdd(&a.dbk[h * 64 + threadIdx.x], bsum[threadIdx.x]);
-            if (a.dbv) atomicAdd(&a.dbv[h * 64 + threadIdx.x], bsum[64 + threadIdx.x]);
+            if (a.dbk) a.dbk[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[threadIdx.x];
+            if (a.dbv) a.dbv[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[64 + threadIdx.x];
         }
     }
 }

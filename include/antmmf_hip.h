@@ -147,8 +147,10 @@ int antmmf_attention_fwd(const void* q, const void* k, const void* v, const floa
                          int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          float scale, antmmf_stream_t stream);
 /* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs.
- * dbq / dbk / dbv (nullable, fp32 [heads*64], accumulated): column sums of dq / dk / dv over all tokens = the bias
- * gradients of the q / k / v projections, which would otherwise be three more full reads of the gradient tensors. */
+ * dbq / dbk / dbv (nullable, fp32 [B][heads*64], overwritten): per-batch-row column sums of dq / dk / dv; their sum over B
+ * is the bias gradient of the q / k / v projections, which would otherwise be three more full reads of the gradient
+ * tensors.  (Plain stores + a tiny column sum on the host side: device-scope fp32 atomics from every workgroup onto the
+ * same 3 * heads * 64 addresses cost more than the reads they were meant to save -- measured.) */
 int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
                          const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* dbq, float* dbk,
                          float* dbv, int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
