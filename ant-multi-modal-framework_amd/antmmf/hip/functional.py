@@ -412,26 +412,8 @@ class _TransformerLayer(torch.autograd.Function):
             do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
-        # q / k / v projection bias gradients: the attention backward kernels emit per-batch-row column sums of dq / dk / dv
-        # ([3, B, d] fp32), one small column sum folds them into the bias gradients
-        if spec.packed_qkv:
-            btargets = None
-            if P["bqkv"] is not None and P["bqkv"].requires_grad:
-                bb = sink.buf(P["bqkv"]).view(-1)
-                btargets = (bb[:d], bb[d:2 * d], bb[2 * d:])
-        else:
-            btargets = tuple(sink.buf(P["b" + nm]).view(-1) if (P["b" + nm] is not None and P["b" + nm].requires_grad) else None for nm in "qkv")
-            if all(t is None for t in btargets):
-                btargets = None
-        bpart = torch.empty(3, B, d, dtype=torch.float32, device=qkv.device) if btargets is not None else None
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
-                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:],
-                          dbq=None if bpart is None else bpart[0], dbk=None if bpart is None else bpart[1],
-                          dbv=None if bpart is None else bpart[2])
-        if btargets is not None:
-            for i, tgt in enumerate(btargets):
-                if tgt is not None:
-                    ops.colsum_(tgt, bpart[i])
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
         del do
         dqkv2 = dqkv.view(T, 3 * d)
         if pre_ln:
@@ -440,10 +422,12 @@ class _TransformerLayer(torch.autograd.Function):
             h = x2
         if spec.packed_qkv:
             _wgrad(sink, P["wqkv"], dqkv2, h)
+            _bgrad(sink, P["bqkv"], dqkv2)
         else:
             for i, nm in enumerate("qkv"):
                 sl = dqkv2[:, i * d:(i + 1) * d]
                 _wgrad(sink, P["w" + nm], sl, h)
+                _bgrad(sink, P["b" + nm], sl)
         del h
         dx = None
         if ctx.needs_input_grad[0]:

@@ -328,15 +328,8 @@ def attention_fwd(q, k, v, heads, scale, key_bias=None):
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dbq=None, dbk=None, dbv=None):
-    """dbq / dbk / dbv: optional fp32 [B, heads*64] buffers that receive the per-batch-row column sums of dq / dk / dv
-    (summing them over B gives the projection bias gradients)."""
-    _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv, dbq, dbk, dbv)
-    for t, n in ((dbq, "dbq"), (dbk, "dbk"), (dbv, "dbv")):
-        if t is not None:
-            _f32(t, n); _c(t, n)
-            if tuple(t.shape) != (q.shape[0], heads * 64):
-                raise ValueError(f"attention_bwd: {n} must be [B, heads*64]")
+def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None):
+    _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
     B, Nq, D = q.shape
     Nk = k.shape[1]
     _c(o, "o"); _c(d_o, "d_o")
@@ -347,7 +340,7 @@ def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk
     if dv is None:
         dv = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
     _rc(_lib.load().antmmf_attention_bwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
-                                         _p(dbq), _p(dbk), _p(dbv), B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
+                                         B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
                                          _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), _stream()),
         "antmmf_attention_bwd")
     return dq, dk, dv

@@ -53,7 +53,6 @@ struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const float* key_bias;
     bf16_t* o; float* lse;
     const bf16_t* d_o; bf16_t* dq; bf16_t* dk; bf16_t* dv;
-    float* dbq; float* dbk; float* dbv;  // optional [B][heads*64] fp32: per-batch-row column sums of dq / dk / dv (projection bias grads)
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, heads, Nq, Nk;
     float scale;
@@ -98,19 +97,6 @@ __device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16, 64); 
 __device__ __forceinline__ void stage_key_bias(float* kb, const AttnArgs& a, int b, int n_pad) {
     for (int i = threadIdx.x; i < n_pad; i += ATTN_THREADS)
         kb[i] = i < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + i] * LOG2E : 0.f) : -INFINITY;
-}
-
-// Column sums of a gradient tile for the projection-bias gradients: acc[dt][r] holds head-dim 16 dt + 4 grp + r summed over
-// this wave's tokens of lane column l15; butterfly over the 16 token lanes, LDS atomics across waves.
-__device__ __forceinline__ void bias_grad_to_lds(float (&acc)[4][4], float* sums, int l15, int grp) {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[dt][r];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (l15 == 0) atomicAdd(&sums[16 * dt + 4 * grp + r], v);
-        }
 }
 
 // ---- forward ----------------------------------------------------------------------------------------
@@ -185,20 +171,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
     float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    __shared__ float bsum[64];
     stage_rows(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
     stage_rows(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
-    if (threadIdx.x < 64) bsum[threadIdx.x] = 0.f;
     __syncthreads();
 
     const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
-    float bq[4][4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bq[dt][r] = 0.f;
     for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
@@ -221,7 +200,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
         }
         dsum = grp_sum(dsum);
         const float lse = a.lse[((long)b * a.heads + h) * a.Nq + qrow];
-        const float lse2 = lse * LOG2E;  // -inf for a fully masked query: exp2(z - (-inf)) is guarded below
+        // fully masked query (lse = -inf): subtracting +inf makes every z = -inf and exp2(z) = 0 without per-element selects
+        const float lse2 = lse == -INFINITY ? INFINITY : lse * LOG2E;
         bf16x8_t dsf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -239,8 +219,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
                 const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = sa[r] * scale2 + bb[r] - lse2;
-                    const float p = (lse == -INFINITY || z == -INFINITY) ? 0.f : EXP2F(z);
+                    const float p = EXP2F(sa[r] * scale2 + bb[r] - lse2);  // masked key: bias = -inf -> p = 0
                     ds[hh][r] = p * (da[r] - dsum);
                 }
             }
@@ -253,18 +232,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
-            if (qi < a.Nq) {
+            if (qi < a.Nq)
                 *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * 64 + 16 * dt + 4 * grp) =
                     make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bq[dt][r] += g[r] * a.scale;
-            }
         }
-    }
-    if (a.dbq) {  // workgroup-uniform
-        bias_grad_to_lds(bq, bsum, l15, grp);
-        __syncthreads();
-        if (threadIdx.x < 64) a.dbq[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[threadIdx.x];
     }
 }
 
@@ -280,19 +251,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
     const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * 64;
     const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * 64;
     const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
-    __shared__ float bsum[128];
-    if (threadIdx.x < 128) bsum[threadIdx.x] = 0.f;
-    float bk[4][4], bv[4][4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { bk[dt][r] = 0.f; bv[dt][r] = 0.f; }
     stage_rows(Qs, qbase, a.ldq, a.Nq, NQP);
     stage_rows(Ds, dobase, a.lddo, a.Nq, NQP);
     for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {
-        float d = 0.f, l = -INFINITY;
+        float d = 0.f, l = INFINITY;  // padding queries: p = 0
         if (i < a.Nq) {
-            l = a.lse[((long)b * a.heads + h) * a.Nq + i] * LOG2E;
+            l = a.lse[((long)b * a.heads + h) * a.Nq + i];
+            l = l == -INFINITY ? INFINITY : l * LOG2E;  // fully masked query: z - inf = -inf -> p = 0
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 float x[8], y[8];
@@ -336,8 +301,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = sa[r] * scale2 + kbias - ll[r];
-                    const float pr = (ll[r] == -INFINITY || kbias == -INFINITY) ? 0.f : EXP2F(z);
+                    const float pr = EXP2F(sa[r] * scale2 + kbias - ll[r]);  // masked / padding key or query: -inf -> 0
                     p[hh][r] = pr;
                     ds[hh][r] = pr * (da[r] - dd[r]);
                 }
@@ -357,18 +321,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
                     make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
                 *reinterpret_cast<uint2*>(a.dk + ((long)b * a.Nk + ki) * a.lddk + off) =
                     make_uint2(pack_bf2(dk[dt][0] * a.scale, dk[dt][1] * a.scale), pack_bf2(dk[dt][2] * a.scale, dk[dt][3] * a.scale));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { bk[dt][r] += dk[dt][r] * a.scale; bv[dt][r] += dv[dt][r]; }
             }
-        }
-    }
-    if (a.dbk || a.dbv) {  // workgroup-uniform
-        bias_grad_to_lds(bk, bsum, l15, grp);
-        bias_grad_to_lds(bv, bsum + 64, l15, grp);
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            if (a.dbk) a.dbk[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[threadIdx.x];
-            if (a.dbv) a.dbv[((long)b * a.heads + h) * 64 + threadIdx.x] = bsum[64 + threadIdx.x];
         }
     }
 }
@@ -397,13 +350,11 @@ extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v,
 }
 
 extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
-                                    const void* d_o, void* dq, void* dk, void* dv, float* dbq, float* dbk, float* dbv, int B, int heads, int Nq,
-                                    int Nk, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale,
-                                    hipStream_t stream) {
+                                    const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq, int Nk, long ldq, long ldk,
+                                    long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, hipStream_t stream) {
     AttnArgs a{};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)const_cast<void*>(o);
     a.lse = const_cast<float*>(lse); a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-    a.dbq = dbq; a.dbk = dbk; a.dbv = dbv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !attn_args_ok(a) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))

@@ -146,15 +146,11 @@ int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tok
 int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
                          int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          float scale, antmmf_stream_t stream);
-/* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs.
- * dbq / dbk / dbv (nullable, fp32 [B][heads*64], overwritten): per-batch-row column sums of dq / dk / dv; their sum over B
- * is the bias gradient of the q / k / v projections, which would otherwise be three more full reads of the gradient
- * tensors.  (Plain stores + a tiny column sum on the host side: device-scope fp32 atomics from every workgroup onto the
- * same 3 * heads * 64 addresses cost more than the reads they were meant to save -- measured.) */
+/* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs. */
 int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
-                         const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* dbq, float* dbk,
-                         float* dbv, int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                         int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, antmmf_stream_t stream);
+                         const float* lse, const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq,
+                         int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                         int64_t lddk, int64_t lddv, float scale, antmmf_stream_t stream);
 
 /* ---- row-sharded MIL-NCE (get_mil_nce_loss, univl_video_ret.py:146-197) on fp32 similarity slabs:
  *   Rm[i][c] = <text_i, clip_c> (c over all Wr = B_g*n clips),  Cm[i][t] = <centre clip of video_i, text_t> (Wc = B_g),

@@ -326,17 +326,10 @@ def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packe
     if key_bias is not None:
         s = s + key_bias[:, None, None, :]
     check(tag + ".lse", lse, torch.logsumexp(s, -1), 1e-2, 1e-2)
-    dbq, dbk, dbv = (torch.full((B, D), 0.5, device=dev) for _ in range(3))  # overwritten with per-batch-row sums
-    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, kb, dbq=dbq, dbk=dbk, dbv=dbv)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, kb)
     check(tag + ".dq", dq, qr.grad, 3e-2, 3e-2)
     check(tag + ".dk", dk, kr.grad, 3e-2, 3e-2)
     check(tag + ".dv", dv, vr.grad, 3e-2, 3e-2)
-    # column sums: error budget = bf16-level noise of the summed elements (the k sum is analytically 0: softmax is shift invariant)
-    for nm, got_b, gr in (("dbq", dbq, qr.grad), ("dbk", dbk, kr.grad), ("dbv", dbv, vr.grad)):
-        want_b = gr.sum((0, 1))
-        budget = 2e-2 * float(gr.abs().max()) * (gr.shape[0] * gr.shape[1]) ** 0.5
-        err = float((got_b.cpu().sum(0) - want_b).abs().max())
-        assert err <= budget + 2e-2 * float(want_b.abs().max()), f"{tag}.{nm}: max abs err {err:.4g} > budget {budget:.4g}"
 
 
 # ------------------------------------------------------------------------------ losses
