@@ -244,12 +244,34 @@ SLOTS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wq", "bq", "wk", "bk", "wv", "bv", "
          "ln2_w", "ln2_b", "w1", "b1", "ffn_w", "ffn_b", "w2", "b2")
 
 
+def _cached_on(p, attr, build):
+    """Per-optimizer-step cache hung on an arena-managed parameter (same validity rule as compute_copy_t)."""
+    ver = _T_CACHE_VERSION[0]
+    c = getattr(p, attr, None)
+    if c is not None and c[0] == ver and getattr(p, "_antmmf_main_grad", None) is not None:
+        return c[1]
+    val = build()
+    try:
+        setattr(p, attr, (ver, val))
+    except AttributeError:
+        pass
+    return val
+
+
 def _packed_qkv_weight(P, spec):
     if spec.packed_qkv:
         return compute_copy(P["wqkv"]), f32(P["bqkv"])
-    w = torch.cat([compute_copy(P["wq"]), compute_copy(P["wk"]), compute_copy(P["wv"])], dim=0)
-    b = torch.cat([f32(P["bq"]), f32(P["bk"]), f32(P["bv"])], dim=0)
+    # separate q / k / v projections (BERT, torchscale): one [3d, d] GEMM operand, rebuilt once per optimizer step
+    w = _cached_on(P["wq"], "_antmmf_qkv_w", lambda: torch.cat([compute_copy(P["wq"]), compute_copy(P["wk"]), compute_copy(P["wv"])], dim=0))
+    b = _cached_on(P["wq"], "_antmmf_qkv_b", lambda: torch.cat([f32(P["bq"]), f32(P["bk"]), f32(P["bv"])], dim=0))
     return w, b
+
+
+def _packed_qkv_weight_t(P, spec):
+    if spec.packed_qkv:
+        return compute_copy_t(P["wqkv"])                                   # [d, 3d]
+    return _cached_on(P["wq"], "_antmmf_qkv_wt",
+                      lambda: torch.cat([compute_copy_t(P["wq"]), compute_copy_t(P["wk"]), compute_copy_t(P["wv"])], dim=1))
 
 
 # Activation-memory policy.  By default a layer saves 20 B per token-channel (x, qkv, o, mid, u) and recomputes every
@@ -431,10 +453,7 @@ class _TransformerLayer(torch.autograd.Function):
         del h
         dx = None
         if ctx.needs_input_grad[0]:
-            if spec.packed_qkv:
-                wqkv_t = compute_copy_t(P["wqkv"])                                   # [d, 3d]
-            else:
-                wqkv_t = torch.cat([compute_copy_t(P["wq"]), compute_copy_t(P["wk"]), compute_copy_t(P["wv"])], dim=1)
+            wqkv_t = _packed_qkv_weight_t(P, spec)
             if pre_ln:
                 dh = ops.gemm(dqkv2, wqkv_t)
                 dgw, dgb = lnw("ln1")
