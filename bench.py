@@ -187,6 +187,8 @@ def main():
         pairs_per_s = a.batch * world * a.steps / elapsed
         gemm_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
         gemm_flops = sum(t[2] for t in trace)
+        # algorithmic bytes of a launch: both operands once + the output once (bf16; fp32 for the wgrad accumulators)
+        gemm_bytes = sum(2.0 * (t[4][0] * t[4][2] + t[4][1] * t[4][2]) + (4.0 if t[4][3] == "wgrad" else 2.0) * t[4][0] * t[4][1] for t in trace)
         n = max(1, len(trace))
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         per_layout = {}
@@ -225,7 +227,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gemm_traffic_*.json); algorithmic bytes per launch = 2(I R + J R + I J)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),
-                         "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
+                         "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "avg_launch_algorithmic_bytes": int(gemm_bytes / n), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
                          "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0}},
         }
         if world == 1 and not a.no_cpu_baseline:
