@@ -46,6 +46,9 @@ _SIGNATURES = {
     "antmmf_milnce_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P],
     "antmmf_softmax_ce_fwd": [P, I, I, I, P, F, P, P, P],
     "antmmf_softmax_ce_bwd": [P, P, P, I, I, I, P, F, P, P, I, P],
+    "antmmf_moco_fwd": [P, P, I, I, I, F, P, P, P, P],
+    "antmmf_moco_bwd": [P, P, P, P, P, I, I, I, F, P, P, I, P],
+    "antmmf_ema_update": [P, P, P, L, F, P],
 }
 
 

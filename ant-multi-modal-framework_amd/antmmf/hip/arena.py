@@ -48,6 +48,7 @@ class ParamArena:
                 p.data = view
                 p._antmmf_main_grad = self.grad[off:off + n].view(p.shape)
                 p._antmmf_bf16 = self.shadow[off:off + n].view(p.shape)
+                p._antmmf_arena, p._antmmf_offset = self, off   # lets a MoCo key tower mirror this layout (one-launch EMA)
                 p.grad = p._antmmf_main_grad
                 off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.sync_shadow()

@@ -168,3 +168,38 @@ def clip_itc_sharded(img_embed, txt_embed, log_scale, group=None):
     """Symmetric InfoNCE over logits = exp(log_scale) * img @ txt^T (prj/M2_Encoder/m2_encoder.py:92-95;
     antmmf/modules/vision/backbone/clip/model.py:442-444), rows sharded over ranks."""
     return _ClipItcSharded.apply(img_embed, txt_embed, log_scale, group)
+
+
+# ------------------------------------------------------------------------------ MoCo (queue negatives)
+class _MocoLoss(torch.autograd.Function):
+    """mean_i [ LSE({<q_i, kpos_i,c>}_c U {<q_i, queue_:,k>}_k) / T - LSE({<q_i, kpos_i,c>}_c / T) ]
+    (MocoUtils.moco_loss + the einsums around it, prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:288-311,
+    moco_utils.py:71-81).  q [R, D] carries the gradient; kpos [R, Np, D] and queue [D, K] are keys (no gradient).
+    The [R, K] negatives come from the fp32-accurate split GEMM and are consumed by one fused row kernel."""
+
+    @staticmethod
+    def forward(ctx, q, kpos, queue, temperature):
+        qf = q.float().contiguous()
+        pos = (qf.unsqueeze(1) * kpos.float()).sum(-1).contiguous()       # [R, Np]  (R * Np * D multiply-adds: tiny)
+        neg = matmul_f32(qf, queue, b_rmajor=True)                         # [R, K]
+        loss_rows, lse_all, lse_pos = ops.moco_fwd(pos, neg, temperature)
+        # the queue is overwritten in place by dequeue_and_enqueue before backward runs: keep the bf16 operand the dq GEMM needs
+        qb = _pad2(queue.to(BF), 8, 8)                                     # [D, K]: r-contiguous Q operand (j = D, r = K)
+        ctx.save_for_backward(pos, neg, lse_all, lse_pos, kpos, qb)
+        ctx.temperature, ctx.q_dtype, ctx.dim = float(temperature), q.dtype, queue.shape[0]
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, neg, lse_all, lse_pos, kpos, qb = ctx.saved_tensors
+        R = pos.shape[0]
+        coef = (g.float() / R).expand(R).contiguous()
+        dpos, dneg = ops.moco_bwd(pos, neg, lse_all, lse_pos, coef, ctx.temperature, out_dtype=BF)
+        dq = ops.gemm(_pad2(dneg, 8, 8), qb, out_dtype=torch.float32)[:R, :ctx.dim]
+        dq = dq + (dpos.unsqueeze(-1) * kpos.float()).sum(1)
+        return dq.to(ctx.q_dtype), None, None, None
+
+
+def moco_loss(q, kpos, queue, temperature):
+    """q [R, D] (grad), kpos [R, Np, D] positive keys per row, queue [D, K] negative keys."""
+    return _MocoLoss.apply(q, kpos.detach(), queue.detach(), temperature)

@@ -382,3 +382,34 @@ def softmax_ce_bwd(x, lse, coef, row_offset, log_scale=None, scale_mul=1.0, dsca
     _rc(_lib.load().antmmf_softmax_ce_bwd(_p(x), _p(lse), _p(coef), x.shape[0], x.shape[1], row_offset, _p(log_scale),
                                           float(scale_mul), _p(dx), _p(dscale), _dt(dx), _stream()), "antmmf_softmax_ce_bwd")
     return dx
+
+
+def moco_fwd(pos, neg, temperature):
+    """Rows of MocoUtils.moco_loss: LSE([pos, neg] / T) - LSE(pos / T); pos [R, Np], neg [R, K] fp32."""
+    _dev_ok(pos, neg); _c(pos, "pos"); _c(neg, "neg"); _f32(pos, "pos"); _f32(neg, "neg")
+    R = pos.shape[0]
+    loss_rows = torch.empty(R, dtype=torch.float32, device=pos.device)
+    lse_all, lse_pos = torch.empty_like(loss_rows), torch.empty_like(loss_rows)
+    _rc(_lib.load().antmmf_moco_fwd(_p(pos), _p(neg), R, pos.shape[1], neg.shape[1], 1.0 / float(temperature), _p(loss_rows), _p(lse_all),
+                                    _p(lse_pos), _stream()), "antmmf_moco_fwd")
+    return loss_rows, lse_all, lse_pos
+
+
+def moco_bwd(pos, neg, lse_all, lse_pos, coef, temperature, out_dtype=torch.bfloat16):
+    _dev_ok(pos, neg, lse_all, lse_pos, coef); _f32(coef, "coef"); _c(coef, "coef")
+    dpos = torch.empty_like(pos)
+    dneg = torch.empty(neg.shape, dtype=out_dtype, device=neg.device)
+    _rc(_lib.load().antmmf_moco_bwd(_p(pos), _p(neg), _p(lse_all), _p(lse_pos), _p(coef), pos.shape[0], pos.shape[1], neg.shape[1],
+                                    1.0 / float(temperature), _p(dpos), _p(dneg), _dt(dneg), _stream()), "antmmf_moco_bwd")
+    return dpos, dneg
+
+
+def ema_update_(k, q, m, k_shadow=None):
+    """k = m k + (1 - m) q in place over flat fp32 ranges (same numel); k_shadow (bf16, optional) is rewritten with bf16(k)."""
+    _dev_ok(k, q, k_shadow); _f32(k, "k"); _f32(q, "q"); _c(k, "k"); _c(q, "q")
+    if k.numel() != q.numel():
+        raise ValueError("ema_update_: size mismatch")
+    if k_shadow is not None and (k_shadow.dtype != torch.bfloat16 or k_shadow.numel() != k.numel() or not k_shadow.is_contiguous()):
+        raise ValueError("ema_update_: k_shadow must be a contiguous bf16 tensor of the same size")
+    _rc(_lib.load().antmmf_ema_update(_p(k), _p(q), _p(k_shadow), k.numel(), float(m), _stream()), "antmmf_ema_update")
+    return k

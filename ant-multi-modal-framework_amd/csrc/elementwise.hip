@@ -361,3 +361,29 @@ extern "C" int antmmf_sumsq(const float* x, float* out, long n, hipStream_t s) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, out, n);
     return antmmf_check_launch();
 }
+
+// ---- momentum (EMA) update of a key encoder: k = m k + (1 - m) q over a flat fp32 range, refreshing the bf16 compute shadow in
+// the same pass.  Replaces the per-parameter Python loop of MocoUtils.momentum_update_key_encoder (moco_utils.py:55-69): with the
+// key tower laid out at the query tower's arena offsets it is ONE launch over ~190 M parameters.  HBM-bound, 14 B / parameter.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const float* __restrict__ q, bf16_t* __restrict__ shadow, long n, float m) {
+    const long nvec = n >> 2;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(k)[v], b = reinterpret_cast<const float4*>(q)[v];
+        float4 r;
+        r.x = a.x * m + b.x * (1.0f - m); r.y = a.y * m + b.y * (1.0f - m); r.z = a.z * m + b.z * (1.0f - m); r.w = a.w * m + b.w * (1.0f - m);
+        reinterpret_cast<float4*>(k)[v] = r;
+        if (shadow) reinterpret_cast<uint2*>(shadow)[v] = make_uint2(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (nvec << 2) + threadIdx.x;
+        const float r = k[i] * m + q[i] * (1.0f - m);
+        k[i] = r;
+        if (shadow) shadow[i] = f2bf(r);
+    }
+}
+extern "C" int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, long n, float m, hipStream_t s) {
+    if (!k || !q || n < 0 || ((uintptr_t)k & 15) || ((uintptr_t)q & 15) || (k_shadow_bf16 && ((uintptr_t)k_shadow_bf16 & 7))) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    hipLaunchKernelGGL(ema_kernel, dim3(ew_grid((n >> 2) + 1)), dim3(256), 0, s, k, q, (bf16_t*)k_shadow_bf16, n, m);
+    return antmmf_check_launch();
+}

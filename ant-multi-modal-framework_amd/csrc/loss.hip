@@ -109,6 +109,55 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
     }
 }
 
+// MoCo loss rows (reference: MocoUtils.moco_loss, prj/base_vtp/roi_univl/univl/model/moco_utils.py:71-81):
+//     l_i = LSE( {pos[i][:]} U {neg[i][:]} ) / T  -  LSE( pos[i][:] / T )         pos [R, Np] (Np = 1 or n clips), neg [R, K] (queue)
+__global__ __launch_bounds__(256) void moco_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int Np, int K, float inv_t,
+                                                       float* __restrict__ loss_rows, float* __restrict__ lse_all, float* __restrict__ lse_pos) {
+    __shared__ MS sh[4];
+    const int i = blockIdx.x;
+    MS ap; ap.m = -INFINITY; ap.s = 0.f;
+    for (int c = threadIdx.x; c < Np; c += 256) ms_add(ap, pos[(long)i * Np + c] * inv_t);
+    const MS tp = block_ms(ap, sh);
+    MS an; an.m = -INFINITY; an.s = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) ms_add(an, neg[(long)i * K + c] * inv_t);
+    const MS tn = block_ms(an, sh);
+    if (threadIdx.x == 0) {
+        const MS ta = ms_merge(tp, tn);
+        const float lp = tp.m + __logf(tp.s), la = ta.m + __logf(ta.s);
+        lse_pos[i] = lp; lse_all[i] = la; loss_rows[i] = la - lp;
+    }
+}
+// dpos = coef/T (softmax_all - softmax_pos) (fp32);  dneg = coef/T softmax_all (out dtype)
+template <typename TO>
+__global__ __launch_bounds__(256) void moco_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ neg, const float* __restrict__ lse_all,
+                                                       const float* __restrict__ lse_pos, const float* __restrict__ coef, int Np, int K, float inv_t,
+                                                       float* __restrict__ dpos, TO* __restrict__ dneg) {
+    const int i = blockIdx.x;
+    const float la = lse_all[i], lp = lse_pos[i], k = coef[i] * inv_t;
+    for (int c = threadIdx.x; c < Np; c += 256) {
+        const float z = pos[(long)i * Np + c] * inv_t;
+        dpos[(long)i * Np + c] = k * (__expf(z - la) - __expf(z - lp));
+    }
+    for (int c = threadIdx.x; c < K; c += 256) st1<TO>(dneg + (long)i * K + c, k * __expf(neg[(long)i * K + c] * inv_t - la));
+}
+
+extern "C" int antmmf_moco_fwd(const float* pos, const float* neg, int R, int Np, int K, float inv_t, float* loss_rows, float* lse_all,
+                               float* lse_pos, hipStream_t s) {
+    if (!pos || !neg || !loss_rows || !lse_all || !lse_pos || R < 0 || Np <= 0 || K <= 0 || !(inv_t > 0.f)) return ANTMMF_EINVAL;
+    if (!R) return ANTMMF_OK;
+    hipLaunchKernelGGL(moco_fwd_kernel, dim3(R), dim3(256), 0, s, pos, neg, Np, K, inv_t, loss_rows, lse_all, lse_pos);
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_moco_bwd(const float* pos, const float* neg, const float* lse_all, const float* lse_pos, const float* coef, int R, int Np,
+                               int K, float inv_t, float* dpos, void* dneg, int out_dtype, hipStream_t s) {
+    if (!pos || !neg || !lse_all || !lse_pos || !coef || !dpos || !dneg || R < 0 || Np <= 0 || K <= 0) return ANTMMF_EINVAL;
+    if (!R) return ANTMMF_OK;
+    if (out_dtype == ANTMMF_BF16) hipLaunchKernelGGL(moco_bwd_kernel<bf16_t>, dim3(R), dim3(256), 0, s, pos, neg, lse_all, lse_pos, coef, Np, K, inv_t, dpos, (bf16_t*)dneg);
+    else if (out_dtype == ANTMMF_F32) hipLaunchKernelGGL(moco_bwd_kernel<float>, dim3(R), dim3(256), 0, s, pos, neg, lse_all, lse_pos, coef, Np, K, inv_t, dpos, (float*)dneg);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
 extern "C" int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
                                  float* loss_rows, float* denom, hipStream_t s) {
     if (!Rm || !Cm || !loss_rows || !denom || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1 || row_offset < 0 || row_offset + B > Wc) return ANTMMF_EINVAL;

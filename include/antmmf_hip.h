@@ -170,6 +170,17 @@ int antmmf_softmax_ce_bwd(const float* x, const float* lse, const float* coef, i
                           const float* log_scale, float scale_mul, void* dx, float* dscale, int out_dtype,
                           antmmf_stream_t stream);
 
+/* ---- MoCo loss rows (MocoUtils.moco_loss, prj/base_vtp/roi_univl/univl/model/moco_utils.py:71-81):
+ *   loss_rows[i] = LSE({pos[i][:]} U {neg[i][:]}) / T - LSE(pos[i][:] / T);  pos [R, Np] fp32, neg [R, K] fp32 (q . queue), inv_t = 1/T. */
+int antmmf_moco_fwd(const float* pos, const float* neg, int R, int Np, int K, float inv_t, float* loss_rows, float* lse_all,
+                    float* lse_pos, antmmf_stream_t stream);
+/* dpos (fp32) and dneg (out_dtype) for upstream per-row coefficients coef[i]. */
+int antmmf_moco_bwd(const float* pos, const float* neg, const float* lse_all, const float* lse_pos, const float* coef, int R,
+                    int Np, int K, float inv_t, float* dpos, void* dneg, int out_dtype, antmmf_stream_t stream);
+/* ---- momentum update of a MoCo key tower laid out flat: k = m k + (1 - m) q, k_shadow_bf16 (nullable) = bf16(k).
+ * Replaces momentum_update_key_encoder's per-parameter loop (moco_utils.py:55-69). */
+int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, float m, antmmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

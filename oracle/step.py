@@ -37,6 +37,31 @@ def univl_stage1(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch
     return out
 
 
+def univl_stage1_moco(P, Pk, queues, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads,
+                      momentum=0.9999, temperature=0.05):
+    """One training step of the level-1 loss with MoCo (univl_video_ret.py:262-312; moco_utils.py:55-107), single process.
+    P: query parameters (autograd leaves), Pk: key-tower parameters (same names; updated IN PLACE by the momentum rule),
+    queues: dict(txt=[D, K_t], img=[D, K_i], txt_ptr=int, img_ptr=int), updated in place by dequeue_and_enqueue.
+    Order as in the reference: momentum update -> key features (no grad) -> both losses -> enqueue."""
+    with torch.no_grad():
+        for k in Pk:
+            Pk[k] = Pk[k] * momentum + P[k].detach() * (1.0 - momentum)
+    q = univl_stage1(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads, training=False)
+    with torch.no_grad():
+        kk = univl_stage1(Pk, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads, training=False)
+    q_v, q_t, key_v, key_t = q["video_embed"], q["text_embed"], kk["video_embed"], kk["text_embed"]
+    pos = (q_v * key_t.repeat_interleave(n_clips, 0)).sum(-1, keepdim=True)          # [B*n, 1]
+    loss_v = losses.moco(pos, q_v @ queues["txt"].clone(), temperature)
+    pos = (q_t.repeat_interleave(n_clips, 0) * key_v).sum(-1).view(-1, n_clips)      # [B, n]
+    loss_t = losses.moco(pos, q_t @ queues["img"].clone(), temperature)
+    for keys, nm in ((key_v, "img"), (key_t, "txt")):
+        K, ptr, n = queues[nm].shape[1], queues[nm + "_ptr"], keys.shape[0]
+        end = min(ptr + n, K)
+        queues[nm][:, end - n:end] = keys.t()
+        queues[nm + "_ptr"] = end % K
+    return dict(loss=(loss_t + loss_v) / 2.0, l1_simi=q["l1_simi"], text_embed=q_t, video_embed=q_v)
+
+
 def m2_itc(P, image, text_ids, text_masks, heads, patch, gather=None):
     """M2 two-level ITC step: towers pinned by VLMo.infer_image/infer_text, logits formula from
     prj/M2_Encoder/m2_encoder.py:92-95, symmetric CE on both the cls and the cls_vlffn pairs

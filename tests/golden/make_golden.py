@@ -14,6 +14,7 @@ Fixtures and the reference symbols that produced them:
   loss_mil_nce.pt      get_mil_nce_loss                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
+  e2e_clip_moco.pt     same model, with_moco: true (K=64, M=0.5): 2 steps   univl_video_ret.py:262-312, moco_utils.py:13-107
   e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
   gather_w2.pt         gather_tensor(back_gradient=True)  antmmf/utils/distributed_utils.py:92-189 (2-proc gloo)
 """
@@ -202,6 +203,52 @@ def gen_e2e_clip():
     save("e2e_clip_arch.pt", d)
 
 
+def moco_queue(name, dim, K):
+    return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
+
+
+def perturb_towers_(module, scale=1.05):
+    """Stands in for an optimizer step between the two MoCo steps (so that the momentum update has something to average)."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.mul_(scale)
+
+
+def gen_e2e_clip_moco():
+    vtp = L.load_vtp("base_vtp")
+    cfg = dict(TINY_CLIP_CFG, with_moco=True, K=64, M=0.5)
+    d = {}
+    bsz, n_clips, tag = 4, 2, "moco"
+    model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
+    W.fill_module_(model)
+    model.train()
+    mu = vtp["moco"].MocoUtils(L.AttrDict(cfg), img_encoder=model.module.img_encoder, txt_encoder=model.module.text_encoder)
+    mu.txt_queue.copy_(moco_queue("moco.txt_queue", 128, 64))
+    mu.img_queue.copy_(moco_queue("moco.img_queue", 128, 16384))
+    model.moco_utils = mu
+    batch = tiny_clip_batch(bsz, n_clips, tag=tag)
+    d.update({f"{tag}.image_data": batch["image"]["image_data"], f"{tag}.input_ids": batch["caption"]["caption_input_ids"],
+              f"{tag}.input_mask": batch["caption"]["caption_input_mask"]})
+    for step in (1, 2):
+        model.zero_grad(set_to_none=True)
+        out = model(batch["image"], batch["caption"])
+        loss = out["losses"]["level1_similarity_loss"]
+        loss.backward()
+        d[f"{tag}.loss{step}"] = loss
+        d[f"{tag}.l1_simi{step}"] = out["l1_simi"]
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                d[f"{tag}.gnorm{step}.{n}"] = p.grad.norm()
+        d[f"{tag}.txt_queue_head{step}"] = mu.txt_queue[:, :12].clone()
+        d[f"{tag}.img_queue_head{step}"] = mu.img_queue[:, :20].clone()
+        d[f"{tag}.txt_ptr{step}"] = mu.txt_queue_ptr.clone()
+        d[f"{tag}.img_ptr{step}"] = mu.img_queue_ptr.clone()
+        if step == 1:
+            perturb_towers_(model.module)
+    d[f"{tag}.key_probe"] = dict(mu.txt_encoder_k.named_parameters())["encoder.layer.0.attention.self.query.weight"][:4, :8].clone()
+    save("e2e_clip_moco.pt", d)
+
+
 TINY_M2 = dict(beit_version="base", encoder_embed_dim=128, out_embed_dim=64, encoder_layers=2, beit3_vl_layers=1,
                image_size=32, patch_size=8, vocab_size=300, max_text_len=12, encoder_attention_heads=2)
 
@@ -293,8 +340,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "losses", "e2e_clip", "e2e_m2", "gather"]
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "losses", "e2e_clip", "e2e_clip_moco", "e2e_m2", "gather"]
     fns = dict(clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
-               e2e_clip=gen_e2e_clip, e2e_m2=gen_e2e_m2, gather=gen_gather)
+               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

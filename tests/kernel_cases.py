@@ -400,3 +400,25 @@ def case_softmax_ce(ops, dev, Bg=8, world=2):
     assert abs(float(lr.mean()) - float(refc)) < 1e-5 * max(1.0, abs(float(refc)))
     dx = ops.softmax_ce_bwd(s.detach().to(dev), lse, torch.full((7,), 1 / 7.).to(dev), 0, None, 100.0, out_dtype=torch.float32)
     check("crossen.dx", dx, s.grad, 1e-4, 1e-5)
+
+
+def case_moco(ops, dev, R=7, Np=2, K=300):
+    """Fused MoCo loss rows + gradients vs the oracle (MocoUtils.moco_loss), and the momentum-update kernel."""
+    pos = rnd((R, Np), 301, 0.3).requires_grad_(True)
+    neg = rnd((R, K), 302, 0.3).requires_grad_(True)
+    ref = olosses.moco(pos, neg, 0.05)
+    ref.backward()
+    rows, la, lp = ops.moco_fwd(pos.detach().to(dev), neg.detach().to(dev), 0.05)
+    check("moco.loss", rows.mean(), ref.detach(), 1e-5, 1e-6)
+    coef = torch.full((R,), 1.0 / R, device=dev)
+    dpos, dneg = ops.moco_bwd(pos.detach().to(dev), neg.detach().to(dev), la, lp, coef, 0.05, out_dtype=torch.float32)
+    check("moco.dpos", dpos, pos.grad, 1e-4, 1e-5)
+    check("moco.dneg", dneg, neg.grad, 1e-4, 1e-5)
+    n = 1000 + 3
+    k, qv = rnd((n,), 303), rnd((n,), 304)
+    want = k * 0.9 + qv * 0.1
+    kd = k.clone().to(dev)
+    sh = torch.zeros(n, dtype=BF, device=dev)
+    ops.ema_update_(kd, qv.to(dev), 0.9, sh)
+    check("ema.k", kd, want, 1e-6, 1e-6)
+    check("ema.shadow", sh, want, 1e-2, 1e-2)

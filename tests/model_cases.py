@@ -86,6 +86,81 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
 
 
+def moco_queue(name, dim, K):
+    return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
+
+
+def case_univl_moco(dev, golden, with_optimizer=False):
+    """Product UnivlForVideoTextRetrieval with MoCo (momentum key towers, queues, fused MoCo loss) over the two steps the
+    reference was run for (tests/golden/make_golden.py gen_e2e_clip_moco; K=64, M=0.5; weights x1.05 between the steps).
+    with_optimizer=True puts the parameters into the flat HipAdamW arena first, so the key towers mirror the arena and the
+    momentum update is the single fused launch."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from roi_univl.univl.model.moco_utils import MocoUtils
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    g = golden("e2e_clip_moco.pt")
+    tag, n_clips = "moco", 2
+    cfg = Configuration(dict(TINY_CLIP_CFG, with_moco=True, K=64, M=0.5))
+    model = UnivlForVideoTextRetrieval(cfg)
+    W.fill_module_(model)
+    model = model.to(dev).train()
+    opt = None
+    if with_optimizer:
+        from antmmf.hip.arena import HipAdamW
+
+        opt = HipAdamW([{"params": [p for p in model.parameters() if p.requires_grad]}], lr=0.0)
+    mu = MocoUtils(cfg, img_encoder=model.module.img_encoder, txt_encoder=model.module.text_encoder).to(dev)
+    mu.txt_queue.copy_(moco_queue("moco.txt_queue", 128, 64))
+    mu.img_queue.copy_(moco_queue("moco.img_queue", 128, 16384))
+    model.moco_utils = mu
+    img = g[f"{tag}.image_data"].to(dev)
+    ids, mask = g[f"{tag}.input_ids"].to(dev), g[f"{tag}.input_mask"].to(dev)
+    bsz = img.shape[0]
+    img_input = dict(image_data=img, image_pad_mask=torch.zeros(bsz, img.shape[1], 32, 32, dtype=torch.bool, device=dev),
+                     image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz)
+    cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
+    res = {}
+    for stp in (1, 2):
+        if opt is not None:
+            opt.zero_grad()
+        else:
+            model.zero_grad(set_to_none=True)
+        out = model(img_input, cap_input)
+        loss = out["losses"]["level1_similarity_loss"]
+        ref_loss = float(g[f"{tag}.loss{stp}"])
+        # temperature 0.05 multiplies the bf16 towers' similarity error by 20: 5e-3 relative on a loss of ~9.8
+        assert abs(float(loss) - ref_loss) <= 5e-3 * abs(ref_loss), (stp, float(loss), ref_loss)
+        loss.backward()
+        worst = []
+        for n, p in model.named_parameters():
+            key = f"{tag}.gnorm{stp}.{n}"
+            if key not in g or p.grad is None:
+                continue
+            worst.append((abs(float(p.grad.float().norm()) - float(g[key])), float(g[key]), n))
+        top = max(w[1] for w in worst)
+        rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-4 * top), reverse=True)
+        assert len(rel) > 40 and rel[0][0] < 0.2, rel[:5]
+        check(f"{tag}.txt_queue{stp}", mu.txt_queue[:, :12], g[f"{tag}.txt_queue_head{stp}"], 5e-2, 3e-2)
+        check(f"{tag}.img_queue{stp}", mu.img_queue[:, :20], g[f"{tag}.img_queue_head{stp}"], 5e-2, 3e-2)
+        assert int(mu.txt_queue_ptr) == int(g[f"{tag}.txt_ptr{stp}"]) and int(mu.img_queue_ptr) == int(g[f"{tag}.img_ptr{stp}"])
+        res[f"loss{stp}"] = (float(loss), ref_loss)
+        if stp == 1:
+            with torch.no_grad():
+                if opt is not None:
+                    opt.arena.master.mul_(1.05)
+                    opt.arena.sync_shadow()
+                else:
+                    for p in model.module.parameters():
+                        p.mul_(1.05)
+    kq = dict(mu.txt_encoder_k.named_parameters())["encoder.layer.0.attention.self.query.weight"]
+    check(f"{tag}.key_probe", kq[:4, :8], g[f"{tag}.key_probe"], 1e-4, 1e-5)
+    if opt is not None:
+        assert mu._flat is not None, "key towers should mirror the optimizer arena"
+    return res
+
+
 # ------------------------------------------------------------------------------ M2
 M2_PRJ = os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder")
 if M2_PRJ not in sys.path:

@@ -130,6 +130,11 @@ def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 
 
+def test_moco_and_ema(ops):
+    kc.case_moco(ops, DEV)
+    kc.case_moco(ops, DEV, R=5, Np=1, K=64)
+
+
 def test_milnce(ops):
     kc.case_milnce(ops, DEV, Bg=6, n=2, world=2)
     kc.case_milnce(ops, DEV, Bg=4, n=1, world=1)

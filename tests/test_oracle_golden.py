@@ -121,6 +121,46 @@ def test_e2e_clip_arch(golden):
         assert checked > 50
 
 
+def moco_queue(name, dim, K):
+    import weightgen as W
+
+    return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
+
+
+def test_e2e_clip_moco(golden):
+    """Two MoCo training steps (momentum key towers, queues, two-direction MoCo loss, enqueue) against the reference run
+    (make_golden.py gen_e2e_clip_moco: K=64, M=0.5, an x1.05 weight perturbation standing in for the optimizer step)."""
+    import tiny_models
+
+    g = golden("e2e_clip_moco.pt")
+    tag, n_clips = "moco", 2
+    P = tiny_models.clip_arch_params(requires_grad=True)
+    Pk = {k: v.detach().clone() for k, v in P.items()}
+    queues = dict(txt=moco_queue("moco.txt_queue", 128, 64), img=moco_queue("moco.img_queue", 128, 16384), txt_ptr=0, img_ptr=0)
+    for stp in (1, 2):
+        for p in P.values():
+            p.grad = None
+        out = step.univl_stage1_moco(P, Pk, queues, g[f"{tag}.image_data"], g[f"{tag}.input_ids"], g[f"{tag}.input_mask"], n_clips,
+                                     vit_heads=2, patch=8, bert_heads=2, momentum=0.5, temperature=0.05)
+        close(out["loss"], g[f"{tag}.loss{stp}"], 1e-5, 1e-6)
+        close(out["l1_simi"], g[f"{tag}.l1_simi{stp}"], 1e-4, 1e-6)
+        out["loss"].backward()
+        checked = 0
+        for n, p in P.items():
+            if f"{tag}.gnorm{stp}.{n}" in g:
+                close(p.grad.norm(), g[f"{tag}.gnorm{stp}.{n}"], 2e-3, 1e-7)
+                checked += 1
+        assert checked > 50
+        close(queues["txt"][:, :12], g[f"{tag}.txt_queue_head{stp}"], 1e-4, 1e-6)
+        close(queues["img"][:, :20], g[f"{tag}.img_queue_head{stp}"], 1e-4, 1e-6)
+        assert queues["txt_ptr"] == int(g[f"{tag}.txt_ptr{stp}"]) and queues["img_ptr"] == int(g[f"{tag}.img_ptr{stp}"])
+        if stp == 1:
+            with torch.no_grad():
+                for p in P.values():
+                    p.mul_(1.05)
+    close(Pk["module.text_encoder.encoder.layer.0.attention.self.query.weight"][:4, :8], g[f"{tag}.key_probe"], 1e-5, 1e-7)
+
+
 def test_e2e_m2(golden):
     import tiny_models
 
