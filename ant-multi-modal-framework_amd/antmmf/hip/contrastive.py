@@ -203,3 +203,56 @@ class _MocoLoss(torch.autograd.Function):
 def moco_loss(q, kpos, queue, temperature):
     """q [R, D] (grad), kpos [R, Np, D] positive keys per row, queue [D, K] negative keys."""
     return _MocoLoss.apply(q, kpos.detach(), queue.detach(), temperature)
+
+
+# ------------------------------------------------------------------------------ DMAE losses on a square similarity matrix
+class _NegNCE(torch.autograd.Function):
+    """NegNCE (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:539-563): c_pos * mean_i(-log p_ii) + c_neg * mean over the
+    margin-violating negatives of -log(1 - p_ij), p = clamp(softmax(scale * S)).  Fused row kernels; the count of selected
+    negatives stays on the device (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, S, scale, c_pos, c_neg, margin):
+        Sf = S.float().contiguous()
+        diag = torch.diagonal(Sf).contiguous()
+        pos, nsum, ncnt, lse = ops.negnce_fwd(Sf, diag, 0, scale, margin)
+        cnt = ncnt.sum()
+        loss = c_pos * pos.mean() + torch.where(cnt > 0, c_neg * nsum.sum() / cnt.clamp_min(1.0), torch.zeros_like(cnt))
+        ctx.save_for_backward(Sf, diag, lse, cnt)
+        ctx.cfg = (float(scale), float(c_pos), float(c_neg), float(margin), S.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        Sf, diag, lse, cnt = ctx.saved_tensors
+        scale, c_pos, c_neg, margin, dt = ctx.cfg
+        coef = torch.stack([g.float() * c_pos / Sf.shape[0], torch.where(cnt > 0, g.float() * c_neg / cnt.clamp_min(1.0), torch.zeros_like(cnt))]).contiguous()
+        dS = ops.negnce_bwd(Sf, diag, lse, coef, 0, scale, margin, out_dtype=torch.float32)
+        return dS.to(dt), None, None, None, None
+
+
+def neg_nce(sim_matrix, logit_scale=100.0, c_pos_w=1.0, c_neg_w=0.5, margin=0.0):
+    return _NegNCE.apply(sim_matrix, logit_scale, c_pos_w, c_neg_w, margin)
+
+
+class _CrossEn(torch.autograd.Function):
+    """CrossEn (dmae_utils.py:528-537): -mean_i log_softmax(scale * S)_ii, on the fused softmax-CE row kernels."""
+
+    @staticmethod
+    def forward(ctx, S, scale):
+        Sf = S.float().contiguous()
+        rows, lse = ops.softmax_ce_fwd(Sf, 0, None, scale)
+        ctx.save_for_backward(Sf, lse)
+        ctx.cfg = (float(scale), S.dtype)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        Sf, lse = ctx.saved_tensors
+        scale, dt = ctx.cfg
+        coef = (g.float() / Sf.shape[0]).expand(Sf.shape[0]).contiguous()
+        return ops.softmax_ce_bwd(Sf, lse, coef, 0, None, scale, None, out_dtype=torch.float32).to(dt), None
+
+
+def cross_en(sim_matrix, logit_scale=100.0):
+    return _CrossEn.apply(sim_matrix, logit_scale)

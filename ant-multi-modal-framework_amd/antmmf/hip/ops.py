@@ -413,3 +413,22 @@ def ema_update_(k, q, m, k_shadow=None):
         raise ValueError("ema_update_: k_shadow must be a contiguous bf16 tensor of the same size")
     _rc(_lib.load().antmmf_ema_update(_p(k), _p(q), _p(k_shadow), k.numel(), float(m), _stream()), "antmmf_ema_update")
     return k
+
+
+def negnce_fwd(S, diag, row_offset=0, scale=100.0, margin=0.0):
+    """Per-row NegNCE pieces on a row slab S [B, W]: (-log p_ii, sum of -log(1 - p_ij) over violating negatives, their count, LSE)."""
+    _dev_ok(S, diag); _c(S, "S"); _c(diag, "diag"); _f32(S, "S"); _f32(diag, "diag")
+    B, W = S.shape
+    outs = [torch.empty(B, dtype=torch.float32, device=S.device) for _ in range(4)]
+    _rc(_lib.load().antmmf_negnce_fwd(_p(S), _p(diag), B, W, row_offset, float(scale), float(margin), *[_p(o) for o in outs], _stream()),
+        "antmmf_negnce_fwd")
+    return tuple(outs)
+
+
+def negnce_bwd(S, diag, lse, coef, row_offset=0, scale=100.0, margin=0.0, out_dtype=torch.float32):
+    """coef: 2-float device tensor (weight of every positive row term, weight of every selected negative term)."""
+    _dev_ok(S, diag, lse, coef); _f32(coef, "coef"); _c(coef, "coef")
+    dS = torch.empty(S.shape, dtype=out_dtype, device=S.device)
+    _rc(_lib.load().antmmf_negnce_bwd(_p(S), _p(diag), _p(lse), _p(coef), S.shape[0], S.shape[1], row_offset, float(scale), float(margin),
+                                      _p(dS), _dt(dS), _stream()), "antmmf_negnce_bwd")
+    return dS

@@ -158,6 +158,84 @@ extern "C" int antmmf_moco_bwd(const float* pos, const float* neg, const float* 
     return antmmf_check_launch();
 }
 
+// NegNCE (reference: prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:539-563) on a row slab S [B, W] of the similarity matrix
+// (row i is global row gi = row_offset + i; diag[j] = S_jj for every column j):
+//   p = clamp(softmax(scale * S_i,:), 1e-6, 1 - 1e-6);  positives -log p_i,gi;  negatives -log(1 - p_ij) over the off-diagonal
+//   (i, j) that violate the margin against either diagonal: relu(m + S_ij - S_ii) + relu(m + S_ij - S_jj) > 0.
+// Forward emits per-row  -log p_ii,  sum and count of the selected negatives, and the row LSE; the caller forms
+//   c_pos * mean(pos) + c_neg * sum(neg) / count   (global count: one all-reduce in the multi-GPU case).
+__global__ __launch_bounds__(256) void negnce_fwd_kernel(const float* __restrict__ S, const float* __restrict__ diag, int W, int row_offset, float scale,
+                                                         float margin, float* __restrict__ pos_rows, float* __restrict__ neg_sum, float* __restrict__ neg_cnt,
+                                                         float* __restrict__ lse) {
+    __shared__ MS sh[4];
+    __shared__ float shf[4];
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float* r = S + (long)i * W;
+    MS acc; acc.m = -INFINITY; acc.s = 0.f;
+    for (int c = threadIdx.x; c < W; c += 256) ms_add(acc, scale * r[c]);
+    const MS tot = block_ms(acc, sh);
+    const float l = tot.m + __logf(tot.s), dii = r[gi];
+    float ns = 0.f, nc = 0.f;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        if (c == gi) continue;
+        const float x = r[c];
+        const float mm = fmaxf(margin + x - dii, 0.f) + fmaxf(margin + x - diag[c], 0.f);
+        if (mm > 0.f) {
+            const float p = fminf(fmaxf(__expf(scale * x - l), 1e-6f), 1.0f - 1e-6f);
+            ns += -__logf(1.0f - p); nc += 1.0f;
+        }
+    }
+    ns = block_sum(ns, shf);
+    nc = block_sum(nc, shf);
+    if (threadIdx.x == 0) {
+        const float p = fminf(fmaxf(__expf(scale * dii - l), 1e-6f), 1.0f - 1e-6f);
+        pos_rows[i] = -__logf(p); neg_sum[i] = ns; neg_cnt[i] = nc; lse[i] = l;
+    }
+}
+// dS for loss = coef[0] * sum_i pos_i + coef[1] * sum_(i,j) neg_ij  (coef on the device: c_pos / B and c_neg / count, times upstream)
+template <typename TO>
+__global__ __launch_bounds__(256) void negnce_bwd_kernel(const float* __restrict__ S, const float* __restrict__ diag, const float* __restrict__ lse,
+                                                         const float* __restrict__ coef, int W, int row_offset, float scale, float margin,
+                                                         TO* __restrict__ dS) {
+    __shared__ float shf[4];
+    const int i = blockIdx.x, gi = row_offset + i;
+    const float* r = S + (long)i * W;
+    const float l = lse[i], dii = r[gi], kp = coef[0], kn = coef[1];
+    auto grad_p = [&](int c, float x, float p) -> float {  // d loss / d p_c  (zero where the clamp is active)
+        if (!(p > 1e-6f && p < 1.0f - 1e-6f)) return 0.f;
+        if (c == gi) return -kp / p;
+        const float mm = fmaxf(margin + x - dii, 0.f) + fmaxf(margin + x - diag[c], 0.f);
+        return mm > 0.f ? kn / (1.0f - p) : 0.f;
+    };
+    float gp = 0.f;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        const float x = r[c], p = __expf(scale * x - l);
+        gp += grad_p(c, x, p) * p;
+    }
+    gp = block_sum(gp, shf);
+    for (int c = threadIdx.x; c < W; c += 256) {
+        const float x = r[c], p = __expf(scale * x - l);
+        st1<TO>(dS + (long)i * W + c, scale * p * (grad_p(c, x, p) - gp));
+    }
+}
+
+extern "C" int antmmf_negnce_fwd(const float* S, const float* diag, int B, int W, int row_offset, float scale, float margin, float* pos_rows,
+                                 float* neg_sum, float* neg_cnt, float* lse, hipStream_t s) {
+    if (!S || !diag || !pos_rows || !neg_sum || !neg_cnt || !lse || B < 0 || W <= 0 || row_offset < 0 || row_offset + B > W) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    hipLaunchKernelGGL(negnce_fwd_kernel, dim3(B), dim3(256), 0, s, S, diag, W, row_offset, scale, margin, pos_rows, neg_sum, neg_cnt, lse);
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_negnce_bwd(const float* S, const float* diag, const float* lse, const float* coef, int B, int W, int row_offset, float scale,
+                                 float margin, void* dS, int out_dtype, hipStream_t s) {
+    if (!S || !diag || !lse || !coef || !dS || B < 0 || W <= 0 || row_offset < 0 || row_offset + B > W) return ANTMMF_EINVAL;
+    if (!B) return ANTMMF_OK;
+    if (out_dtype == ANTMMF_BF16) hipLaunchKernelGGL(negnce_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, S, diag, lse, coef, W, row_offset, scale, margin, (bf16_t*)dS);
+    else if (out_dtype == ANTMMF_F32) hipLaunchKernelGGL(negnce_bwd_kernel<float>, dim3(B), dim3(256), 0, s, S, diag, lse, coef, W, row_offset, scale, margin, (float*)dS);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
 extern "C" int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
                                  float* loss_rows, float* denom, hipStream_t s) {
     if (!Rm || !Cm || !loss_rows || !denom || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1 || row_offset < 0 || row_offset + B > Wc) return ANTMMF_EINVAL;

@@ -177,6 +177,15 @@ int antmmf_moco_fwd(const float* pos, const float* neg, int R, int Np, int K, fl
 /* dpos (fp32) and dneg (out_dtype) for upstream per-row coefficients coef[i]. */
 int antmmf_moco_bwd(const float* pos, const float* neg, const float* lse_all, const float* lse_pos, const float* coef, int R,
                     int Np, int K, float inv_t, float* dpos, void* dneg, int out_dtype, antmmf_stream_t stream);
+/* ---- NegNCE rows (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:539-563) on a row slab S [B, W] (row i = global row
+ * row_offset + i; diag[j] = S_jj): pos_rows[i] = -log p_ii, neg_sum / neg_cnt = sum and count of -log(1 - p_ij) over the
+ * margin-violating off-diagonal entries, p = clamp(softmax(scale * S_i), 1e-6, 1 - 1e-6).  CrossEn (:528-537) is
+ * antmmf_softmax_ce_* with scale_mul = 100. */
+int antmmf_negnce_fwd(const float* S, const float* diag, int B, int W, int row_offset, float scale, float margin,
+                      float* pos_rows, float* neg_sum, float* neg_cnt, float* lse, antmmf_stream_t stream);
+/* dS (out_dtype) for loss = coef[0] * sum_i pos_i + coef[1] * sum neg_ij; coef is a 2-float DEVICE array. */
+int antmmf_negnce_bwd(const float* S, const float* diag, const float* lse, const float* coef, int B, int W, int row_offset,
+                      float scale, float margin, void* dS, int out_dtype, antmmf_stream_t stream);
 /* ---- momentum update of a MoCo key tower laid out flat: k = m k + (1 - m) q, k_shadow_bf16 (nullable) = bf16(k).
  * Replaces momentum_update_key_encoder's per-parameter loop (moco_utils.py:55-69). */
 int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, float m, antmmf_stream_t stream);

@@ -67,7 +67,7 @@ def attention_core(q, k, v, scale, key_bias=None):
     return torch.matmul(p, v)
 
 
-def clip_mha(x, in_w, in_b, out_w, out_b, heads):
+def clip_mha(x, in_w, in_b, out_w, out_b, heads, key_bias=None):
     """nn.MultiheadAttention self-attention as CLIP uses it, on [B, N, d] (the reference feeds LND;
     the arithmetic per (batch, head) is identical).  Packed in_proj [3d, d] = (q | k | v) rows;
     q is scaled by dh^-0.5.  clip/model.py:231,245-251."""
@@ -75,7 +75,7 @@ def clip_mha(x, in_w, in_b, out_w, out_b, heads):
     qkv = linear(x, in_w, in_b)
     q, k, v = qkv.split(d, dim=-1)
     dh = d // heads
-    ctx = attention_core(split_heads(q, heads), split_heads(k, heads), split_heads(v, heads), dh ** -0.5)
+    ctx = attention_core(split_heads(q, heads), split_heads(k, heads), split_heads(v, heads), dh ** -0.5, key_bias)
     return linear(merge_heads(ctx), out_w, out_b)
 
 

@@ -27,6 +27,32 @@ def clip_block(P, x, heads):
     return x + ops.linear(ops.quick_gelu(u), P["mlp.c_proj.weight"], P["mlp.c_proj.bias"])
 
 
+def dmae_block(P, x, key_bias, heads):
+    """ResidualAttentionBlockDmae on [B, N, d] (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:589-611): the CLIP block with
+    TF-style LayerNorm eps 1e-12 (:574-587) and an additive attention mask; the mask the caller builds depends on the key
+    only ((1 - video_mask) * -1e6 expanded over queries, :205-206), so it is restated as a per-key bias [B, N]."""
+    h = ops.layer_norm(x, P["ln_1.weight"], P["ln_1.bias"], 1e-12)
+    x = x + ops.clip_mha(h, P["attn.in_proj_weight"], P["attn.in_proj_bias"],
+                         P["attn.out_proj.weight"], P["attn.out_proj.bias"], heads, key_bias)
+    h = ops.layer_norm(x, P["ln_2.weight"], P["ln_2.bias"], 1e-12)
+    u = ops.linear(h, P["mlp.c_fc.weight"], P["mlp.c_fc.bias"])
+    return x + ops.linear(ops.quick_gelu(u), P["mlp.c_proj.weight"], P["mlp.c_proj.bias"])
+
+
+def dmae_agg_visual_feat(P, visual_output, video_mask, heads, layers, sim_header="seqTransf"):
+    """DmaeUtils._agg_visual_feat (dmae_utils.py:186-227) for one token per frame (expand_times = 1):
+    seqTransf: v + frame_position_embeddings(arange(n)) -> `layers` x dmae_block with key bias (1 - mask) * -1e6 -> + v.
+    Returns (visual_output, video_token_mask, visual_output_original)."""
+    if sim_header == "meanP":
+        return visual_output, video_mask, visual_output
+    n = visual_output.shape[1]
+    x = visual_output + P["frame_position_embeddings.weight"][:n][None]
+    key_bias = (1.0 - video_mask.float()) * -1000000.0
+    for i in range(layers):
+        x = dmae_block(_sub(P, f"transformerClip.resblocks.{i}."), x, key_bias, heads)
+    return x + visual_output, video_mask, visual_output
+
+
 def patchify(image, patch):
     """[B, C, H, W] -> [B, G*G, C*patch*patch], inner order (c, py, px) == Conv2d weight.flatten(1)."""
     b, c, hh, ww = image.shape

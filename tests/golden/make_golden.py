@@ -13,6 +13,7 @@ Fixtures and the reference symbols that produced them:
   ops_m2_layer.pt      torchscale EncoderLayer A/B branch prj/M2_Encoder/vlmo/torchscale/architecture/encoder.py:113-168
   loss_mil_nce.pt      get_mil_nce_loss                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
+  ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_moco.pt     same model, with_moco: true (K=64, M=0.5): 2 steps   univl_video_ret.py:262-312, moco_utils.py:13-107
   e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
@@ -104,6 +105,30 @@ def gen_m2_layer():
         d.update(grads_of(layer, prefix=f"{tag}.grad."))
     d["pad"] = pad
     save("ops_m2_layer.pt", d)
+
+
+DMAE_CFG = dict(hidden_size=128, l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="seqTransf", l3_partial_type=-1,
+                l3_max_frames=6, l3_max_words=12, l3_sim_header_hidden_layer=2)
+
+
+def gen_dmae_seqtransf():
+    vtp = L.load_vtp("dmae_vtp")
+    du = vtp["dmae"].DmaeUtils(L.AttrDict(DMAE_CFG))
+    W.fill_module_(du)
+    v = W.data_tensor("dmae.visual", (3, 6, 128)).requires_grad_(True)
+    w = W.data_tensor("dmae.w", (3, 6, 128))
+    lengths = torch.tensor([6, 4, 2])
+    mask = (torch.arange(6)[None, :] < lengths[:, None]).float()
+    out, tok_mask, orig = du._agg_visual_feat(v, mask, "seqTransf")
+    (out * w).sum().backward()
+    d = dict(visual=v, w=w, mask=mask, out=out, tok_mask=tok_mask, dvisual=v.grad)
+    for k, g_ in grads_of(du).items():  # full gradients for the small tensors, norms for the weight matrices (keeps the fixture small)
+        if g_.numel() <= 1024:
+            d[k] = g_
+        else:
+            d[k.replace("grad.", "gnorm.", 1)] = g_.norm()
+            d[k.replace("grad.", "gprobe.", 1)] = g_.flatten()[:64].clone()
+    save("ops_dmae_seqtransf.pt", d)
 
 
 def gen_losses():
@@ -340,8 +365,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "losses", "e2e_clip", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "losses", "e2e_clip", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(dmae_seqtransf=gen_dmae_seqtransf, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -422,3 +422,19 @@ def case_moco(ops, dev, R=7, Np=2, K=300):
     ops.ema_update_(kd, qv.to(dev), 0.9, sh)
     check("ema.k", kd, want, 1e-6, 1e-6)
     check("ema.shadow", sh, want, 1e-2, 1e-2)
+
+
+def case_dmae_losses(contrastive, dev, B=9):
+    """CrossEn / NegNCE (DMAE) autograd wrappers over the fused row kernels vs the oracle restatements (pinned to the reference
+    in tests/test_oracle_golden.py::test_loss_misc)."""
+    for seed, sc in ((401, 0.05), (402, 0.01)):
+        S = (rnd((B, B), seed, sc) + 0.2 * torch.eye(B)).requires_grad_(True)
+        for name, ofn, fn in (("crossen", olosses.cross_en, contrastive.cross_en), ("negnce", olosses.neg_nce, contrastive.neg_nce)):
+            S.grad = None
+            ref = ofn(S)
+            ref.backward()
+            Sd = S.detach().clone().to(dev).requires_grad_(True)
+            got = fn(Sd)
+            got.backward()
+            check(f"dmae.{name}.loss", got, ref.detach(), 1e-4, 1e-5)
+            check(f"dmae.{name}.grad", Sd.grad, S.grad, 2e-3, 1e-4)

@@ -161,6 +161,49 @@ def case_univl_moco(dev, golden, with_optimizer=False):
     return res
 
 
+def load_dmae_utils():
+    """prj/dmae_vtp's dmae_utils module, by path (its package is also called roi_univl, like base_vtp's)."""
+    import importlib.util
+
+    path = os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "dmae_vtp", "roi_univl", "univl", "model", "dmae_utils.py")
+    spec = importlib.util.spec_from_file_location("antmmf_dmae_utils", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+DMAE_CFG = dict(hidden_size=128, l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="seqTransf", l3_partial_type=-1,
+                l3_max_frames=6, l3_max_words=12, l3_sim_header_hidden_layer=2)
+
+
+def case_dmae_seqtransf(dev, golden):
+    """DmaeUtils._agg_visual_feat(seqTransf) -- frame position embedding + 2 masked CLIP blocks (fused HIP layers) + residual --
+    vs the reference run (ops_dmae_seqtransf.pt), forward and every parameter gradient."""
+    from antmmf.common.configuration import Configuration
+
+    g = golden("ops_dmae_seqtransf.pt")
+    du = load_dmae_utils().DmaeUtils(Configuration(DMAE_CFG))
+    W.fill_module_(du)
+    du = du.to(dev)
+    x = g["visual"].to(dev).requires_grad_(True)
+    out, tok_mask, orig = du._agg_visual_feat(x, g["mask"].to(dev), "seqTransf")
+    check("dmae.out", out, g["out"], 5e-2, 3e-2)
+    check("dmae.tok_mask", tok_mask, g["tok_mask"], 0, 0)
+    (out.float() * g["w"].to(dev)).sum().backward()
+    check("dmae.dvisual", x.grad, g["dvisual"], 1e-1, 5e-2)
+    n = 0
+    for name, p in du.named_parameters():
+        if "grad." + name in g:
+            check("dmae.grad." + name, p.grad, g["grad." + name], 1e-1, 1e-1)
+            n += 1
+        elif "gnorm." + name in g:
+            ref = float(g["gnorm." + name])
+            assert abs(float(p.grad.float().norm()) - ref) <= 0.15 * ref, (name, float(p.grad.float().norm()), ref)
+            n += 1
+    assert n >= 25
+    return dict(checked=n)
+
+
 # ------------------------------------------------------------------------------ M2
 M2_PRJ = os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder")
 if M2_PRJ not in sys.path:

@@ -59,5 +59,9 @@ def test_univl_moco_arena_ema(golden):
     print(mc.case_univl_moco(torch.device("cpu"), golden, with_optimizer=True))
 
 
+def test_dmae_seqtransf_vs_reference(golden):
+    print(mc.case_dmae_seqtransf(torch.device("cpu"), golden))
+
+
 def test_m2_itc_step_vs_oracle():
     print(mc.case_m2_itc_vs_oracle(torch.device("cpu")))

@@ -135,6 +135,12 @@ def test_moco_and_ema(ops):
     kc.case_moco(ops, DEV, R=5, Np=1, K=64)
 
 
+def test_dmae_losses(ops):
+    from antmmf.hip import contrastive
+
+    kc.case_dmae_losses(contrastive, DEV)
+
+
 def test_milnce(ops):
     kc.case_milnce(ops, DEV, Bg=6, n=2, world=2)
     kc.case_milnce(ops, DEV, Bg=4, n=1, world=1)

@@ -121,6 +121,35 @@ def test_e2e_clip_arch(golden):
         assert checked > 50
 
 
+def test_dmae_seqtransf(golden):
+    """DmaeUtils._agg_visual_feat(sim_header="seqTransf"): frame position embedding + 2 masked CLIP blocks + residual."""
+    import weightgen as W
+
+    g = golden("ops_dmae_seqtransf.pt")
+    names = [k[len("grad."):] for k in g if k.startswith("grad.")] + [k[len("gnorm."):] for k in g if k.startswith("gnorm.")]
+    shapes = {"frame_position_embeddings.weight": (77, 128), "text_weight_fc.weight": (1, 128), "text_weight_fc.bias": (1,),
+              "video_weight_fc.weight": (1, 128), "video_weight_fc.bias": (1,)}
+    for i in range(2):
+        b = f"transformerClip.resblocks.{i}."
+        shapes.update({b + "attn.in_proj_weight": (384, 128), b + "attn.in_proj_bias": (384,), b + "attn.out_proj.weight": (128, 128),
+                       b + "attn.out_proj.bias": (128,), b + "ln_1.weight": (128,), b + "ln_1.bias": (128,), b + "ln_2.weight": (128,),
+                       b + "ln_2.bias": (128,), b + "mlp.c_fc.weight": (512, 128), b + "mlp.c_fc.bias": (512,),
+                       b + "mlp.c_proj.weight": (128, 512), b + "mlp.c_proj.bias": (128,)})
+    P = W.fill_dict(shapes)
+    for v in P.values():
+        v.requires_grad_(True)
+    x = g["visual"].clone().requires_grad_(True)
+    out, tok_mask, _ = towers.dmae_agg_visual_feat(P, x, g["mask"], heads=2, layers=2)
+    close(out, g["out"], 1e-4, 1e-5)
+    (out * g["w"]).sum().backward()
+    close(x.grad, g["dvisual"], 1e-3, 1e-5)
+    for n in names:
+        if "grad." + n in g:
+            close(P[n].grad, g["grad." + n], 2e-3, 1e-5)
+        else:
+            close(P[n].grad.norm(), g["gnorm." + n], 2e-3, 1e-6)
+
+
 def moco_queue(name, dim, K):
     import weightgen as W
 
