@@ -256,3 +256,32 @@ class _CrossEn(torch.autograd.Function):
 
 def cross_en(sim_matrix, logit_scale=100.0):
     return _CrossEn.apply(sim_matrix, logit_scale)
+
+
+# ------------------------------------------------------------------------------ MIL-NCE on an explicit [T, V] matrix (stage 2)
+class _MilNceMatrix(torch.autograd.Function):
+    """get_mil_nce_loss (univl_video_ret.py:146-197) for n_pair = 1 on a given square similarity matrix S[t, v] (the stage-2
+    cross-encoder scores, :389-443): the fused row kernels with Rm = S and Cm = S^T; optional per-row weights (:192-195)."""
+
+    @staticmethod
+    def forward(ctx, S, weight):
+        Sf = S.float().contiguous()
+        St = Sf.t().contiguous()
+        rows, denom = ops.milnce_fwd(Sf, St, 1, 0)
+        ctx.save_for_backward(Sf, St, denom, weight)
+        ctx.dt = S.dtype
+        return (rows * weight).mean() if weight is not None else rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        Sf, St, denom, weight = ctx.saved_tensors
+        B = Sf.shape[0]
+        coef = (g.float() / B).expand(B)
+        if weight is not None:
+            coef = coef * weight.float()
+        dR, dC = ops.milnce_bwd(Sf, St, denom, coef.contiguous(), 1, 0, out_dtype=torch.float32)
+        return (dR + dC.t()).to(ctx.dt), None
+
+
+def mil_nce_matrix(S, weight=None):
+    return _MilNceMatrix.apply(S, weight)

@@ -142,11 +142,24 @@ class BertEmbeddings(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, input_ids=None, inputs_embeds=None, token_type_ids=None, position_ids=None):
-        if inputs_embeds is not None or position_ids is not None:
-            raise NotImplementedError("the HIP embedding path takes token ids with default positions")
-        if token_type_ids is not None and bool((token_type_ids != 0).any()):
-            raise NotImplementedError("non-zero token_type_ids are only used by the stage-2 cross encoder (out of scope)")
-        x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight)
+        """Token ids with all-zero token types take the fused gather kernel.  The stage-2 cross encoder's other uses
+        (univl_video_base.py:168-204) -- pre-computed `inputs_embeds` (clip tokens + the [SEP] word embedding) and token type 1 --
+        are a few [B, n + 1, d] elementwise adds in front of the same LayerNorm kernel."""
+        if position_ids is not None:
+            raise NotImplementedError("explicit position_ids (default positions 0..N-1 only)")
+        nonzero_types = token_type_ids is not None and bool((token_type_ids != 0).any())
+        if inputs_embeds is None and not nonzero_types:
+            x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight)
+        else:
+            if inputs_embeds is None:
+                x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, None).float()
+                seq = input_ids.shape[1]
+            else:
+                seq = inputs_embeds.shape[1]
+                x = inputs_embeds.float() + self.position_embeddings.weight[:seq][None]
+            if token_type_ids is None:
+                token_type_ids = torch.zeros(x.shape[:2], dtype=torch.long, device=x.device)
+            x = (x + self.token_type_embeddings.weight[token_type_ids]).to(torch.bfloat16)
         x = HF.layer_norm(x, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
         if self.training and self.dropout.p > 0:
             x = self.dropout(x)

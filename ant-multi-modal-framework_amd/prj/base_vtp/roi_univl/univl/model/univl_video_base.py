@@ -1,7 +1,8 @@
 """UnivlVideoBase: the two towers + pooling + L2 normalisation of the contrastive step (reference:
-prj/base_vtp/roi_univl/univl/model/univl_video_base.py:14-166,272-299).  In scope: arch_type "clip", stage 1
-(ITC).  The stage-2 cross encoder (prepare_cross_*, get_cross_output; reference :168-271) is a "next" row of
-SURVEY.md section 8(f) and raises here."""
+prj/base_vtp/roi_univl/univl/model/univl_video_base.py:14-166,272-299) and the stage-2 cross-modal merged attention
+(prepare_cross_text / prepare_cross_visual / get_cross_output, reference :168-271): [text tokens ; clip tokens ; SEP] through
+the text tower's own BERT layers (fused HIP layers with the -10000 key mask), pooled = cls @ text_projection.
+In scope: arch_type "clip"."""
 import torch
 from torch import nn
 
@@ -57,15 +58,66 @@ class UnivlVideoBase(nn.Module):
         pooled_output = HF.l2_normalize(pooled_output.contiguous())
         return dict(sequence_output=sequence_output, pooled_output=pooled_output, input_mask=input_mask, words_importance=None)
 
+    # ------------------------------------------------------------------ stage-2 cross encoder
+    def prepare_cross_text(self, input_ids, input_mask):
+        cap_embed = self.cross_embeddings(input_ids=input_ids, token_type_ids=torch.zeros_like(input_ids))
+        return cap_embed, input_mask, cap_embed.shape[0]
+
+    def prepare_cross_visual(self, visual_embed, visual_mask=None):
+        """clip tokens + the [SEP] (id 102) word embedding, token type 1, positions 0..n  (reference :178-204)."""
+        bsz, num_clip = visual_embed.shape[0], visual_embed.shape[1]
+        if visual_mask is None:
+            visual_mask = torch.zeros((bsz, num_clip), device=visual_embed.device).bool()
+        sep_id = torch.full((bsz,), 102, dtype=torch.long, device=visual_embed.device)
+        sep = self.cross_embeddings.word_embeddings(sep_id).unsqueeze(1)
+        visual_mask = visual_mask.logical_not().long()
+        inputs_embeds = torch.cat([visual_embed.float(), sep.float()], 1)
+        token_type_ids = torch.ones(inputs_embeds.shape[:2], dtype=torch.long, device=inputs_embeds.device)
+        new_visual_embed = self.cross_embeddings(inputs_embeds=inputs_embeds, token_type_ids=token_type_ids)
+        new_visual_mask = torch.cat([visual_mask, visual_mask.new_ones((bsz, 1))], 1)
+        return new_visual_embed, new_visual_mask, num_clip
+
+    def build_transformer_input(self, visual_embed_dict, text_embed_dict, caption_input):
+        cap_embed, cap_mask, batch_size = self.prepare_cross_text(caption_input["caption_input_ids"], caption_input["caption_input_mask"])
+        visual_embed, visual_mask, num_clip = self.prepare_cross_visual(visual_embed_dict["visual_embed"], visual_embed_dict["visual_mask"])
+        return cap_embed, visual_embed, cap_mask, visual_mask, num_clip, batch_size
+
+    def _align_text_to_video_clips(self, cap_embed, cap_mask, num_clip: int = 1):
+        if num_clip > 1:
+            cap_embed = cap_embed.repeat_interleave(num_clip, dim=0)
+            cap_mask = cap_mask.repeat_interleave(num_clip, dim=0)
+        return cap_embed, cap_mask
+
+    def get_cross_output(self, cap_embed, visual_embed, cap_mask, visual_mask, n_clips):
+        """-> (text part, visual part without its SEP, pooled = cls @ text_projection)  (reference :224-271)."""
+        cap_embed, cap_mask = self._align_text_to_video_clips(cap_embed, cap_mask, n_clips)
+        n_text = cap_embed.size(1)
+        embed = torch.cat([cap_embed, visual_embed], 1).contiguous()
+        mask = torch.cat([cap_mask, visual_mask], 1)
+        key_bias = (1.0 - mask.float()) * -10000.0
+        sequence_output = self.cross_encoder(embed, key_bias.contiguous(), head_mask=None)[0]
+        cls = sequence_output[:, 0, :].contiguous()
+        if self.text_encoder.text_projection is not None:
+            pooled_output = HF.linear(cls, self.text_encoder.text_projection, weight_layout="io")
+        else:
+            pooled_output = cls
+        return sequence_output[:, :n_text], sequence_output[:, n_text:-1], pooled_output
+
     def get_l2_input(self, img_input, caption_input):
         visual = self.forward_img_encoder(**img_input)
         text = self.forward_text_encoder(caption_input["caption_raw_input_ids"], caption_input["caption_input_mask"])
         n_clips = visual["visual_embed"].shape[1]
         batch_size = text["pooled_output"].shape[0]
-        # (cap_embed, cap_mask) / (visual_embed, visual_mask) feed only the stage-2 cross encoder; stage 1 carries None
-        cap_input = (None, caption_input["caption_input_mask"], text["pooled_output"], batch_size)
-        vis_input = (visual["visual_embed"], visual["visual_mask"], visual["clip_feature"], n_clips)
+        if self.with_cross_encoder:
+            cap_embed, visual_embed, cap_mask, visual_mask, n_clips, batch_size = self.build_transformer_input(visual, text, caption_input)
+            cap_input = (cap_embed, cap_mask, text["pooled_output"], batch_size)
+            vis_input = (visual_embed, visual_mask, visual["clip_feature"], n_clips)
+        else:
+            # (cap_embed, cap_mask) / (visual_embed, visual_mask) feed only the stage-2 cross encoder; stage 1 carries None
+            cap_input = (None, caption_input["caption_input_mask"], text["pooled_output"], batch_size)
+            vis_input = (visual["visual_embed"], visual["visual_mask"], visual["clip_feature"], n_clips)
         return cap_input, vis_input, text, visual
 
-    def get_cross_output(self, *args, **kwargs):
-        raise NotImplementedError("stage-2 cross encoder: SURVEY.md section 8(f) 'next' row, not built in this round")
+    def forward(self, img_input, caption_input):
+        cap_input, vis_input, _, _ = self.get_l2_input(img_input, caption_input)
+        return self.get_cross_output(cap_input[0], vis_input[0], cap_input[1], vis_input[1], vis_input[3])

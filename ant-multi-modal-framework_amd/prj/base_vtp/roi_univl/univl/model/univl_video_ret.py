@@ -5,11 +5,19 @@ Training step: towers -> L2-normalised embeddings -> row-sharded global MIL-NCE 
 replaces gather_tensor x2 + get_l1_simi_matrix + the tiled [T*n, V*n] matrix + get_mil_nce_loss.  `l1_simi`
 (reported [T, V] scores, logsumexp over clips) is produced for the LOCAL pairs, as in the single-process
 reference.  with_moco: true (the reference default) replaces the level-1 loss with the two-direction MoCo loss against the
-momentum key encoders' queues (reference :262-312, moco_utils.py).  Stage 2 is a 'next' row and raises."""
+momentum key encoders' queues (reference :262-312, moco_utils.py).
+
+Stage 2 (reference :33-144,389-443): every (caption, video) pair of the local batch goes through the cross encoder
+([text ; clips ; SEP] through the text tower's BERT layers) -> similarity_dense -> [T, V] scores -> MIL-NCE on that matrix;
+optional hard-negative mining picks each caption's videos from the (gathered) level-1 scores.  The pair batch is built once per
+chunk of caption rows (expand + one cat), there is no Python loop over captions in the mining branch, and the loss runs on
+the fused row kernels."""
 import torch
 from torch import nn
 
 from antmmf.hip import contrastive
+from antmmf.hip import functional as HF
+from antmmf.utils.distributed_utils import all_gather, gather_tensor, get_rank
 from .moco_utils import MocoUtils
 from .univl_video_base import UnivlVideoBase
 
@@ -18,9 +26,13 @@ class UnivlForVideoTextRetrieval(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        if "stage2" in self.config.training_stage:
-            raise NotImplementedError("stage2 (cross-encoder scoring + hard-negative mining): SURVEY.md 8(f) 'next' row")
-        self.module = UnivlVideoBase(config, with_cross_encoder=False)
+        with_cross_encoder = "stage2" in self.config.training_stage
+        self.module = UnivlVideoBase(config, with_cross_encoder=with_cross_encoder)
+        if with_cross_encoder:
+            self.dropout = nn.Dropout(0.1)
+            self.similarity_dense = nn.Sequential(nn.Linear(self.config.hidden_size, self.config.hidden_size * 2), nn.ReLU(True),
+                                                  nn.Linear(self.config.hidden_size * 2, 1))
+        self.pair_chunk_rows = int(self.config.get("cross_chunk_rows", 5))  # caption rows per cross-encoder call (reference: 5)
         self.with_moco = bool(self.config.get("with_moco", True))
         self.moco_utils = None  # built lazily at the first training step, as in the reference (:263-268)
 
@@ -68,8 +80,101 @@ class UnivlForVideoTextRetrieval(nn.Module):
         mu.dequeue_and_enqueue(key_v, key_t)
         return (loss_t + loss_v) / 2.0
 
+    # ------------------------------------------------------------------ stage 2
+    def _score_pairs(self, cap_embed, cap_mask, vis_embed, vis_mask):
+        """Cross-encode aligned pairs (row p of every argument) -> similarity_dense score [P]."""
+        _, _, pooled = self.module.get_cross_output(cap_embed, vis_embed, cap_mask, vis_mask, 1)
+        pooled = self.dropout(pooled) if self.training and self.dropout.p > 0 else pooled
+        fc1, fc2 = self.similarity_dense[0], self.similarity_dense[2]
+        hidden = HF.linear(pooled.contiguous(), fc1.weight, fc1.bias, act="relu")
+        # the final Linear has ONE output: a [P, 2h] x [2h] product, done as an fp32 reduction (no GEMM tile to fill)
+        return (hidden.float() * fc2.weight.float().view(1, -1)).sum(-1) + fc2.bias.float()
+
+    def _cross_similarity(self, sequence_output, visual_output, attention_mask, video_mask, num_clips):
+        """[b_text, b_visual] cross-encoder scores of all pairs, `pair_chunk_rows` caption rows per call (reference :33-89)."""
+        b_text, b_visual = sequence_output.size(0), visual_output.size(0)
+        rows = []
+        for r0 in range(0, b_text, self.pair_chunk_rows):
+            seq = sequence_output[r0:r0 + self.pair_chunk_rows]
+            msk = attention_mask[r0:r0 + self.pair_chunk_rows]
+            step = seq.size(0)
+            seq_l = seq.unsqueeze(1).expand(-1, b_visual, -1, -1).reshape(step * b_visual, seq.size(1), seq.size(2))
+            msk_l = msk.unsqueeze(1).expand(-1, b_visual, -1).reshape(step * b_visual, -1)
+            vis_r = visual_output.unsqueeze(0).expand(step, -1, -1, -1).reshape(step * b_visual, visual_output.size(1), visual_output.size(2))
+            vmk_r = video_mask.unsqueeze(0).expand(step, -1, -1).reshape(step * b_visual, -1)
+            rows.append(self._score_pairs(seq_l, msk_l, vis_r, vmk_r).view(step, b_visual))
+        return torch.cat(rows, dim=0)
+
+    def _cross_similarity_hard_mining(self, vis_input, cap_input, l1_simi_matrix):
+        """Each caption is scored against `bsz` videos chosen from the level-1 scores (top_k / nearliest), its own video forced
+        onto the diagonal (reference :91-144) -- batched: one index tensor instead of a Python loop over captions."""
+        sequence_output, attention_mask, bsz = cap_input[0], cap_input[1], cap_input[3]
+        visual_output, video_mask = vis_input[0], vis_input[1]
+        visual_output = gather_tensor(visual_output, method="cat", back_gradient=True, pad_tensors=True)
+        video_mask = gather_tensor(video_mask, method="cat", back_gradient=True, pad_tensors=True)
+        all_bsz = all_gather(bsz)
+        beg_idx = sum(all_bsz[:get_rank()])
+        own = torch.arange(bsz, device=l1_simi_matrix.device)
+        raw = beg_idx + own
+        score = l1_simi_matrix[raw].clone()                                    # [bsz, B_g]
+        if self.config.re_sample_method == "top_k":
+            score[own, raw] -= 100.0
+            chosen = torch.topk(score, bsz, dim=1, sorted=False).indices
+        elif self.config.re_sample_method == "nearliest":
+            score = (score - score[own, raw].unsqueeze(1)).abs()
+            score[own, raw] = 100.0
+            chosen = torch.topk(score, bsz, dim=1, sorted=False, largest=False).indices
+        else:
+            raise ValueError(f"re_sample_method {self.config.re_sample_method!r}")
+        chosen[own, own] = raw                                                 # the true pair sits on the diagonal
+        self._last_chosen = chosen.detach()                                    # (for tests: topk(sorted=False) order is unspecified)
+        flat = chosen.reshape(-1)
+        vis_r, vmk_r = visual_output[flat], video_mask[flat]
+        seq_l = sequence_output.unsqueeze(1).expand(-1, bsz, -1, -1).reshape(bsz * bsz, sequence_output.size(1), sequence_output.size(2))
+        msk_l = attention_mask.unsqueeze(1).expand(-1, bsz, -1).reshape(bsz * bsz, -1)
+        out = []
+        step = self.pair_chunk_rows * bsz
+        for p0 in range(0, bsz * bsz, step):
+            out.append(self._score_pairs(seq_l[p0:p0 + step], msk_l[p0:p0 + step], vis_r[p0:p0 + step], vmk_r[p0:p0 + step]))
+        return torch.cat(out).view(bsz, bsz)
+
+    def get_l2_simi_matrix(self, cap_embed, cap_mask, visual_embed, visual_mask, num_clips, cal_cross=False):
+        if cal_cross:
+            return self._cross_similarity(cap_embed, visual_embed, cap_mask, visual_mask, num_clips)
+        return self._score_pairs(*self.module._align_text_to_video_clips(cap_embed, cap_mask, 1), visual_embed, visual_mask).view(-1, 1)
+
+    def forward_stage2(self, vis_input, cap_input, output_dict=None, cal_cross=True):
+        output_dict = dict(losses={}) if output_dict is None else output_dict
+        cap_embed, cap_mask, batch_size = cap_input[0], cap_input[1], cap_input[3]
+        visual_embed, visual_mask, num_clips = vis_input[0], vis_input[1], vis_input[3]
+        mining = self.training and self.config.get("hard_example_mining", False)
+        if mining:
+            l1_simi_clone = output_dict["l1_simi"].clone().detach()
+            l2_simi = self._cross_similarity_hard_mining(vis_input, cap_input, l1_simi_clone)
+        else:
+            l2_simi = self.get_l2_simi_matrix(cap_embed, cap_mask, visual_embed, visual_mask, num_clips, cal_cross=cal_cross)
+        if cal_cross and l2_simi.size(0) == l2_simi.size(1):
+            weight = None
+            if mining and self.config.re_weight_method == "median":
+                beg = sum(all_gather(batch_size)[:get_rank()])
+                l1_diag = torch.diagonal(l1_simi_clone[beg:beg + batch_size, beg:beg + batch_size])
+                l1_mean, l1_min = l1_diag.mean(), l1_diag.min()   # ("median" in the reference's config is a mean, :425)
+                down = torch.clamp((l1_mean - l1_min) / (l1_diag - l1_min), min=0.2)
+                weight = torch.where(l1_diag > l1_mean, down, torch.ones_like(l1_diag))
+            loss = contrastive.mil_nce_matrix(l2_simi.view(batch_size, batch_size), weight)
+        else:
+            loss = l2_simi.new_tensor(0.0)
+        output_dict["losses"]["level2_similarity_loss"] = loss
+        output_dict["l2_simi"] = self.reduce_clips(l2_simi, "l2")
+        return output_dict
+
     def forward_stage(self, cap_input, vis_input, cal_cross=True):
-        return self.forward_stage1(vis_input, cap_input, None, cal_cross=cal_cross)
+        output_dict = None
+        if "stage1" in self.config.training_stage:
+            output_dict = self.forward_stage1(vis_input, cap_input, output_dict, cal_cross=cal_cross)
+        if "stage2" in self.config.training_stage:
+            output_dict = self.forward_stage2(vis_input, cap_input, output_dict, cal_cross=cal_cross)
+        return output_dict
 
     def forward(self, img_input, caption_input, ocr_input=None, region_input=None, caption_output=None, sample_list=None):
         cap_input, vis_input, _, _ = self.module.get_l2_input(img_input, caption_input)

@@ -62,6 +62,40 @@ def univl_stage1_moco(P, Pk, queues, image_data, input_ids, input_mask, n_clips,
     return dict(loss=(loss_t + loss_v) / 2.0, l1_simi=q["l1_simi"], text_embed=q_t, video_embed=q_v)
 
 
+def univl_stage2(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads, chosen=None, weight=None):
+    """Stage-2 cross-encoder scoring + MIL-NCE on the [T, V] score matrix (univl_video_ret.py:33-144,389-443;
+    univl_video_base.py:168-271), single process, dropout p = 0.
+    Every (caption t, video v) pair: [BertEmbeddings(ids_t, type 0) ; BertEmbeddings(inputs_embeds=[clip tokens_v ; word_emb[102]],
+    type 1)] -> the text tower's BERT layers with the -10000 key mask -> cls @ text_projection -> similarity_dense.
+    `chosen` [T, T] (optional): hard-negative mining's video index for every (t, column) -- row t is scored against
+    videos chosen[t, :] (the reference picks them with torch.topk(sorted=False), whose order is unspecified; the caller passes
+    the indices actually used).  `weight` [T]: optional per-row loss weights (:192-195).  Returns dict(l2_simi, loss)."""
+    b = image_data.shape[0]
+    frames_per_clip = image_data.shape[1] // n_clips
+    Pt = towers._sub(P, "module.text_encoder.")
+    Pe = towers._sub(Pt, "embeddings.")
+    vis = towers.clip_vit(towers._sub(P, "module.img_encoder.visual."), image_data.flatten(0, 1), vit_heads, patch)
+    clip_tokens = vis.view(b * n_clips, frames_per_clip, -1).mean(1).view(b, n_clips, -1)          # visual_embed (not normalised)
+    cap_embed = towers.bert_embeddings(Pe, input_ids=input_ids)                                   # [T, S, h]
+    sep = Pe["word_embeddings.weight"][torch.full((b,), 102)].unsqueeze(1)
+    vis_in = torch.cat([clip_tokens, sep], 1)
+    vis_embed = towers.bert_embeddings(Pe, inputs_embeds=vis_in, token_type_ids=torch.ones(vis_in.shape[:2], dtype=torch.long))
+    vis_mask = torch.ones(b, n_clips + 1)
+    if chosen is None:
+        chosen = torch.arange(b)[None, :].expand(b, b)
+    rows = []
+    for t in range(b):
+        idx = chosen[t]
+        emb = torch.cat([cap_embed[t][None].expand(b, -1, -1), vis_embed[idx]], 1)
+        mask = torch.cat([input_mask[t][None].expand(b, -1).float(), vis_mask[idx]], 1)
+        seq = towers.bert_encoder(towers._sub(Pt, "encoder."), emb, towers.bert_key_bias(mask), bert_heads)
+        pooled = seq[:, 0] @ Pt["text_projection"]
+        hid = torch.relu(ops.linear(pooled, P["similarity_dense.0.weight"], P["similarity_dense.0.bias"]))
+        rows.append(ops.linear(hid, P["similarity_dense.2.weight"], P["similarity_dense.2.bias"]).view(1, b))
+    l2 = torch.cat(rows, 0)
+    return dict(l2_simi=l2, loss=losses.mil_nce(l2, b, 1, weight))
+
+
 def m2_itc(P, image, text_ids, text_masks, heads, patch, gather=None):
     """M2 two-level ITC step: towers pinned by VLMo.infer_image/infer_text, logits formula from
     prj/M2_Encoder/m2_encoder.py:92-95, symmetric CE on both the cls and the cls_vlffn pairs

@@ -15,6 +15,8 @@ Fixtures and the reference symbols that produced them:
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
   ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
+  e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
+                       reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
   e2e_clip_moco.pt     same model, with_moco: true (K=64, M=0.5): 2 steps   univl_video_ret.py:262-312, moco_utils.py:13-107
   e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
   gather_w2.pt         gather_tensor(back_gradient=True)  antmmf/utils/distributed_utils.py:92-189 (2-proc gloo)
@@ -228,6 +230,30 @@ def gen_e2e_clip():
     save("e2e_clip_arch.pt", d)
 
 
+def gen_e2e_clip_stage2():
+    vtp = L.load_vtp("base_vtp")
+    d = {}
+    bsz, n_clips = 4, 2
+    batch = tiny_clip_batch(bsz, n_clips, tag="s2")
+    d.update({"s2.image_data": batch["image"]["image_data"], "s2.input_ids": batch["caption"]["caption_input_ids"],
+              "s2.input_mask": batch["caption"]["caption_input_mask"]})
+    for tag, extra in (("plain", {}), ("mine", dict(hard_example_mining=True, re_sample_method="top_k", re_weight_method="median"))):
+        cfg = dict(TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True, **extra)
+        model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
+        W.fill_module_(model)
+        model.train()
+        model.dropout.p = 0.0  # the only stochastic op on the path (BERT dropouts are 0 in this config)
+        out = model(batch["image"], batch["caption"])
+        loss = out["losses"]["level1_similarity_loss"] + out["losses"]["level2_similarity_loss"]
+        loss.backward()
+        d.update({f"s2.{tag}.loss1": out["losses"]["level1_similarity_loss"], f"s2.{tag}.loss2": out["losses"]["level2_similarity_loss"],
+                  f"s2.{tag}.l2_simi": out["l2_simi"], f"s2.{tag}.l1_simi": out["l1_simi"]})
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                d[f"s2.{tag}.gnorm.{n}"] = p.grad.norm()
+    save("e2e_clip_stage2.pt", d)
+
+
 def moco_queue(name, dim, K):
     return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
 
@@ -365,8 +391,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "losses", "e2e_clip", "e2e_clip_moco", "e2e_m2", "gather"]
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_clip_moco", "e2e_m2", "gather"]
     fns = dict(dmae_seqtransf=gen_dmae_seqtransf, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
-               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_m2=gen_e2e_m2, gather=gen_gather)
+               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -58,8 +58,13 @@ def clip_arch_shapes(c=CLIP_ARCH):
     return s
 
 
-def clip_arch_params(requires_grad=False):
-    P = W.fill_dict(clip_arch_shapes())
+def clip_arch_params(requires_grad=False, stage2=False):
+    shapes = clip_arch_shapes()
+    if stage2:  # similarity_dense of the stage-2 head (univl_video_ret.py:23-29)
+        h = CLIP_ARCH["hidden"]
+        shapes.update({"similarity_dense.0.weight": (2 * h, h), "similarity_dense.0.bias": (2 * h,),
+                       "similarity_dense.2.weight": (1, 2 * h), "similarity_dense.2.bias": (1,)})
+    P = W.fill_dict(shapes)
     if requires_grad:
         for v in P.values():
             v.requires_grad_(True)

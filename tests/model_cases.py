@@ -86,6 +86,58 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
 
 
+def case_univl_stage2(dev, golden, mining=False):
+    """stage1 + stage2 of the product model.  Plain: against the reference run (e2e_clip_stage2.pt).  Hard-negative mining +
+    mean re-weighting: against the CPU oracle given the video indices the model actually picked (torch.topk(sorted=False) order
+    is unspecified, so the reference's own pick order cannot be pinned)."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    g = golden("e2e_clip_stage2.pt")
+    extra = dict(hard_example_mining=True, re_sample_method="top_k", re_weight_method="median") if mining else {}
+    cfg = Configuration(dict(TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True, **extra))
+    model = UnivlForVideoTextRetrieval(cfg)
+    W.fill_module_(model)
+    model = model.to(dev).train()
+    model.dropout.p = 0.0
+    img, ids, mask = g["s2.image_data"].to(dev), g["s2.input_ids"].to(dev), g["s2.input_mask"].to(dev)
+    bsz, n_clips = img.shape[0], 2
+    img_input = dict(image_data=img, image_pad_mask=torch.zeros(bsz, img.shape[1], 32, 32, dtype=torch.bool, device=dev),
+                     image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz)
+    cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
+    out = model(img_input, cap_input)
+    l1, l2 = out["losses"]["level1_similarity_loss"], out["losses"]["level2_similarity_loss"]
+    (l1 + l2).backward()
+    if not mining:
+        ref1, ref2 = float(g["s2.plain.loss1"]), float(g["s2.plain.loss2"])
+        assert abs(float(l1) - ref1) <= 2e-3 * abs(ref1), (float(l1), ref1)
+        assert abs(float(l2) - ref2) <= 5e-3 * abs(ref2), (float(l2), ref2)
+        check("s2.l2_simi", out["l2_simi"], g["s2.plain.l2_simi"], 5e-2, 3e-2)
+        worst = []
+        for n, p in model.named_parameters():
+            key = f"s2.plain.gnorm.{n}"
+            if key in g and p.grad is not None:
+                worst.append((abs(float(p.grad.float().norm()) - float(g[key])), float(g[key]), n))
+        top = max(w[1] for w in worst)
+        rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-4 * top), reverse=True)
+        assert len(rel) > 50 and rel[0][0] < 0.2, rel[:5]
+        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3])
+    from oracle import step as ostep
+
+    P = tiny_models.clip_arch_params(stage2=True)
+    chosen = model._last_chosen.cpu()
+    l1m = out["l1_simi"].detach().float().cpu()
+    d = torch.diagonal(l1m)
+    weight = torch.where(d > d.mean(), torch.clamp((d.mean() - d.min()) / (d - d.min()), min=0.2), torch.ones_like(d))
+    ref = ostep.univl_stage2(P, g["s2.image_data"], g["s2.input_ids"], g["s2.input_mask"], n_clips, vit_heads=2, patch=8, bert_heads=2,
+                             chosen=chosen, weight=weight)
+    assert bool((torch.diagonal(chosen) == torch.arange(bsz)).all()) and chosen.shape == (bsz, bsz)
+    check("s2.mine.l2_simi", out["l2_simi"], ref["l2_simi"], 5e-2, 3e-2)
+    assert abs(float(l2) - float(ref["loss"])) <= 5e-3 * abs(float(ref["loss"])), (float(l2), float(ref["loss"]))
+    return dict(loss2=(float(l2), float(ref["loss"])))
+
+
 def moco_queue(name, dim, K):
     return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
 

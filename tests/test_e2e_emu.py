@@ -59,6 +59,16 @@ def test_univl_moco_arena_ema(golden):
     print(mc.case_univl_moco(torch.device("cpu"), golden, with_optimizer=True))
 
 
+@SLOW
+def test_univl_stage2_vs_reference(golden):
+    print(mc.case_univl_stage2(torch.device("cpu"), golden))
+
+
+@SLOW
+def test_univl_stage2_hard_mining_vs_oracle(golden):
+    print(mc.case_univl_stage2(torch.device("cpu"), golden, mining=True))
+
+
 def test_dmae_seqtransf_vs_reference(golden):
     print(mc.case_dmae_seqtransf(torch.device("cpu"), golden))
 

@@ -39,6 +39,14 @@ def test_univl_moco_arena_ema(golden):
     print(mc.case_univl_moco(DEV, golden, with_optimizer=True))
 
 
+def test_univl_stage2_vs_reference(golden):
+    print(mc.case_univl_stage2(DEV, golden))
+
+
+def test_univl_stage2_hard_mining_vs_oracle(golden):
+    print(mc.case_univl_stage2(DEV, golden, mining=True))
+
+
 def test_dmae_seqtransf_vs_reference(golden):
     print(mc.case_dmae_seqtransf(DEV, golden))
 

@@ -150,6 +150,27 @@ def test_dmae_seqtransf(golden):
             close(P[n].grad.norm(), g["gnorm." + n], 2e-3, 1e-6)
 
 
+def test_e2e_clip_stage2(golden):
+    """stage1 + stage2 (cross-encoder scores of every caption/video pair, MIL-NCE on the score matrix) vs the reference run."""
+    import tiny_models
+
+    g = golden("e2e_clip_stage2.pt")
+    P = tiny_models.clip_arch_params(requires_grad=True, stage2=True)
+    args = (g["s2.image_data"], g["s2.input_ids"], g["s2.input_mask"], 2)
+    o1 = step.univl_stage1(P, *args, vit_heads=2, patch=8, bert_heads=2)
+    o2 = step.univl_stage2(P, *args, vit_heads=2, patch=8, bert_heads=2)
+    close(o1["loss"], g["s2.plain.loss1"], 1e-5, 1e-6)
+    close(o2["l2_simi"], g["s2.plain.l2_simi"], 1e-4, 1e-5)
+    close(o2["loss"], g["s2.plain.loss2"], 1e-5, 1e-6)
+    (o1["loss"] + o2["loss"]).backward()
+    checked = 0
+    for n, p in P.items():
+        if f"s2.plain.gnorm.{n}" in g:
+            close(p.grad.norm(), g[f"s2.plain.gnorm.{n}"], 2e-3, 1e-7)
+            checked += 1
+    assert checked > 55
+
+
 def moco_queue(name, dim, K):
     import weightgen as W
 
