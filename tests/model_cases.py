@@ -86,6 +86,51 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
 
 
+def case_temporal_head(dev):
+    """UnivlForVideo.get_temporal_output ([cls] + clip features through a 3-layer BERT, inputs_embeds path) vs the CPU oracle's
+    BERT restatement on the same weights, forward and input / parameter gradients."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from oracle import towers as otowers
+    from roi_univl.univl.model.univl_video_pretrain import UnivlForVideo
+
+    tenc = dict(type="RobertBertEncoder", params=dict(pretrained=False, vocab_size=40, hidden_size=128, intermediate_size=512,
+                                                      num_hidden_layers=3, num_attention_heads=2, max_position_embeddings=40,
+                                                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=128, is_proj=False))
+    model = UnivlForVideo(Configuration(dict(TINY_CLIP_CFG, with_temporal_encoder=True, temporal_encoder=tenc)))
+    W.fill_module_(model)
+    model = model.to(dev).train()
+    clip = (W.data_tensor("temporal.clip", (3, 8, 128)) * 0.5)
+    w = W.data_tensor("temporal.w", (3, 9, 128))
+    x = clip.detach().clone().to(dev).requires_grad_(True)
+    out = model.get_temporal_output(x)
+    (out.float() * w.to(dev)).sum().backward()
+    P = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in model.named_parameters() if n.startswith(("temporal_encoder.", "cls_token"))}
+    xr = clip.detach().clone().requires_grad_(True)
+    emb_in = torch.cat([P["cls_token"].expand(3, -1, -1), xr], 1)
+    Pe = {k[len("temporal_encoder.embeddings."):]: v for k, v in P.items() if k.startswith("temporal_encoder.embeddings.")}
+    Pe["word_embeddings.weight"] = None
+    h = otowers.bert_embeddings(Pe, inputs_embeds=emb_in)
+    ref = otowers.bert_encoder({k[len("temporal_encoder.encoder."):]: v for k, v in P.items() if k.startswith("temporal_encoder.encoder.")},
+                               h, torch.zeros(3, 9), 2)
+    (ref * w).sum().backward()
+    check("temporal.out", out, ref, 5e-2, 3e-2)
+    check("temporal.dclip", x.grad, xr.grad, 1e-1, 5e-2)
+    check("temporal.dcls", model.cls_token.grad, P["cls_token"].grad, 1e-1, 5e-2)
+    named = dict(model.named_parameters())
+    n = 0
+    top = max(float(v.grad.norm()) for v in P.values() if v.grad is not None)
+    for k, v in P.items():
+        if v.grad is None or named[k].grad is None:
+            continue
+        rn = float(v.grad.norm())
+        if rn > 1e-4 * top:  # (key-projection biases have an analytically zero gradient)
+            assert abs(float(named[k].grad.float().norm()) - rn) <= 0.15 * rn, (k, float(named[k].grad.float().norm()), rn)
+            n += 1
+    assert n > 30
+    return dict(checked=n)
+
+
 def case_univl_stage2(dev, golden, mining=False):
     """stage1 + stage2 of the product model.  Plain: against the reference run (e2e_clip_stage2.pt).  Hard-negative mining +
     mean re-weighting: against the CPU oracle given the video indices the model actually picked (torch.topk(sorted=False) order
