@@ -49,6 +49,8 @@ _SIGNATURES = {
     "antmmf_moco_fwd": [P, P, I, I, I, F, P, P, P, P],
     "antmmf_moco_bwd": [P, P, P, P, P, I, I, I, F, P, P, I, P],
     "antmmf_ema_update": [P, P, P, L, F, P],
+    "antmmf_wti_reduce_fwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    "antmmf_wti_reduce_bwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "antmmf_negnce_fwd": [P, P, I, I, I, F, F, P, P, P, P, P],
     "antmmf_negnce_bwd": [P, P, P, P, I, I, I, F, F, P, I, P],
 }

@@ -285,3 +285,65 @@ class _MilNceMatrix(torch.autograd.Function):
 
 def mil_nce_matrix(S, weight=None):
     return _MilNceMatrix.apply(S, weight)
+
+
+# ------------------------------------------------------------------------------ DMAE token-wise interaction
+class _WtiReduce(torch.autograd.Function):
+    """(t2v [A,B,T], v2t [A,B,V]) of DmaeUtils._get_wti_similarity for one block of text rows: the fp32-accurate split GEMM gives
+    the [A*T, B*V] similarity slab, one fused kernel reduces it (max over frames / words, optional second-best-frame term) and
+    records the arg-max routing; backward rebuilds the sparse slab gradient in one pass and returns to the features with two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, text, video, tmask, vmask, f2f, z2_of):
+        A, T, D = text.shape
+        B, V, _ = video.shape
+        t2d, v2d = text.reshape(A * T, D).float().contiguous(), video.reshape(B * V, D).float().contiguous()
+        S = matmul_f32(t2d, v2d).contiguous()                               # [A*T, B*V] (matmul_f32 slices its padded result)
+        tmask, vmask = tmask.float().contiguous(), vmask.float().contiguous()
+        f2f_c = None if f2f is None else f2f.detach().float().contiguous()
+        z2_c = None if z2_of is None else z2_of.to(torch.int32).contiguous()
+        t2v, v2t, z1, tmax = ops.wti_reduce_fwd(S, A, T, B, V, tmask, vmask, f2f_c, z2_c)
+        ctx.save_for_backward(S, t2d, v2d, tmask, vmask, f2f_c, z2_c, z1, tmax)
+        ctx.dims = (A, T, B, V, D, text.dtype, video.dtype)
+        return t2v, v2t
+
+    @staticmethod
+    def backward(ctx, dt2v, dv2t):
+        S, t2d, v2d, tmask, vmask, f2f_c, z2_c, z1, tmax = ctx.saved_tensors
+        A, T, B, V, D, tdt, vdt = ctx.dims
+        dS, df2f = ops.wti_reduce_bwd(S, A, T, B, V, tmask, vmask, f2f_c, z2_c, z1, tmax, dt2v.float(), dv2t.float(), out_dtype=BF)
+        dSp = _pad2(dS, 8, 8)
+        vb, tb = _pad2(v2d.to(BF), 8, 8), _pad2(t2d.to(BF), 8, 8)
+        # dtext[i, d] = sum_j dS[i, j] video[j, d];  dvideo[j, d] = sum_i dS[i, j] text[i, d]
+        dtext = ops.gemm(dSp, vb, q_rmajor=True, out_dtype=torch.float32)[:A * T, :D]
+        dvideo = ops.gemm(dSp, tb, p_rmajor=True, q_rmajor=True, out_dtype=torch.float32)[:B * V, :D]
+        return dtext.reshape(A, T, D).to(tdt), dvideo.reshape(B, V, D).to(vdt), None, None, df2f, None
+
+
+def wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight=None, video_weight=None, self_weight=False, weighted=True,
+                   rows_per_block=None):
+    """DmaeUtils._get_wti_similarity (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:85-131) -> [A, B].
+    text_feat [A, T, D], video_feat [B, V, D] (L2-normalised by the caller), masks 1 = real token; see oracle.losses.dmae_wti_similarity
+    for the arithmetic.  Text rows are processed in blocks so that the fp32 slab stays below ~1 GiB."""
+    A, T, _ = text_feat.shape
+    B, V, _ = video_feat.shape
+    tmask, vmask = text_mask.float(), video_mask.float()
+    f2f = z2_of = None
+    if self_weight:  # per-video frame-frame table: [B, V, V], tiny next to the text-video slab
+        vf = video_feat.float()
+        F = torch.matmul(vf, vf.transpose(1, 2)) * vmask[:, :, None] * vmask[:, None, :]
+        F = F * (1.0 - torch.eye(V, device=F.device, dtype=F.dtype))[None]
+        f2f, z2_of = F.max(dim=-1)
+    if rows_per_block is None:
+        rows_per_block = max(1, (1 << 28) // max(1, T * B * V))
+    t2v_s, v2t_s = [], []
+    for a0 in range(0, A, rows_per_block):
+        t2v, v2t = _WtiReduce.apply(text_feat[a0:a0 + rows_per_block].contiguous(), video_feat, tmask[a0:a0 + rows_per_block], vmask, f2f, z2_of)
+        tm = tmask[a0:a0 + rows_per_block]
+        if weighted:
+            t2v_s.append((t2v * (tm * text_weight[a0:a0 + rows_per_block].float())[:, None, :]).sum(-1))
+            v2t_s.append((v2t * (vmask * video_weight.float())[None, :, :]).sum(-1))
+        else:
+            t2v_s.append((t2v * (tm / tm.sum(-1, keepdim=True))[:, None, :]).sum(-1))
+            v2t_s.append((v2t * (vmask / vmask.sum(-1, keepdim=True))[None, :, :]).sum(-1))
+    return (torch.cat(t2v_s, 0) + torch.cat(v2t_s, 0)) / 2.0

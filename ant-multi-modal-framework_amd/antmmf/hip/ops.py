@@ -432,3 +432,25 @@ def negnce_bwd(S, diag, lse, coef, row_offset=0, scale=100.0, margin=0.0, out_dt
     _rc(_lib.load().antmmf_negnce_bwd(_p(S), _p(diag), _p(lse), _p(coef), S.shape[0], S.shape[1], row_offset, float(scale), float(margin),
                                       _p(dS), _dt(dS), _stream()), "antmmf_negnce_bwd")
     return dS
+
+
+def wti_reduce_fwd(S, A, T, B, V, tmask, vmask, f2f=None, z2_of=None):
+    """S [A*T, B*V] fp32 -> (t2v [A,B,T], v2t [A,B,V], z1 [A,B,T] int32, tmax [A,B,V] int32); see include/antmmf_hip.h."""
+    _dev_ok(S, tmask, vmask, f2f, z2_of); _c(S, "S"); _f32(S, "S")
+    dev = S.device
+    t2v = torch.empty(A, B, T, dtype=torch.float32, device=dev)
+    v2t = torch.empty(A, B, V, dtype=torch.float32, device=dev)
+    z1 = torch.empty(A, B, T, dtype=torch.int32, device=dev)
+    tmax = torch.empty(A, B, V, dtype=torch.int32, device=dev)
+    _rc(_lib.load().antmmf_wti_reduce_fwd(_p(S), A, T, B, V, _p(tmask), _p(vmask), _p(f2f), _p(z2_of), _p(t2v), _p(v2t), _p(z1), _p(tmax),
+                                          _stream()), "antmmf_wti_reduce_fwd")
+    return t2v, v2t, z1, tmax
+
+
+def wti_reduce_bwd(S, A, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t, out_dtype=torch.bfloat16):
+    _dev_ok(S, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t)
+    dS = torch.empty(S.shape, dtype=out_dtype, device=S.device)
+    df2f = torch.zeros(B, V, dtype=torch.float32, device=S.device) if f2f is not None else None
+    _rc(_lib.load().antmmf_wti_reduce_bwd(_p(S), A, T, B, V, _p(tmask), _p(vmask), _p(f2f), _p(z2_of), _p(z1), _p(tmax), _p(dt2v.contiguous()),
+                                          _p(dv2t.contiguous()), _p(dS), _p(df2f), _dt(dS), _stream()), "antmmf_wti_reduce_bwd")
+    return dS, df2f

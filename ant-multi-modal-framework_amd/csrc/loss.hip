@@ -236,6 +236,92 @@ extern "C" int antmmf_negnce_bwd(const float* S, const float* diag, const float*
     return antmmf_check_launch();
 }
 
+// ---- DMAE weighted token-wise interaction, reduction part (reference: DmaeUtils._get_wti_similarity,
+// prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:85-131).  The reference materialises M[a,b,t,v] = <text_a,t, video_b,v> * masks
+// as a 4-D tensor and reduces it with max / einsum / advanced indexing; here S = text x video^T comes out of the MFMA GEMM as a
+// [A*T, B*V] slab and ONE pass per (a, b) pair produces
+//     t2v[a,b,t] = max_v M  (+ 0.5 * f2f[b,z1] * M[a,b,t,z2_of[b,z1]],  z1 = argmax_v:  the "second best frame" term)
+//     v2t[a,b,v] = max_t M
+// plus the arg-max indices the backward pass routes gradients through.  HBM-bound: S is read once (4 B per (t, v) pair).
+#define WTI_MAXV 32
+__global__ __launch_bounds__(256) void wti_reduce_fwd_kernel(const float* __restrict__ S, int T, int B, int V, const float* __restrict__ tmask,
+                                                             const float* __restrict__ vmask, const float* __restrict__ f2f, const int* __restrict__ z2_of,
+                                                             float* __restrict__ t2v, float* __restrict__ v2t, int* __restrict__ z1_out, int* __restrict__ tmax_out) {
+    const int a = blockIdx.x, b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= B) return;
+    float vm[WTI_MAXV], best_t[WTI_MAXV];
+    int arg_t[WTI_MAXV];
+#pragma unroll 4
+    for (int v = 0; v < V; ++v) { vm[v] = vmask[(long)b * V + v]; best_t[v] = -INFINITY; arg_t[v] = 0; }
+    const long ab = (long)a * B + b;
+    for (int t = 0; t < T; ++t) {
+        const float tm = tmask[(long)a * T + t];
+        const float* row = S + ((long)a * T + t) * ((long)B * V) + (long)b * V;
+        float best = -INFINITY; int arg = 0;
+        for (int v = 0; v < V; ++v) {
+            const float m = row[v] * tm * vm[v];
+            if (m > best) { best = m; arg = v; }           // first maximum, like torch.max
+            if (m > best_t[v]) { best_t[v] = m; arg_t[v] = t; }
+        }
+        float out = best;
+        if (f2f) {
+            const int z2 = z2_of[(long)b * V + arg];
+            out += 0.5f * f2f[(long)b * V + arg] * (row[z2] * tm * vm[z2]);
+        }
+        t2v[ab * T + t] = out;
+        z1_out[ab * T + t] = arg;
+    }
+    for (int v = 0; v < V; ++v) { v2t[ab * V + v] = best_t[v]; tmax_out[ab * V + v] = arg_t[v]; }
+}
+// dS[a*T+t][b*V+v] = tm vm ( [v == z1] dt2v + [v == z2] 0.5 f2f[b,z1] dt2v + [t == tmax[v]] dv2t[v] );  df2f[b,z1] += 0.5 M[t][z2] dt2v
+template <typename TO>
+__global__ __launch_bounds__(256) void wti_reduce_bwd_kernel(const float* __restrict__ S, int T, int B, int V, const float* __restrict__ tmask,
+                                                             const float* __restrict__ vmask, const float* __restrict__ f2f, const int* __restrict__ z2_of,
+                                                             const int* __restrict__ z1_in, const int* __restrict__ tmax_in, const float* __restrict__ dt2v,
+                                                             const float* __restrict__ dv2t, TO* __restrict__ dS, float* __restrict__ df2f) {
+    const int a = blockIdx.x, b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= B) return;
+    const long ab = (long)a * B + b;
+    for (int t = 0; t < T; ++t) {
+        const float tm = tmask[(long)a * T + t];
+        const long ro = ((long)a * T + t) * ((long)B * V) + (long)b * V;
+        const int z1 = z1_in[ab * T + t];
+        const float g = dt2v[ab * T + t];
+        int z2 = -1; float w2 = 0.f;
+        if (f2f) {
+            z2 = z2_of[(long)b * V + z1];
+            w2 = 0.5f * f2f[(long)b * V + z1];
+            if (df2f) atomicAdd(&df2f[(long)b * V + z1], 0.5f * g * (S[ro + z2] * tm * vmask[(long)b * V + z2]));
+        }
+        for (int v = 0; v < V; ++v) {
+            float val = 0.f;
+            if (v == z1) val += g;
+            if (v == z2) val += g * w2;
+            if (tmax_in[ab * V + v] == t) val += dv2t[ab * V + v];
+            st1<TO>(dS + ro + v, val * tm * vmask[(long)b * V + v]);
+        }
+    }
+}
+
+extern "C" int antmmf_wti_reduce_fwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
+                                     const int* z2_of, float* t2v, float* v2t, int* z1, int* tmax, hipStream_t s) {
+    if (!S || !tmask || !vmask || !t2v || !v2t || !z1 || !tmax || A < 0 || B < 0 || T <= 0 || V <= 0 || V > WTI_MAXV || (!f2f) != (!z2_of)) return ANTMMF_EINVAL;
+    if (!A || !B) return ANTMMF_OK;
+    hipLaunchKernelGGL(wti_reduce_fwd_kernel, dim3(A, (B + 255) / 256), dim3(256), 0, s, S, T, B, V, tmask, vmask, f2f, z2_of, t2v, v2t, z1, tmax);
+    return antmmf_check_launch();
+}
+extern "C" int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
+                                     const int* z2_of, const int* z1, const int* tmax, const float* dt2v, const float* dv2t, void* dS, float* df2f,
+                                     int out_dtype, hipStream_t s) {
+    if (!S || !tmask || !vmask || !z1 || !tmax || !dt2v || !dv2t || !dS || A < 0 || B < 0 || T <= 0 || V <= 0 || V > WTI_MAXV || (!f2f) != (!z2_of)) return ANTMMF_EINVAL;
+    if (!A || !B) return ANTMMF_OK;
+    const dim3 grid(A, (B + 255) / 256);
+    if (out_dtype == ANTMMF_BF16) hipLaunchKernelGGL(wti_reduce_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, S, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t, (bf16_t*)dS, df2f);
+    else if (out_dtype == ANTMMF_F32) hipLaunchKernelGGL(wti_reduce_bwd_kernel<float>, grid, dim3(256), 0, s, S, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t, (float*)dS, df2f);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}
+
 extern "C" int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
                                  float* loss_rows, float* denom, hipStream_t s) {
     if (!Rm || !Cm || !loss_rows || !denom || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1 || row_offset < 0 || row_offset + B > Wc) return ANTMMF_EINVAL;

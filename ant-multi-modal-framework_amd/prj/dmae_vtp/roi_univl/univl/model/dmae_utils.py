@@ -1,12 +1,14 @@
 """DMAE retrieval head pieces on the MI355X path (reference: prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py).
 
-Built so far (SURVEY.md section 8a rows T11b and the L5 losses):
+Built:
   * LayerNormDmae / ResidualAttentionBlockDmae / TransformerClip (:574-619) -- CLIP4Clip's temporal transformer: the fused
     HIP transformer layer, kind "clip", LayerNorm eps 1e-12, additive key mask;
   * DmaeUtils._agg_visual_feat (:186-227), meanP and seqTransf;
+  * the weighted token-wise interaction (_get_wti_similarity / wti_interaction / _loose_similarity / get_similarity_logits,
+    :85-184,229-278): split GEMM -> [A*T, B*V] slab -> one fused max / arg-max reduction kernel (antmmf_wti_reduce_*), in blocks of
+    text rows -- the reference's [B_t, B_v, N_t, N_v] einsum tensor (96 GB at B_g = 8192) is never materialised;
   * CrossEn (:528-537) and NegNCE (:539-563) on fused row kernels.
-Not built yet: the WTI token-wise interaction (_get_wti_similarity / wti_interaction, :85-184) and TPM-CL
-(get_partial_similarity, :280-463) raise NotImplementedError."""
+Not built: TPM-CL (get_partial_similarity, :280-463; l3_partial_type > 0 raises NotImplementedError) and wti_arch 2 / 3."""
 from collections import OrderedDict
 
 import torch
@@ -126,5 +128,57 @@ class DmaeUtils(nn.Module):
         idx = torch.arange(0, visual_output.shape[1], expand_times, dtype=torch.long, device=visual_output.device)
         return visual_output[:, idx, :], video_token_mask[:, idx], visual_output_original[:, idx, :]
 
-    def wti_interaction(self, *args, **kwargs):
-        raise NotImplementedError("WTI token-wise interaction: SURVEY.md 8a row L5 (similarity), not built in this round")
+    @staticmethod
+    def _masked_softmax(fc, feat, mask):
+        z = torch.nn.functional.linear(feat.float(), fc.weight.float(), fc.bias.float()).squeeze(2)   # Linear(D, 1): a [*, D] x [D] reduction
+        return torch.softmax(z.masked_fill(mask.float() < 0.5, float("-inf")), dim=-1)
+
+    def _get_wti_similarity(self, text_feat, video_feat, text_mask, video_mask, text_weight=None, video_weight=None, self_weight=False):
+        return contrastive.wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight, video_weight,
+                                          self_weight=self_weight, weighted="wti" in self.interaction)
+
+    def wti_interaction(self, text_feat, word_feat, video_feat, word_mask, video_mask):
+        """text_feat [A, 1, D] sentence embedding, word_feat [A, Nw, D] or None, video_feat [B, V, D]; masks 1 = real.
+        Multi-GPU: the reference all-gathers the five tensors with gradient (:135-146); that is the caller's job here
+        (antmmf.utils.distributed_utils.gather_tensor) so that this function stays a pure [A, B] scorer."""
+        expand_times = video_feat.shape[1] // video_mask.shape[1]
+        video_mask = video_mask.unsqueeze(1).repeat(1, 1, expand_times).view(video_mask.shape[0], -1)
+        text_mask = word_mask
+        if word_mask.shape[1] != text_feat.shape[1]:
+            text_mask = word_mask[:, 0].reshape(text_feat.shape[0], -1)
+        text_weight = word_weight = video_weight = None
+        if "wti" in self.interaction:
+            text_weight = self._masked_softmax(self.text_weight_fc, text_feat, text_mask)
+            if word_feat is not None:
+                word_weight = self._masked_softmax(self.text_weight_fc, word_feat, word_mask)
+            video_weight = self._masked_softmax(self.video_weight_fc, video_feat, video_mask)
+        logits = self._get_wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight, video_weight, self_weight=self.with_va)
+        if self.interaction in ["att_ti", "att_wti"] and word_feat is not None:
+            words = self._get_wti_similarity(word_feat, video_feat, word_mask, video_mask, word_weight, video_weight, self_weight=self.with_va)
+            logits = (logits + words) / 2.0
+        return logits
+
+    def _loose_similarity(self, sequence_output, visual_output, attention_mask, video_mask, sim_header="meanP"):
+        sequence_token_hidden = None
+        if isinstance(sequence_output, tuple):
+            sequence_output, sequence_token_hidden = sequence_output
+        agg, video_token_mask, _ = self._agg_visual_feat(visual_output.contiguous(), video_mask, sim_header=sim_header)
+        if "ti" not in self.interaction:
+            raise NotImplementedError(f"l3_interaction {self.interaction!r}")
+        return self.wti_interaction(sequence_output.contiguous(), sequence_token_hidden, agg, attention_mask, video_token_mask)
+
+    def get_similarity_logits(self, vis_input, cap_input, output_dict=None, shaped=False, loose_type=False):
+        """(simi_matrix [B_t, B_v], margin_loss) of stage 3 (reference :249-278); TPM-CL's margin loss is not built (0)."""
+        cap_embed, cap_mask, text_embed_l1, _, twm_cap_mask = cap_input[:5]
+        visual_embed, visual_mask = vis_input[0], vis_input[1]
+        cap_embed = cap_embed.float() / cap_embed.float().norm(dim=-1, keepdim=True)
+        visual_embed = visual_embed.float() / visual_embed.float().norm(dim=-1, keepdim=True)
+        if twm_cap_mask is not None:
+            cap_mask = twm_cap_mask
+        if not shaped:
+            cap_mask = cap_mask.view(-1, cap_mask.shape[-1])
+            visual_mask = visual_mask.view(-1, visual_mask.shape[-1])
+        if not loose_type:
+            raise NotImplementedError("tight similarity header")
+        simi = self._loose_similarity((text_embed_l1.float().unsqueeze(1), cap_embed), visual_embed, cap_mask, visual_mask, sim_header=self.sim_header)
+        return simi, 0.0

@@ -186,6 +186,16 @@ int antmmf_negnce_fwd(const float* S, const float* diag, int B, int W, int row_o
 /* dS (out_dtype) for loss = coef[0] * sum_i pos_i + coef[1] * sum neg_ij; coef is a 2-float DEVICE array. */
 int antmmf_negnce_bwd(const float* S, const float* diag, const float* lse, const float* coef, int B, int W, int row_offset,
                       float scale, float margin, void* dS, int out_dtype, antmmf_stream_t stream);
+/* ---- DMAE weighted token-wise interaction, reduction over one S = text x video^T slab (DmaeUtils._get_wti_similarity,
+ * prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:85-131).  S [A*T, B*V] fp32 (row a*T+t, column b*V+v), masks tmask [A,T] /
+ * vmask [B,V] (1 = real), optional second-best-frame tables f2f [B,V] (max masked frame-frame similarity) and z2_of [B,V] (its
+ * arg-max) -- both or neither.  Outputs t2v [A,B,T], v2t [A,B,V] and the arg-max indices z1 [A,B,T], tmax [A,B,V].  V <= 32. */
+int antmmf_wti_reduce_fwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
+                          const int* z2_of, float* t2v, float* v2t, int* z1, int* tmax, antmmf_stream_t stream);
+/* dS (out_dtype, fully written) from dt2v / dv2t; df2f [B,V] (nullable) is accumulated with atomics (caller zeroes it). */
+int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
+                          const int* z2_of, const int* z1, const int* tmax, const float* dt2v, const float* dv2t, void* dS,
+                          float* df2f, int out_dtype, antmmf_stream_t stream);
 /* ---- momentum update of a MoCo key tower laid out flat: k = m k + (1 - m) q, k_shadow_bf16 (nullable) = bf16(k).
  * Replaces momentum_update_key_encoder's per-parameter loop (moco_utils.py:55-69). */
 int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, float m, antmmf_stream_t stream);

@@ -14,6 +14,7 @@ Fixtures and the reference symbols that produced them:
   loss_mil_nce.pt      get_mil_nce_loss                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
   ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
+  ops_dmae_wti.pt      DmaeUtils.wti_interaction (wti / att_wti, with and without the 2nd-frame term)   dmae_utils.py:85-184
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
                        reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
@@ -131,6 +132,36 @@ def gen_dmae_seqtransf():
             d[k.replace("grad.", "gnorm.", 1)] = g_.norm()
             d[k.replace("grad.", "gprobe.", 1)] = g_.flatten()[:64].clone()
     save("ops_dmae_seqtransf.pt", d)
+
+
+def gen_dmae_wti():
+    vtp = L.load_vtp("dmae_vtp")
+    d = {}
+    A = B = 4
+    Nw, V, D = 6, 5, 128
+    nrm = torch.nn.functional.normalize
+    text = nrm(W.data_tensor("wti.text", (A, 1, D)), dim=-1)
+    word = nrm(W.data_tensor("wti.word", (A, Nw, D)), dim=-1)
+    video = nrm(W.data_tensor("wti.video", (B, V, D)), dim=-1)
+    wlen, vlen = torch.tensor([6, 4, 2, 5]), torch.tensor([5, 3, 4, 1])
+    word_mask = (torch.arange(Nw)[None, :] < wlen[:, None]).float()
+    video_mask = (torch.arange(V)[None, :] < vlen[:, None]).float()
+    gw = W.data_tensor("wti.g", (A, B))
+    d.update(dict(text=text, word=word, video=video, word_mask=word_mask, video_mask=video_mask, g=gw))
+    for inter in ("wti", "att_wti"):
+        for va in (True, False):
+            du = vtp["dmae"].DmaeUtils(L.AttrDict(dict(DMAE_CFG, l3_interaction=inter, l3_with_nfc=va, l3_sim_header="meanP")))
+            W.fill_module_(du)
+            du.train()
+            t, w_, v = (x.clone().requires_grad_(True) for x in (text, word, video))
+            out = du.wti_interaction(t, w_, v, word_mask.clone(), video_mask.clone())
+            (out * gw).sum().backward()
+            tag = f"{inter}.va{int(va)}"
+            d.update({f"{tag}.out": out, f"{tag}.dtext": t.grad, f"{tag}.dvideo": v.grad,
+                      f"{tag}.dword": w_.grad if w_.grad is not None else torch.zeros_like(word)})
+            for k, g_ in grads_of(du).items():
+                d[f"{tag}.{k}"] = g_
+    save("ops_dmae_wti.pt", d)
 
 
 def gen_losses():
@@ -391,8 +422,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(dmae_seqtransf=gen_dmae_seqtransf, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -301,6 +301,38 @@ def case_dmae_seqtransf(dev, golden):
     return dict(checked=n)
 
 
+def case_dmae_wti(dev, golden):
+    """DmaeUtils.wti_interaction on the HIP path (split GEMM + fused reduction kernel) vs the reference run: wti / att_wti, with and
+    without the second-best-frame term, forward + gradients of the features and of the weight heads."""
+    from antmmf.common.configuration import Configuration
+
+    g = golden("ops_dmae_wti.pt")
+    mod = load_dmae_utils()
+    res = {}
+    for inter in ("wti", "att_wti"):
+        for va in (True, False):
+            tag = f"{inter}.va{int(va)}"
+            du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction=inter, l3_with_nfc=va, l3_sim_header="meanP")))
+            W.fill_module_(du)
+            du = du.to(dev).train()
+            t, w_, v = (g[k].to(dev).clone().requires_grad_(True) for k in ("text", "word", "video"))
+            out = du.wti_interaction(t, w_, v, g["word_mask"].to(dev), g["video_mask"].to(dev))
+            check(f"{tag}.out", out, g[f"{tag}.out"], 1e-3, 1e-3)
+            (out * g["g"].to(dev)).sum().backward()
+            check(f"{tag}.dtext", t.grad, g[f"{tag}.dtext"], 2e-2, 2e-2)    # bf16 slab gradient through the two GEMMs back
+            check(f"{tag}.dvideo", v.grad, g[f"{tag}.dvideo"], 2e-2, 2e-2)
+            if inter == "att_wti":
+                check(f"{tag}.dword", w_.grad, g[f"{tag}.dword"], 2e-2, 2e-2)
+            for n, p in du.named_parameters():
+                if f"{tag}.grad.{n}" in g and p.grad is not None:
+                    if float(g[f"{tag}.grad.{n}"].abs().max()) < 1e-6:   # bias of a softmax-fed Linear: analytically zero gradient
+                        assert float(p.grad.abs().max()) < 1e-5
+                        continue
+                    check(f"{tag}.grad.{n}", p.grad, g[f"{tag}.grad.{n}"], 1e-2, 1e-2)
+            res[tag] = float(out.sum())
+    return res
+
+
 # ------------------------------------------------------------------------------ M2
 M2_PRJ = os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder")
 if M2_PRJ not in sys.path:

@@ -69,6 +69,10 @@ def test_univl_stage2_hard_mining_vs_oracle(golden):
     print(mc.case_univl_stage2(torch.device("cpu"), golden, mining=True))
 
 
+def test_dmae_wti_vs_reference(golden):
+    print(mc.case_dmae_wti(torch.device("cpu"), golden))
+
+
 def test_temporal_head_vs_oracle():
     print(mc.case_temporal_head(torch.device("cpu")))
 

@@ -171,6 +171,31 @@ def test_e2e_clip_stage2(golden):
     assert checked > 55
 
 
+def test_dmae_wti(golden):
+    """DmaeUtils.wti_interaction: wti / att_wti, with and without the second-best-frame term, forward and all gradients."""
+    import weightgen as W
+
+    g = golden("ops_dmae_wti.pt")
+    shapes = {"text_weight_fc.weight": (1, 128), "text_weight_fc.bias": (1,), "video_weight_fc.weight": (1, 128), "video_weight_fc.bias": (1,)}
+    for inter in ("wti", "att_wti"):
+        for va in (True, False):
+            tag = f"{inter}.va{int(va)}"
+            P = W.fill_dict(shapes)
+            for v in P.values():
+                v.requires_grad_(True)
+            t, w_, v = (g[k].clone().requires_grad_(True) for k in ("text", "word", "video"))
+            out = losses.dmae_wti_interaction(P, t, w_, v, g["word_mask"], g["video_mask"], inter, va)
+            close(out, g[f"{tag}.out"], 1e-5, 1e-6)
+            (out * g["g"]).sum().backward()
+            close(t.grad, g[f"{tag}.dtext"], 1e-4, 1e-6)
+            close(v.grad, g[f"{tag}.dvideo"], 1e-4, 1e-6)
+            if inter == "att_wti":
+                close(w_.grad, g[f"{tag}.dword"], 1e-4, 1e-6)
+            for n in shapes:
+                if f"{tag}.grad.{n}" in g:
+                    close(P[n].grad, g[f"{tag}.grad.{n}"], 1e-4, 1e-6)
+
+
 def moco_queue(name, dim, K):
     import weightgen as W
 
