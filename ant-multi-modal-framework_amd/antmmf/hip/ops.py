@@ -449,8 +449,9 @@ def wti_reduce_fwd(S, A, T, B, V, tmask, vmask, f2f=None, z2_of=None):
 
 def wti_reduce_bwd(S, A, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t, out_dtype=torch.bfloat16):
     _dev_ok(S, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t)
+    dt2v, dv2t = dt2v.float().contiguous(), dv2t.float().contiguous()  # bound to locals: the launch reads them after this line
     dS = torch.empty(S.shape, dtype=out_dtype, device=S.device)
     df2f = torch.zeros(B, V, dtype=torch.float32, device=S.device) if f2f is not None else None
-    _rc(_lib.load().antmmf_wti_reduce_bwd(_p(S), A, T, B, V, _p(tmask), _p(vmask), _p(f2f), _p(z2_of), _p(z1), _p(tmax), _p(dt2v.contiguous()),
-                                          _p(dv2t.contiguous()), _p(dS), _p(df2f), _dt(dS), _stream()), "antmmf_wti_reduce_bwd")
+    _rc(_lib.load().antmmf_wti_reduce_bwd(_p(S), A, T, B, V, _p(tmask), _p(vmask), _p(f2f), _p(z2_of), _p(z1), _p(tmax), _p(dt2v),
+                                          _p(dv2t), _p(dS), _p(df2f), _dt(dS), _stream()), "antmmf_wti_reduce_bwd")
     return dS, df2f

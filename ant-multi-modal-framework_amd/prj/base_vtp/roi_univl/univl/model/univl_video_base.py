@@ -108,13 +108,14 @@ class UnivlVideoBase(nn.Module):
         text = self.forward_text_encoder(caption_input["caption_raw_input_ids"], caption_input["caption_input_mask"])
         n_clips = visual["visual_embed"].shape[1]
         batch_size = text["pooled_output"].shape[0]
-        if self.with_cross_encoder:
+        twm_input_mask = caption_input.get("caption_twm_input_mask")  # DMAE's token-weighting mask (dmae_vtp :293-300), usually absent
+        if self.with_cross_encoder or getattr(self, "need_cross_inputs", False):
             cap_embed, visual_embed, cap_mask, visual_mask, n_clips, batch_size = self.build_transformer_input(visual, text, caption_input)
-            cap_input = (cap_embed, cap_mask, text["pooled_output"], batch_size)
+            cap_input = (cap_embed, cap_mask, text["pooled_output"], batch_size, twm_input_mask)
             vis_input = (visual_embed, visual_mask, visual["clip_feature"], n_clips)
         else:
-            # (cap_embed, cap_mask) / (visual_embed, visual_mask) feed only the stage-2 cross encoder; stage 1 carries None
-            cap_input = (None, caption_input["caption_input_mask"], text["pooled_output"], batch_size)
+            # (cap_embed, cap_mask) / (visual_embed, visual_mask) feed only the stage-2 / stage-3 heads; stage 1 carries None
+            cap_input = (None, caption_input["caption_input_mask"], text["pooled_output"], batch_size, twm_input_mask)
             vis_input = (visual["visual_embed"], visual["visual_mask"], visual["clip_feature"], n_clips)
         return cap_input, vis_input, text, visual
 

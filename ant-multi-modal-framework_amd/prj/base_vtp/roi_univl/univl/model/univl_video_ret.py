@@ -32,6 +32,17 @@ class UnivlForVideoTextRetrieval(nn.Module):
             self.dropout = nn.Dropout(0.1)
             self.similarity_dense = nn.Sequential(nn.Linear(self.config.hidden_size, self.config.hidden_size * 2), nn.ReLU(True),
                                                   nn.Linear(self.config.hidden_size * 2, 1))
+        if "stage3" in self.config.training_stage:
+            # DMAE head (reference: prj/dmae_vtp/roi_univl/univl/model/univl_video_ret.py:35-42,457-476); lives in the dmae_vtp overlay
+            try:
+                from .dmae_utils import CrossEn, DmaeUtils, NegNCE
+            except ImportError as e:
+                raise ImportError("training_stage with stage3 is the dmae_vtp project: put prj/dmae_vtp (not prj/base_vtp) on sys.path") from e
+            self.module.need_cross_inputs = True
+            self.dmae_utils = DmaeUtils(config)
+            self.loss_type = self.config.get("l3_loss_type", "negNCE")
+            assert self.loss_type in ["cross_entropy", "negNCE"]
+            self.loss_fct = NegNCE() if self.loss_type == "negNCE" else CrossEn()
         self.pair_chunk_rows = int(self.config.get("cross_chunk_rows", 5))  # caption rows per cross-encoder call (reference: 5)
         self.with_moco = bool(self.config.get("with_moco", True))
         self.moco_utils = None  # built lazily at the first training step, as in the reference (:263-268)
@@ -168,12 +179,26 @@ class UnivlForVideoTextRetrieval(nn.Module):
         output_dict["l2_simi"] = self.reduce_clips(l2_simi, "l2")
         return output_dict
 
+    def forward_stage3(self, vis_input, cap_input, output_dict=None, cal_cross=True):
+        """DMAE cross-modal retrieval head: token-wise interaction scores [T, V] -> CrossEn / NegNCE in both directions."""
+        output_dict = dict(losses={}) if output_dict is None else output_dict
+        l3_simi, margin_loss = self.dmae_utils.get_similarity_logits(vis_input, cap_input, shaped=True, loose_type=True)
+        if cal_cross and l3_simi.size(0) == l3_simi.size(1):
+            loss = (self.loss_fct(l3_simi) + self.loss_fct(l3_simi.t())) / 2
+        else:
+            loss = l3_simi.new_tensor(0.0)
+        output_dict["losses"]["level3_similarity_loss"] = loss + margin_loss
+        output_dict["l3_simi"] = self.reduce_clips(l3_simi, "l2")
+        return output_dict
+
     def forward_stage(self, cap_input, vis_input, cal_cross=True):
         output_dict = None
         if "stage1" in self.config.training_stage:
             output_dict = self.forward_stage1(vis_input, cap_input, output_dict, cal_cross=cal_cross)
         if "stage2" in self.config.training_stage:
             output_dict = self.forward_stage2(vis_input, cap_input, output_dict, cal_cross=cal_cross)
+        if "stage3" in self.config.training_stage:
+            output_dict = self.forward_stage3(vis_input, cap_input, output_dict, cal_cross=cal_cross)
         return output_dict
 
     def forward(self, img_input, caption_input, ocr_input=None, region_input=None, caption_output=None, sample_list=None):

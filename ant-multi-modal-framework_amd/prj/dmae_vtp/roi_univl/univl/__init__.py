@@ -1,1 +1,3 @@
-"""dmae_vtp (MI355X path): DMAE retrieval pieces of SURVEY.md section 8a (T11b, L5)."""
+import os
+
+__path__.append(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "..", "base_vtp", "roi_univl", "univl")))

@@ -96,6 +96,35 @@ def univl_stage2(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch
     return dict(l2_simi=l2, loss=losses.mil_nce(l2, b, 1, weight))
 
 
+def dmae_stage3(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch, bert_heads, loss_type="negNCE", interaction="wti",
+                with_va=True, sim_header="meanP", sim_layers=2):
+    """DMAE stage-3 head on the clip-arch towers (prj/dmae_vtp/roi_univl/univl/model/univl_video_ret.py:457-476;
+    dmae_utils.py:249-278,229-247,133-184), single process, l3_partial_type -1.
+    Word features = BertEmbeddings(ids) (the EMBEDDING layer output, univl_video_base.py:168-176), frame features =
+    BertEmbeddings(inputs_embeds=[clip tokens ; word_emb[102]], type 1) (:178-204), both L2-normalised per token; sentence feature
+    = the stage-1 pooled text embedding; optional seqTransf aggregation; token-wise interaction -> [T, V]; loss in both directions."""
+    b = image_data.shape[0]
+    frames_per_clip = image_data.shape[1] // n_clips
+    Pt = towers._sub(P, "module.text_encoder.")
+    Pe = towers._sub(Pt, "embeddings.")
+    vis = towers.clip_vit(towers._sub(P, "module.img_encoder.visual."), image_data.flatten(0, 1), vit_heads, patch)
+    clip_tokens = vis.view(b * n_clips, frames_per_clip, -1).mean(1).view(b, n_clips, -1)
+    cap_embed = towers.bert_embeddings(Pe, input_ids=input_ids)
+    sep = Pe["word_embeddings.weight"][torch.full((b,), 102)].unsqueeze(1)
+    vis_in = torch.cat([clip_tokens, sep], 1)
+    vis_embed = towers.bert_embeddings(Pe, inputs_embeds=vis_in, token_type_ids=torch.ones(vis_in.shape[:2], dtype=torch.long))
+    vis_mask = torch.ones(b, n_clips + 1)
+    _, pooled = towers.roberta_bert_encoder(Pt, input_ids, input_mask, bert_heads)
+    text_l1 = ops.l2_normalize(pooled).unsqueeze(1)
+    cap_embed = cap_embed / cap_embed.norm(dim=-1, keepdim=True)
+    vis_embed = vis_embed / vis_embed.norm(dim=-1, keepdim=True)
+    Pd = towers._sub(P, "dmae_utils.")
+    agg, tok_mask, _ = towers.dmae_agg_visual_feat(Pd, vis_embed, vis_mask, heads=vis_embed.shape[-1] // 64, layers=sim_layers, sim_header=sim_header)
+    simi = losses.dmae_wti_interaction(Pd, text_l1, cap_embed, agg, input_mask.float(), tok_mask, interaction, with_va)
+    fn = losses.neg_nce if loss_type == "negNCE" else losses.cross_en
+    return dict(l3_simi=simi, loss=(fn(simi) + fn(simi.t())) / 2)
+
+
 def m2_itc(P, image, text_ids, text_masks, heads, patch, gather=None):
     """M2 two-level ITC step: towers pinned by VLMo.infer_image/infer_text, logits formula from
     prj/M2_Encoder/m2_encoder.py:92-95, symmetric CE on both the cls and the cls_vlffn pairs

@@ -18,6 +18,7 @@ Fixtures and the reference symbols that produced them:
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
                        reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
+  e2e_dmae_stage3.pt   dmae_vtp UnivlForVideoTextRetrieval, stage1+stage3 (seqTransf + WTI + NegNCE / CrossEn)   prj/dmae_vtp/.../univl_video_ret.py:457-476
   e2e_clip_moco.pt     same model, with_moco: true (K=64, M=0.5): 2 steps   univl_video_ret.py:262-312, moco_utils.py:13-107
   e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
   gather_w2.pt         gather_tensor(back_gradient=True)  antmmf/utils/distributed_utils.py:92-189 (2-proc gloo)
@@ -285,6 +286,33 @@ def gen_e2e_clip_stage2():
     save("e2e_clip_stage2.pt", d)
 
 
+DMAE_E2E = dict(l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="meanP", l3_partial_type=-1, l3_max_frames=4,
+                l3_max_words=12, l3_sim_header_hidden_layer=2)
+
+
+def gen_e2e_dmae_stage3():
+    vtp = L.load_vtp("dmae_vtp")
+    d = {}
+    bsz, n_clips = 4, 4
+    batch = tiny_clip_batch(bsz, n_clips, tag="s3")
+    d.update({"s3.image_data": batch["image"]["image_data"], "s3.input_ids": batch["caption"]["caption_input_ids"],
+              "s3.input_mask": batch["caption"]["caption_input_mask"]})
+    for loss_type in ("negNCE", "cross_entropy"):
+        cfg = dict(TINY_CLIP_CFG, training_stage="stage1+stage3", l3_loss_type=loss_type, **DMAE_E2E)
+        model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
+        W.fill_module_(model)
+        model.train()
+        out = model(batch["image"], batch["caption"])
+        loss = out["losses"]["level1_similarity_loss"] + out["losses"]["level3_similarity_loss"]
+        loss.backward()
+        d.update({f"s3.{loss_type}.loss1": out["losses"]["level1_similarity_loss"], f"s3.{loss_type}.loss3": out["losses"]["level3_similarity_loss"],
+                  f"s3.{loss_type}.l3_simi": out["l3_simi"]})
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                d[f"s3.{loss_type}.gnorm.{n}"] = p.grad.norm()
+    save("e2e_dmae_stage3.pt", d)
+
+
 def moco_queue(name, dim, K):
     return torch.nn.functional.normalize(W.data_tensor(name, (dim, K)), dim=0)
 
@@ -422,8 +450,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_clip_moco", "e2e_m2", "gather"]
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
     fns = dict(dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
-               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_m2=gen_e2e_m2, gather=gen_gather)
+               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -58,8 +58,12 @@ def clip_arch_shapes(c=CLIP_ARCH):
     return s
 
 
-def clip_arch_params(requires_grad=False, stage2=False):
+def clip_arch_params(requires_grad=False, stage2=False, dmae=False):
     shapes = clip_arch_shapes()
+    if dmae:  # DmaeUtils' weight heads (dmae_utils.py:36-38), meanP header
+        h = CLIP_ARCH["hidden"]
+        shapes.update({"dmae_utils.text_weight_fc.weight": (1, h), "dmae_utils.text_weight_fc.bias": (1,),
+                       "dmae_utils.video_weight_fc.weight": (1, h), "dmae_utils.video_weight_fc.bias": (1,)})
     if stage2:  # similarity_dense of the stage-2 head (univl_video_ret.py:23-29)
         h = CLIP_ARCH["hidden"]
         shapes.update({"similarity_dense.0.weight": (2 * h, h), "similarity_dense.0.bias": (2 * h,),

@@ -69,6 +69,18 @@ def test_univl_stage2_hard_mining_vs_oracle(golden):
     print(mc.case_univl_stage2(torch.device("cpu"), golden, mining=True))
 
 
+@SLOW
+@pytest.mark.parametrize("loss_type", ["negNCE", "cross_entropy"])
+def test_dmae_stage3_vs_reference(loss_type):
+    import subprocess
+    import sys
+
+    code = mc.case_dmae_stage3() % (mc.ROOT, "cpu", loss_type, mc.TINY_CLIP_CFG, mc.DMAE_E2E)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=dict(os.environ))
+    assert "okdmae" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    print(out.stdout[-400:])
+
+
 def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(torch.device("cpu"), golden))
 

@@ -196,6 +196,28 @@ def test_dmae_wti(golden):
                     close(P[n].grad, g[f"{tag}.grad.{n}"], 1e-4, 1e-6)
 
 
+def test_e2e_dmae_stage3(golden):
+    """dmae_vtp stage1 + stage3 (WTI scores, NegNCE / CrossEn both directions) vs the reference run."""
+    import tiny_models
+
+    g = golden("e2e_dmae_stage3.pt")
+    for loss_type in ("negNCE", "cross_entropy"):
+        P = tiny_models.clip_arch_params(requires_grad=True, dmae=True)
+        args = (g["s3.image_data"], g["s3.input_ids"], g["s3.input_mask"], 4)
+        o1 = step.univl_stage1(P, *args, vit_heads=2, patch=8, bert_heads=2)
+        o3 = step.dmae_stage3(P, *args, vit_heads=2, patch=8, bert_heads=2, loss_type=loss_type)
+        close(o1["loss"], g[f"s3.{loss_type}.loss1"], 1e-5, 1e-6)
+        close(o3["l3_simi"], g[f"s3.{loss_type}.l3_simi"], 1e-4, 1e-6)
+        close(o3["loss"], g[f"s3.{loss_type}.loss3"], 1e-4, 1e-5)
+        (o1["loss"] + o3["loss"]).backward()
+        checked = 0
+        for n, p in P.items():
+            if f"s3.{loss_type}.gnorm.{n}" in g and p.grad is not None:
+                close(p.grad.norm(), g[f"s3.{loss_type}.gnorm.{n}"], 3e-3, 1e-6)
+                checked += 1
+        assert checked > 55
+
+
 def moco_queue(name, dim, K):
     import weightgen as W
 
