@@ -282,7 +282,7 @@ def case_dmae_seqtransf(dev, golden):
     du = load_dmae_utils().DmaeUtils(Configuration(DMAE_CFG))
     W.fill_module_(du)
     du = du.to(dev)
-    x = g["visual"].to(dev).requires_grad_(True)
+    x = g["visual"].detach().clone().to(dev).requires_grad_(True)   # (never flag the cached fixture tensor itself)
     out, tok_mask, orig = du._agg_visual_feat(x, g["mask"].to(dev), "seqTransf")
     check("dmae.out", out, g["out"], 5e-2, 3e-2)
     check("dmae.tok_mask", tok_mask, g["tok_mask"], 0, 0)

@@ -93,5 +93,6 @@ def test_dmae_seqtransf_vs_reference(golden):
     print(mc.case_dmae_seqtransf(torch.device("cpu"), golden))
 
 
+@SLOW
 def test_m2_itc_step_vs_oracle():
     print(mc.case_m2_itc_vs_oracle(torch.device("cpu")))
