@@ -51,6 +51,7 @@ _SIGNATURES = {
     "antmmf_ema_update": [P, P, P, L, F, P],
     "antmmf_wti_reduce_fwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "antmmf_wti_reduce_bwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
+    "antmmf_rank_rows": [P, L, I, I, P, P, P, P],
     "antmmf_negnce_fwd": [P, P, I, I, I, F, F, P, P, P, P, P],
     "antmmf_negnce_bwd": [P, P, P, P, I, I, I, F, F, P, I, P],
 }

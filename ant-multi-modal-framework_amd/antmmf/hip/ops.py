@@ -455,3 +455,14 @@ def wti_reduce_bwd(S, A, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t
     _rc(_lib.load().antmmf_wti_reduce_bwd(_p(S), A, T, B, V, _p(tmask), _p(vmask), _p(f2f), _p(z2_of), _p(z1), _p(tmax), _p(dt2v),
                                           _p(dv2t), _p(dS), _p(df2f), _dt(dS), _stream()), "antmmf_wti_reduce_bwd")
     return dS, df2f
+
+
+def rank_rows(S, gt_off, gt_idx):
+    """rank [rows] int32: position (0 = first) of the best ground-truth column of every row of S [rows, cols] fp32;
+    gt_off [rows + 1] / gt_idx int32 list the ground-truth columns of each row (CSR)."""
+    _dev_ok(S, gt_off, gt_idx); _f32(S, "S")
+    if S.dim() != 2 or S.stride(1) != 1:
+        raise ValueError("rank_rows: S must be 2-D with unit inner stride")
+    rank = torch.empty(S.shape[0], dtype=torch.int32, device=S.device)
+    _rc(_lib.load().antmmf_rank_rows(_p(S), S.stride(0), S.shape[0], S.shape[1], _p(gt_off), _p(gt_idx), _p(rank), _stream()), "antmmf_rank_rows")
+    return rank

@@ -322,6 +322,31 @@ extern "C" int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V,
     return antmmf_check_launch();
 }
 
+// ---- retrieval evaluation: rank of the ground truth in every row of a similarity matrix (reference: np.argsort(-sim) + a Python
+// loop per row, antmmf/modules/metrics/global_retrieval_recall.py:13-89).  rank[i] = min over the row's ground-truth columns g of
+// #{ j : S[i][j] > S[i][g] }  (0 = retrieved first).  HBM-bound: one pass over the row per ground-truth id.
+__global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict__ S, long ld, int cols, const int* __restrict__ gt_off,
+                                                        const int* __restrict__ gt_idx, int* __restrict__ rank) {
+    __shared__ float shf[4];
+    const int i = blockIdx.x;
+    const float* r = S + (long)i * ld;
+    int best = cols;
+    for (int g = gt_off[i]; g < gt_off[i + 1]; ++g) {
+        const float thr = r[gt_idx[g]];
+        float c = 0.f;
+        for (int j = threadIdx.x; j < cols; j += 256) c += r[j] > thr ? 1.f : 0.f;
+        const int cnt = (int)block_sum(c, shf);
+        best = cnt < best ? cnt : best;
+    }
+    if (threadIdx.x == 0) rank[i] = best;
+}
+extern "C" int antmmf_rank_rows(const float* S, long ld, int rows, int cols, const int* gt_off, const int* gt_idx, int* rank, hipStream_t s) {
+    if (!S || !gt_off || !gt_idx || !rank || rows < 0 || cols <= 0 || ld < cols) return ANTMMF_EINVAL;
+    if (!rows) return ANTMMF_OK;
+    hipLaunchKernelGGL(rank_rows_kernel, dim3(rows), dim3(256), 0, s, S, ld, cols, gt_off, gt_idx, rank);
+    return antmmf_check_launch();
+}
+
 extern "C" int antmmf_milnce_fwd(const float* Rm, const float* Cm, int B, int Wr, int Wc, int n_pair, int row_offset,
                                  float* loss_rows, float* denom, hipStream_t s) {
     if (!Rm || !Cm || !loss_rows || !denom || B < 0 || Wr <= 0 || Wc <= 0 || n_pair < 1 || row_offset < 0 || row_offset + B > Wc) return ANTMMF_EINVAL;

@@ -196,6 +196,10 @@ int antmmf_wti_reduce_fwd(const float* S, int A, int T, int B, int V, const floa
 int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
                           const int* z2_of, const int* z1, const int* tmax, const float* dt2v, const float* dv2t, void* dS,
                           float* df2f, int out_dtype, antmmf_stream_t stream);
+/* ---- retrieval evaluation (antmmf/modules/metrics/global_retrieval_recall.py:13-89): rank[i] = min over the ground-truth columns
+ * gt_idx[gt_off[i] .. gt_off[i+1]) of #{ j : S[i][j] > S[i][g] } (0 = first).  S fp32 [rows, cols] with row stride ld. */
+int antmmf_rank_rows(const float* S, int64_t ld, int rows, int cols, const int* gt_off, const int* gt_idx, int* rank,
+                     antmmf_stream_t stream);
 /* ---- momentum update of a MoCo key tower laid out flat: k = m k + (1 - m) q, k_shadow_bf16 (nullable) = bf16(k).
  * Replaces momentum_update_key_encoder's per-parameter loop (moco_utils.py:55-69). */
 int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, float m, antmmf_stream_t stream);

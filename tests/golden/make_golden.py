@@ -15,6 +15,7 @@ Fixtures and the reference symbols that produced them:
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
   ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
   ops_dmae_wti.pt      DmaeUtils.wti_interaction (wti / att_wti, with and without the 2nd-frame term)   dmae_utils.py:85-184
+  metric_recall.pt     _cal_recall / _cal_sym_recall (retrieval evaluation)   antmmf/modules/metrics/global_retrieval_recall.py:13-103
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
                        reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
@@ -163,6 +164,31 @@ def gen_dmae_wti():
             for k, g_ in grads_of(du).items():
                 d[f"{tag}.{k}"] = g_
     save("ops_dmae_wti.pt", d)
+
+
+def gen_metric_recall():
+    import importlib
+    import types
+
+    L.load_antmmf_core()
+    reg = types.ModuleType("antmmf.common.registry")
+    reg.registry = types.SimpleNamespace(register_metric=lambda name: (lambda c: c))
+    sys.modules["antmmf.common.registry"] = reg
+    L._pkg("antmmf.modules.metrics", f"{L.REF}/antmmf/modules/metrics")
+    m = importlib.import_module("antmmf.modules.metrics.global_retrieval_recall")
+    d = {}
+    sq = W.data_tensor("metric.square", (23, 23))
+    for k, v in m._cal_recall(sq).items():
+        d["sq." + k] = torch.tensor(float(v), dtype=torch.float64)
+    d["sq.sim"] = sq
+    T, V = 17, 11                                   # 17 captions, 11 videos, several captions per video
+    sim = W.data_tensor("metric.rect", (T, V))
+    t2v = [[i % V] for i in range(T)]
+    v2t = [[i for i in range(T) if i % V == j] for j in range(V)]
+    for k, v in m._cal_sym_recall(sim.numpy(), t2v, v2t).items():
+        d["rect." + k] = torch.tensor(float(v), dtype=torch.float64)
+    d["rect.sim"] = sim
+    save("metric_recall.pt", d)
 
 
 def gen_losses():
@@ -450,8 +476,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "metric_recall", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -438,3 +438,27 @@ def case_dmae_losses(contrastive, dev, B=9):
             got.backward()
             check(f"dmae.{name}.loss", got, ref.detach(), 1e-4, 1e-5)
             check(f"dmae.{name}.grad", Sd.grad, S.grad, 2e-3, 1e-4)
+
+
+def case_retrieval_metrics(dev, golden):
+    """GlobalRetrievalRecall's rank kernel + reductions vs the reference metric run (metric_recall.pt): square matrix with the
+    diagonal as ground truth, and a 17 x 11 matrix with explicit (multi-)ground-truth lists in both directions."""
+    from antmmf.modules.metrics import global_retrieval_recall as grr
+
+    g = golden("metric_recall.pt")
+    got = grr._cal_recall(g["sq.sim"].to(dev))
+    for k in ("mr", "r@1", "r@5", "r@10"):
+        assert abs(got[k] - float(g["sq." + k])) < 1e-6, (k, got[k], float(g["sq." + k]))
+    T, V = g["rect.sim"].shape
+    t2v = [[i % V] for i in range(T)]
+    v2t = [[i for i in range(T) if i % V == j] for j in range(V)]
+    got = grr._cal_sym_recall(g["rect.sim"].to(dev), t2v, v2t)
+    for k, v in got.items():
+        assert abs(v - float(g["rect." + k])) < 1e-6, (k, v, float(g["rect." + k]))
+    m = grr.GlobalRetrievalRecall(simi_logit_key=["l1_simi"])
+    out = m.calculate(None, {"l1_simi": g["sq.sim"].to(dev)})
+    assert abs(float(out["l1_simi_r@10"]) - float(g["sq.r@10"])) < 1e-6
+    m.collect(None, {"l1_simi": g["rect.sim"][:9].to(dev)}, 0, 0, t2v=t2v[:9], v2t=v2t)
+    m.collect(None, {"l1_simi": g["rect.sim"][9:].to(dev)}, 1, 0, t2v=t2v[9:])
+    summ = m.summarize()
+    assert abs(float(summ["l1_simi_t2v-mr"]) - float(g["rect.t2v-mr"])) < 1e-6 and abs(float(summ["l1_simi_v2t-r@5"]) - float(g["rect.v2t-r@5"])) < 1e-6
