@@ -10,6 +10,8 @@ prj/M2_Encoder/m2_encoder.py:92-95) on both the `cls_feats` and `cls_vlffn_feats
 over RCCL and the loss row-sharded (antmmf.hip.contrastive).  Tokeniser, transforms, checkpoint conversion and the
 Lightning plumbing are outside the step path.
 """
+import math
+
 import numpy as np
 import torch
 from torch import nn
@@ -19,6 +21,54 @@ from antmmf.hip import functional as HF
 from . import heads
 from .modeling_utils import BEiT3, get_config
 from ..torchscale.architecture.encoder import Encoder
+
+
+def _resize_pos_embed(value, n_special, num_visual_token):
+    """Area-interpolate the square patch grid of a position table to sqrt(num_visual_token - 1)^2 cells; the first `n_special`
+    rows (cls / special positions) are kept."""
+    n_old = value.shape[0] - n_special
+    dim = value.shape[-1]
+    side_old, side_new = int(math.sqrt(n_old)), int(math.sqrt(num_visual_token - 1))
+    special, patch = value[:n_special], value[n_special:].float()
+    patch = nn.functional.interpolate(patch.reshape(1, side_old, side_old, dim).permute(0, 3, 1, 2), size=(side_new, side_new), mode="area")
+    patch = patch.to(special.dtype).permute(0, 2, 3, 1).reshape(-1, dim)
+    return torch.cat((special, patch), dim=0)
+
+
+def convert_pl_ckpt(state_dict, num_visual_token=197):
+    """Lightning checkpoint -> this model (reference vlmo_module.py:22-56): drop the visual tokenizer, and bring
+    backbone.encoder.embed_positions.A.weight (3 special rows + patch grid) to `num_visual_token + 2` rows -- area interpolation of
+    the grid when the checkpoint has fewer rows, truncation when it has more."""
+    new_state_dict = {}
+    for key, value in state_dict.items():
+        if "visual_tokenizer" in key:
+            continue
+        if "backbone.encoder.embed_positions.A.weight" in key:
+            if value.shape[0] < num_visual_token + 2:
+                value = _resize_pos_embed(value, 3, num_visual_token)
+            elif value.shape[0] > num_visual_token + 2:
+                value = value[:num_visual_token + 2, :]
+        new_state_dict[key] = value
+    return new_state_dict
+
+
+def convert_deepspeed_ckpt(state_dict, num_visual_token=197):
+    """DeepSpeed checkpoint -> this model (reference :59-106): strip the `_forward_module.` prefix; resize the visual tokenizer's
+    [1, 1 + grid, dim] position tables and the backbone's position table (same rule as convert_pl_ckpt, interpolation only)."""
+    new_state_dict = {}
+    for key, value in state_dict.items():
+        if not key.startswith("_forward_module."):
+            new_state_dict[key] = value
+            continue
+        new_key = key[len("_forward_module."):]
+        if ("visual_tokenizer.encoder.pos_embed" in new_key or "visual_tokenizer.decoder.pos_embed" in new_key) and value.shape[1] != num_visual_token:
+            value = _resize_pos_embed(value[0], 1, num_visual_token).unsqueeze(0)
+        if "backbone.encoder.embed_positions.A.weight" in new_key and value.shape[1] != num_visual_token + 2:
+            # (the reference compares shape[1] -- the embedding width -- so this branch runs for every checkpoint; a table that already
+            # has the target grid comes back unchanged from the area interpolation)
+            value = _resize_pos_embed(value, 3, num_visual_token)
+        new_state_dict[new_key] = value
+    return new_state_dict
 
 
 def init_weights(module):
@@ -71,6 +121,26 @@ class VLMo(nn.Module):
             self.backbone_vl.apply(init_weights)
         self._local_loss = config.get("local_loss", False)
         self._aggregate_nodes = config.get("aggregate_nodes", -1)
+        if config.get("load_path", "") != "" and config.get("test_only", False):
+            self.load_checkpoint(config["load_path"])
+
+    def load_checkpoint(self, path):
+        """Released-weight loading (reference :207-232): Lightning ("state_dict"), DeepSpeed ("module" / `_forward_module.` keys) or
+        plain state dicts, position tables resized to this model's patch grid, strict=False."""
+        ckpt = torch.load(path, map_location="cpu")
+        n_pos = self.backbone.vision_embed.num_position_embeddings()
+        state_dict = None
+        for k in ("state_dict", "module", "model"):
+            if k in ckpt:
+                state_dict = ckpt[k]
+                if k == "module":
+                    state_dict = convert_deepspeed_ckpt(state_dict, n_pos)
+                elif k == "state_dict":
+                    state_dict = convert_pl_ckpt(state_dict, n_pos)
+                break
+        if state_dict is None:
+            state_dict = convert_deepspeed_ckpt(ckpt, n_pos) if next(iter(ckpt)).startswith("_forward_module.") else ckpt
+        return self.load_state_dict(state_dict, strict=False)
 
     # ------------------------------------------------------------------ towers (reference :323-405)
     def infer_text(self, batch, mask_text=False):

@@ -16,6 +16,7 @@ Fixtures and the reference symbols that produced them:
   ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
   ops_dmae_wti.pt      DmaeUtils.wti_interaction (wti / att_wti, with and without the 2nd-frame term)   dmae_utils.py:85-184
   metric_recall.pt     _cal_recall / _cal_sym_recall (retrieval evaluation)   antmmf/modules/metrics/global_retrieval_recall.py:13-103
+  m2_ckpt_convert.pt   convert_pl_ckpt / convert_deepspeed_ckpt (position-table resize)   prj/M2_Encoder/vlmo/modules/vlmo_module.py:22-106
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
                        reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
@@ -189,6 +190,28 @@ def gen_metric_recall():
         d["rect." + k] = torch.tensor(float(v), dtype=torch.float64)
     d["rect.sim"] = sim
     save("metric_recall.pt", d)
+
+
+def gen_m2_ckpt_convert():
+    L.load_m2()
+    from vlmo.modules import vlmo_module as vm
+
+    dim = 8
+    d = {}
+    for tag, rows in (("grow", 3 + 16), ("shrink", 3 + 64), ("same", 3 + 36)):
+        sd = {"backbone.encoder.embed_positions.A.weight": W.data_tensor(f"ckpt.{tag}.pos", (rows, dim)),
+              "visual_tokenizer.x": torch.ones(2), "other.weight": W.data_tensor(f"ckpt.{tag}.o", (3, 2))}
+        out = vm.convert_pl_ckpt(dict(sd), num_visual_token=37)
+        d[f"pl.{tag}.pos"] = out["backbone.encoder.embed_positions.A.weight"]
+        d[f"pl.{tag}.nkeys"] = torch.tensor(len(out))
+    ds = {"_forward_module.backbone.encoder.embed_positions.A.weight": W.data_tensor("ckpt.ds.pos", (3 + 16, dim)),
+          "_forward_module.visual_tokenizer.encoder.pos_embed": W.data_tensor("ckpt.ds.vt", (1, 1 + 16, dim)),
+          "_forward_module.head.weight": W.data_tensor("ckpt.ds.h", (2, 2)), "plain.bias": torch.zeros(2)}
+    out = vm.convert_deepspeed_ckpt(dict(ds), num_visual_token=37)
+    d["ds.pos"] = out["backbone.encoder.embed_positions.A.weight"]
+    d["ds.vt"] = out["visual_tokenizer.encoder.pos_embed"]
+    d["ds.keys"] = torch.tensor(sorted(len(k) for k in out))
+    save("m2_ckpt_convert.pt", d)
 
 
 def gen_losses():
@@ -476,8 +499,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "metric_recall", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -254,3 +254,30 @@ def test_base_trainer_data_parallel_two_ranks():
     out = _spawn(_trainer_case, 29645)
     assert out[0]["iters"] == 6 and out[1]["iters"] == 6  # one increment per batch
     torch.testing.assert_close(out[0]["w"], out[1]["w"])  # replicas stay in sync (broadcast init + averaged grads)
+
+
+def test_m2_checkpoint_converters_match_reference(golden):
+    """convert_pl_ckpt / convert_deepspeed_ckpt (released-weight loading of the M2 encoder) against the reference's own functions
+    (tests/golden/m2_ckpt_convert.pt): position-table growth by area interpolation, truncation, prefix stripping."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weightgen as W
+    from vlmo.modules import vlmo_module as vm
+
+    g = golden("m2_ckpt_convert.pt")
+    dim = 8
+    for tag, rows in (("grow", 3 + 16), ("shrink", 3 + 64), ("same", 3 + 36)):
+        sd = {"backbone.encoder.embed_positions.A.weight": W.data_tensor(f"ckpt.{tag}.pos", (rows, dim)),
+              "visual_tokenizer.x": torch.ones(2), "other.weight": W.data_tensor(f"ckpt.{tag}.o", (3, 2))}
+        out = vm.convert_pl_ckpt(dict(sd), num_visual_token=37)
+        torch.testing.assert_close(out["backbone.encoder.embed_positions.A.weight"], g[f"pl.{tag}.pos"], rtol=1e-6, atol=1e-7)
+        assert len(out) == int(g[f"pl.{tag}.nkeys"])
+    ds = {"_forward_module.backbone.encoder.embed_positions.A.weight": W.data_tensor("ckpt.ds.pos", (3 + 16, dim)),
+          "_forward_module.visual_tokenizer.encoder.pos_embed": W.data_tensor("ckpt.ds.vt", (1, 1 + 16, dim)),
+          "_forward_module.head.weight": W.data_tensor("ckpt.ds.h", (2, 2)), "plain.bias": torch.zeros(2)}
+    out = vm.convert_deepspeed_ckpt(dict(ds), num_visual_token=37)
+    torch.testing.assert_close(out["backbone.encoder.embed_positions.A.weight"], g["ds.pos"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(out["visual_tokenizer.encoder.pos_embed"], g["ds.vt"], rtol=1e-6, atol=1e-7)
+    assert sorted(len(k) for k in out) == g["ds.keys"].tolist()
