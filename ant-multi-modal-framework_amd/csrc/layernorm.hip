@@ -139,13 +139,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     if (!BLOCK) {
         for (int i = threadIdx.x; i < NS * cols; i += 256) red[i] = 0.f;
     }
-    float ag[VPL][8], ab[VPL][8], ad[DXSUM ? VPL : 1][8], gm[VPL][8];
+    // gamma: registers for the wave-per-row variant; the workgroup-per-row variant (wide rows, three accumulator sets live) keeps it
+    // in LDS instead -- 16 VGPRs less, which is the difference between 2 and 3 resident waves per SIMD for the fused-GELU backward
+    float ag[VPL][8], ab[VPL][8], ad[DXSUM ? VPL : 1][8], gm[BLOCK ? 1 : VPL][8];
+    if (BLOCK) {
+        for (int i = threadIdx.x; i < cols; i += 256) red[i] = gamma[i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int vi = v0 + vstep * i;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; gm[i][e] = 0.f; if (DXSUM) ad[i][e] = 0.f; }
-        if (vi < nvec) ld8<float>(gamma + vi * 8, gm[i]);
+        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; if (!BLOCK) gm[i][e] = 0.f; if (DXSUM) ad[i][e] = 0.f; }
+        if (!BLOCK && vi < nvec) ld8<float>(gamma + vi * 8, gm[i]);
     }
     const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
     long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
@@ -180,13 +186,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
+                float gmv[8];
+                if (BLOCK) ld8<float>(red + (v0 + vstep * i) * 8, gmv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float z;
                     const float dv = g[i][e];
                     act_fwd_grad<ACT>(zh[i][e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
-                    g[i][e] = dv * gm[i][e];
+                    g[i][e] = dv * (BLOCK ? gmv[e] : gm[i][e]);
                     s1 += g[i][e];
                     s2 += g[i][e] * zh[i][e];
                     ag[i][e] += dv * zh[i][e];
@@ -331,8 +339,8 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
 #define LN_BWD(V, BLK, GRID, LDS) do { if (act == ANTMMF_ACT_NONE) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_GELU_ERF); else LN_BWD_A(V, BLK, GRID, LDS, -1); } while (0)
     if (nvec <= 64) LN_BWD(1, false, gw, lds);
     else if (nvec <= 128) LN_BWD(2, false, gw, lds);
-    else if (nvec <= 256) LN_BWD(1, true, gb, 16);
-    else if (nvec <= 512) LN_BWD(2, true, gb, 16);
+    else if (nvec <= 256) LN_BWD(1, true, gb, (size_t)cols * sizeof(float));
+    else if (nvec <= 512) LN_BWD(2, true, gb, (size_t)cols * sizeof(float));
     else return ANTMMF_EINVAL;
 #undef LN_BWD
 #undef LN_BWD_A
