@@ -256,6 +256,40 @@ def test_base_trainer_data_parallel_two_ranks():
     torch.testing.assert_close(out[0]["w"], out[1]["w"])  # replicas stay in sync (broadcast init + averaged grads)
 
 
+def _moco_queue_case(rank, world):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "base_vtp"))
+    from antmmf.common.configuration import Configuration
+    from roi_univl.univl.model.moco_utils import MocoUtils
+
+    mu = MocoUtils(Configuration(dict(hidden_size=8, K=12)), img_encoder=torch.nn.Linear(2, 2), txt_encoder=torch.nn.Linear(2, 2))
+    mu.txt_queue.zero_()
+    out = []
+    for step in range(3):  # 3 pushes of 2 x 3 keys into K = 12: the third wraps (write pointer back to 0, tail overwritten)
+        keys = torch.full((3, 8), float(10 * step + rank + 1))
+        vkeys = keys.clone()
+        if step == 1 and rank == 1:
+            vkeys[0, 0] = float("nan")  # a NaN anywhere in the gathered keys skips the whole update on every rank
+        mu.dequeue_and_enqueue(vkeys, keys)
+        out.append((mu.txt_queue[0].clone(), int(mu.txt_queue_ptr), torch.isfinite(mu.img_queue).all().item()))
+    return out
+
+
+def test_moco_enqueue_two_ranks():
+    """dequeue_and_enqueue over 2 gloo ranks: every rank's queue receives [rank0 keys ; rank1 keys] at the shared write pointer,
+    the pointer wraps at K, replicas stay identical, and a NaN key leaves the (image) queue untouched on every rank."""
+    out = _spawn(_moco_queue_case, 29655)
+    for step in range(3):
+        torch.testing.assert_close(out[0][step][0], out[1][step][0])
+        assert out[0][step][1] == out[1][step][1] == (6 * (step + 1)) % 12
+        assert out[0][step][2] and out[1][step][2]
+    q1 = out[0][0][0]
+    assert q1[:6].tolist() == [1.0, 1.0, 1.0, 2.0, 2.0, 2.0] and q1[6:].abs().sum() == 0
+    q3 = out[0][2][0]
+    assert q3[:6].tolist() == [21.0, 21.0, 21.0, 22.0, 22.0, 22.0] and q3[6:].tolist() == [11.0, 11.0, 11.0, 12.0, 12.0, 12.0]
+
+
 def test_m2_checkpoint_converters_match_reference(golden):
     """convert_pl_ckpt / convert_deepspeed_ckpt (released-weight loading of the M2 encoder) against the reference's own functions
     (tests/golden/m2_ckpt_convert.pt): position-table growth by area interpolation, truncation, prefix stripping."""
