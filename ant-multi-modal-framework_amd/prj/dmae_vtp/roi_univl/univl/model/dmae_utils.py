@@ -17,6 +17,7 @@ from torch import nn
 from antmmf.hip import contrastive
 from antmmf.hip import functional as HF
 from antmmf.modules.vision.backbone.clip.model import QuickGELU
+from antmmf.utils.distributed_utils import gather_tensor, get_world_size
 
 
 class LayerNormDmae(nn.Module):
@@ -139,8 +140,16 @@ class DmaeUtils(nn.Module):
 
     def wti_interaction(self, text_feat, word_feat, video_feat, word_mask, video_mask):
         """text_feat [A, 1, D] sentence embedding, word_feat [A, Nw, D] or None, video_feat [B, V, D]; masks 1 = real.
-        Multi-GPU: the reference all-gathers the five tensors with gradient (:135-146); that is the caller's job here
-        (antmmf.utils.distributed_utils.gather_tensor) so that this function stays a pure [A, B] scorer."""
+        Multi-GPU training: like the reference (:135-146) every rank scores the GLOBAL batch -- features and masks are all-gathered
+        with gradient (gather_tensor: backward = reduce-sum to the owner, i.e. W x the single-process gradient before the
+        data-parallel mean) -- but without the reference's forced barrier and its `torch.cuda.is_available()` gate."""
+        if self.training and get_world_size() > 1:
+            text_feat = gather_tensor(text_feat.contiguous(), method="cat", back_gradient=True, pad_tensors=True)
+            if word_feat is not None:
+                word_feat = gather_tensor(word_feat.contiguous(), method="cat", back_gradient=True, pad_tensors=True)
+            video_feat = gather_tensor(video_feat.contiguous(), method="cat", back_gradient=True, pad_tensors=True)
+            word_mask = gather_tensor(word_mask.float().contiguous(), method="cat", back_gradient=False, pad_tensors=True)
+            video_mask = gather_tensor(video_mask.float().contiguous(), method="cat", back_gradient=False, pad_tensors=True)
         expand_times = video_feat.shape[1] // video_mask.shape[1]
         video_mask = video_mask.unsqueeze(1).repeat(1, 1, expand_times).view(video_mask.shape[0], -1)
         text_mask = word_mask

@@ -290,6 +290,39 @@ def test_moco_enqueue_two_ranks():
     assert q3[:6].tolist() == [21.0, 21.0, 21.0, 22.0, 22.0, 22.0] and q3[6:].tolist() == [11.0, 11.0, 11.0, 12.0, 12.0, 12.0]
 
 
+def _dmae_wti_case(rank, world):
+    """DMAE wti_interaction on 2 ranks (emulated kernels): each rank holds half of the batch, scores the gathered global batch."""
+    os.environ["ANTMMF_HIP_LIB"] = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+    import model_cases as mc
+    import weightgen as W
+    from antmmf.common.configuration import Configuration
+
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "ops_dmae_wti.pt"))
+    du = mc.load_dmae_utils().DmaeUtils(Configuration(dict(mc.DMAE_CFG, l3_interaction="att_wti", l3_with_nfc=True, l3_sim_header="meanP")))
+    W.fill_module_(du)
+    du.train()
+    sl = slice(rank * 2, rank * 2 + 2)
+    t, w_, v = (g[k][sl].clone().requires_grad_(True) for k in ("text", "word", "video"))
+    out = du.wti_interaction(t, w_, v, g["word_mask"][sl], g["video_mask"][sl])
+    (out * g["g"]).sum().backward()
+    return dict(out=out.detach(), dtext=t.grad, dvideo=v.grad, dword=w_.grad)
+
+
+def test_dmae_wti_two_ranks_match_reference(golden):
+    """wti_interaction with the batch split over 2 gloo ranks == the reference's single-process result on the whole batch:
+    identical [4, 4] scores on both ranks, and local feature gradients = W x the single-process gradient slice (the gather's
+    reduce-sum backward; the data-parallel mean divides it back)."""
+    if not os.path.exists(os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")):
+        pytest.skip("emulated kernel library not built")
+    out = _spawn(_dmae_wti_case, 29665)
+    g = golden("ops_dmae_wti.pt")
+    for r in (0, 1):
+        sl = slice(r * 2, r * 2 + 2)
+        torch.testing.assert_close(out[r]["out"], g["att_wti.va1.out"], rtol=1e-3, atol=1e-3)
+        for key, ref in (("dtext", "att_wti.va1.dtext"), ("dvideo", "att_wti.va1.dvideo"), ("dword", "att_wti.va1.dword")):
+            torch.testing.assert_close(out[r][key], 2.0 * g[ref][sl], rtol=3e-2, atol=3e-2 * float(g[ref].abs().max()))
+
+
 def test_m2_checkpoint_converters_match_reference(golden):
     """convert_pl_ckpt / convert_deepspeed_ckpt (released-weight loading of the M2 encoder) against the reference's own functions
     (tests/golden/m2_ckpt_convert.pt): position-table growth by area interpolation, truncation, prefix stripping."""
