@@ -7,7 +7,7 @@ which only accepts host tensors).
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_void_p
+from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libantmmf_hip.so"))
@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
 ACT_IDS = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "quick_gelu": 2, "relu": 3}
 
-P, I, L, F = c_void_p, c_int, c_int64, c_float
+P, I, L, F, U64 = c_void_p, c_int, c_int64, c_float, c_uint64
 _SIGNATURES = {
     "antmmf_backend": [],
     "antmmf_abi_version": [],
@@ -40,8 +40,8 @@ _SIGNATURES = {
     "antmmf_sumsq": [P, P, L, P],
     "antmmf_gemm_bf16": [P, P, P, I, I, I, L, L, L, I, I, I, F, P, I, P, L, P, L, P, L, I, I, P],
     "antmmf_gemm_wgrad_bf16": [P, P, P, L, I, I, L, L, L, I, P, L, P],
-    "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, P],
-    "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
+    "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, F, U64, P],
+    "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
     "antmmf_milnce_fwd": [P, P, I, I, I, I, I, P, P, P],
     "antmmf_milnce_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P],
     "antmmf_softmax_ce_fwd": [P, I, I, I, P, F, P, P, P],
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "antmmf_moco_fwd": [P, P, I, I, I, F, P, P, P, P],
     "antmmf_moco_bwd": [P, P, P, P, P, I, I, I, F, P, P, I, P],
     "antmmf_ema_update": [P, P, P, L, F, P],
+    "antmmf_dropout_add": [P, P, P, L, F, U64, I, P],
     "antmmf_wti_reduce_fwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "antmmf_wti_reduce_bwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "antmmf_rank_rows": [P, L, I, I, P, P, P, P],

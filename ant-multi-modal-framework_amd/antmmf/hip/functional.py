@@ -237,6 +237,8 @@ class LayerSpec:
     eps: float
     act: str           # "quick_gelu" | "gelu"
     packed_qkv: bool   # True: one [3d, d] in_proj (CLIP);  False: separate q/k/v weights
+    attn_dropout: float = 0.0    # BERT only, training only: attention_probs_dropout_prob (modeling_bert.py:157)
+    hidden_dropout: float = 0.0  # BERT only, training only: hidden_dropout_prob after both dense layers (:175-186,227-238)
 
 
 # parameter slots of `transformer_layer` (absent ones are None)
@@ -288,8 +290,10 @@ def set_keep_ffn_norm(flag):
 
 class _TransformerLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, key_bias, spec, *params):
+    def forward(ctx, x, key_bias, spec, seed, *params):
         P = dict(zip(SLOTS, params))
+        p_att, p_hid = (spec.attn_dropout, spec.hidden_dropout) if spec.kind == "bert" else (0.0, 0.0)
+        seed = int(seed or 0)
         B, N, d = x.shape
         x2 = x.reshape(B * N, d)
         if not x2.is_contiguous():
@@ -308,7 +312,7 @@ class _TransformerLayer(torch.autograd.Function):
         qkv = ops.gemm(h, wqkv, bias=bqkv)  # [T, 3d]
         del h
         q3 = qkv.view(B, N, 3 * d)
-        o, lse = ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], spec.heads, scale, key_bias)
+        o, lse = ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], spec.heads, scale, key_bias, p_att, seed)
         o2 = o.view(T, d)
         st_in = None
         if spec.kind == "m2":
@@ -316,7 +320,10 @@ class _TransformerLayer(torch.autograd.Function):
             st_in = (mi, ri)
         else:
             o_n = o2
-        x1 = ops.gemm(o_n, compute_copy(P["wo"]), bias=f32(P["bo"]), residual=x2)  # attention output + residual
+        if p_hid > 0:  # LayerNorm(dropout(dense(ctx)) + x): the dropout sits between the bias and the residual add
+            x1 = ops.dropout_add(ops.gemm(o_n, compute_copy(P["wo"]), bias=f32(P["bo"])), p_hid, seed + 1, residual=x2)
+        else:
+            x1 = ops.gemm(o_n, compute_copy(P["wo"]), bias=f32(P["bo"]), residual=x2)  # attention output + residual
         del o_n
         if pre_ln:
             mid = x1  # residual stream after attention
@@ -336,7 +343,10 @@ class _TransformerLayer(torch.autograd.Function):
             u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
             g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
         res = mid if pre_ln else h2
-        y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
+        if p_hid > 0:
+            y = ops.dropout_add(ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"])), p_hid, seed + 2, residual=res)
+        else:
+            y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
         kept_gn = g_n if (KEEP_FFN_NORM and spec.kind == "m2") else None
         del g_n
         st_y = None
@@ -351,7 +361,7 @@ class _TransformerLayer(torch.autograd.Function):
         saved.append(s2)
         saved.append(kept_gn)
         ctx.save_for_backward(*saved, *params)
-        ctx.spec, ctx.shape, ctx.nsaved = spec, (B, N, d), len(saved)
+        ctx.spec, ctx.shape, ctx.nsaved, ctx.drop = spec, (B, N, d), len(saved), (p_att, p_hid, seed)
         return y.view(B, N, d)
 
     @staticmethod
@@ -368,6 +378,7 @@ class _TransformerLayer(torch.autograd.Function):
         sink = GradSink()
         pre_ln = spec.kind in ("clip", "m2")
         scale = 64 ** -0.5
+        p_att, p_hid, seed = ctx.drop
         dy2 = dy.reshape(T, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -388,8 +399,10 @@ class _TransformerLayer(torch.autograd.Function):
             g_n, _, _ = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False, act=spec.act)
         else:
             g_n = ops.act_fwd(u, spec.act)
-        _wgrad(sink, P["w2"], ds2, g_n)
-        _bgrad(sink, P["b2"], ds2)
+        # hidden dropout: the dense output's gradient is the masked / rescaled ds2; the residual branch keeps ds2 itself
+        dy_w2 = ops.dropout_add(ds2.contiguous(), p_hid, seed + 2) if p_hid > 0 else ds2
+        _wgrad(sink, P["w2"], dy_w2, g_n)
+        _bgrad(sink, P["b2"], dy_w2)
         del g_n
         if spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
@@ -400,7 +413,7 @@ class _TransformerLayer(torch.autograd.Function):
             del dgn
         else:
             b1_fused = False
-            du = dgrad(ds2, P["w2"], gate=u, act=spec.act)  # (ds2 W2) * act'(u)
+            du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act)  # (d(dense out) W2) * act'(u)
         ln_mid = ("ln2" if pre_ln else "ln1")
         h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
         _wgrad(sink, P["w1"], du, h2)
@@ -408,7 +421,7 @@ class _TransformerLayer(torch.autograd.Function):
             _bgrad(sink, P["b1"], du)
         del h2
         dgw, dgb = lnw(ln_mid)
-        bo_fused = P["bo"] is not None and P["bo"].requires_grad  # out-projection bias gradient = column sums of dmid
+        bo_fused = P["bo"] is not None and P["bo"].requires_grad and p_hid == 0  # out-projection bias gradient = column sums of dmid
         bo_sum = sink.buf(P["bo"]) if bo_fused else None
         if pre_ln:
             dh2 = dgrad(du, P["w1"])
@@ -424,18 +437,19 @@ class _TransformerLayer(torch.autograd.Function):
             o_n, _, _ = ops.layernorm_fwd(o2, f32(P["inner_w"]), f32(P["inner_b"]), spec.eps, want_stats=False)
         else:
             o_n = o2
-        _wgrad(sink, P["wo"], dmid, o_n)
+        dy_wo = ops.dropout_add(dmid.contiguous(), p_hid, seed + 1) if p_hid > 0 else dmid
+        _wgrad(sink, P["wo"], dy_wo, o_n)
         if not bo_fused:
-            _bgrad(sink, P["bo"], dmid)
+            _bgrad(sink, P["bo"], dy_wo)
         del o_n
-        do = dgrad(dmid, P["wo"])
+        do = dgrad(dy_wo, P["wo"])
         if spec.kind == "m2":
             dgw, dgb = lnw("inner")
             do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
-                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dropout_p=p_att, dropout_seed=seed)
         del do
         dqkv2 = dqkv.view(T, 3 * d)
         if pre_ln:
@@ -461,13 +475,16 @@ class _TransformerLayer(torch.autograd.Function):
             else:
                 dx = ops.gemm(dqkv2, wqkv_t, residual=dmid)
             dx = dx.view(B, N, d)
-        grads = [sink.result(p, p is not None and ctx.needs_input_grad[3 + i]) for i, p in enumerate(params)]
-        return (dx, None, None, *grads)
+        grads = [sink.result(p, p is not None and ctx.needs_input_grad[4 + i]) for i, p in enumerate(params)]
+        return (dx, None, None, None, *grads)
 
 
-def transformer_layer(x, spec, params, key_bias=None):
-    """x [B, N, d] bf16 -> [B, N, d]; `params` maps SLOTS names to fp32 master parameters."""
-    return _TransformerLayer.apply(x, key_bias, spec, *[params.get(s) for s in SLOTS])
+def transformer_layer(x, spec, params, key_bias=None, seed=None):
+    """x [B, N, d] bf16 -> [B, N, d]; `params` maps SLOTS names to fp32 master parameters.  `seed`: dropout seed of this call
+    (BERT layers with dropout > 0 only); None draws one from torch's CPU generator (host side: no device sync)."""
+    if seed is None and spec.kind == "bert" and (spec.attn_dropout > 0 or spec.hidden_dropout > 0):
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _TransformerLayer.apply(x, key_bias, spec, seed, *[params.get(s) for s in SLOTS])
 
 
 # ------------------------------------------------------------------------------ embeddings

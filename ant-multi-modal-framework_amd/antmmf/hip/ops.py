@@ -312,7 +312,8 @@ def _tok_ld(t, name):
     return t.stride(1)
 
 
-def attention_fwd(q, k, v, heads, scale, key_bias=None):
+def attention_fwd(q, k, v, heads, scale, key_bias=None, dropout_p=0.0, dropout_seed=0):
+    """dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_seed, element index)."""
     _dev_ok(q, k, v, key_bias)
     B, Nq, D = q.shape
     Nk = k.shape[1]
@@ -323,12 +324,13 @@ def attention_fwd(q, k, v, heads, scale, key_bias=None):
         _f32(key_bias, "key_bias"); _c(key_bias, "key_bias")
         assert tuple(key_bias.shape) == (B, Nk)
     _rc(_lib.load().antmmf_attention_fwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), B, heads, Nq, Nk,
-                                         _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, float(scale), _stream()),
+                                         _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, float(scale), float(dropout_p),
+                                         int(dropout_seed), _stream()),
         "antmmf_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None):
+def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dropout_p=0.0, dropout_seed=0):
     _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
     B, Nq, D = q.shape
     Nk = k.shape[1]
@@ -341,7 +343,8 @@ def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk
         dv = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
     _rc(_lib.load().antmmf_attention_bwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
                                          B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
-                                         _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), _stream()),
+                                         _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), float(dropout_p),
+                                         int(dropout_seed), _stream()),
         "antmmf_attention_bwd")
     return dq, dk, dv
 
@@ -466,3 +469,14 @@ def rank_rows(S, gt_off, gt_idx):
     rank = torch.empty(S.shape[0], dtype=torch.int32, device=S.device)
     _rc(_lib.load().antmmf_rank_rows(_p(S), S.stride(0), S.shape[0], S.shape[1], _p(gt_off), _p(gt_idx), _p(rank), _stream()), "antmmf_rank_rows")
     return rank
+
+
+def dropout_add(x, p, seed, residual=None):
+    """y = x * keep / (1 - p) (+ residual) with the counter-based mask keep(seed, element index); its own backward w.r.t. x is the
+    same call on dy without residual."""
+    _dev_ok(x, residual); _c(x, "x")
+    if residual is not None:
+        _c(residual, "residual")
+    y = torch.empty_like(x)
+    _rc(_lib.load().antmmf_dropout_add(_p(x), _p(residual), _p(y), x.numel(), float(p), int(seed), _dt(x), _stream()), "antmmf_dropout_add")
+    return y

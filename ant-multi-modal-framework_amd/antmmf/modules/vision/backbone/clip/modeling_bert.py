@@ -4,8 +4,10 @@ BertIntermediate, BertOutput, BertLayer, BertEncoder, BertPooler, BertModel) so 
 BertLayer is one fused autograd node (antmmf.hip.functional.transformer_layer, kind "bert": post-LN, erf-GELU,
 additive -10000 key mask).  The sub-modules are parameter holders; their own forward is not on the path.
 
-Dropout: the fused layer implements p = 0 (eval, or *_dropout_prob = 0).  Training with p > 0 raises -- the
-flagship M2 path has p = 0 everywhere (torchscale config.py:14-17); see DESIGN.md "out of scope".
+Dropout: in training mode the fused layer applies attention-probability dropout inside the attention kernels and hidden dropout
+after both dense layers, with counter-based masks that forward and backward regenerate (nothing stored); the mask stream is this
+build's own (not torch's Philox), so runs are reproducible per seed but not bit-identical to the reference's random draws.
+The flagship M2 path has p = 0 everywhere (torchscale config.py:14-17).
 """
 import math
 
@@ -74,8 +76,10 @@ class BertLayer(nn.Module):
         self.attention = BertAttention(config)
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
-        self._p_drop = max(config.hidden_dropout_prob, config.attention_probs_dropout_prob)
         self._spec = HF.LayerSpec(kind="bert", heads=config.num_attention_heads, eps=config.layer_norm_eps, act="gelu", packed_qkv=False)
+        # training-mode twin with the two dropouts of the block (attention probabilities, both dense outputs) switched on
+        self._spec_train = HF.LayerSpec(kind="bert", heads=config.num_attention_heads, eps=config.layer_norm_eps, act="gelu", packed_qkv=False,
+                                        attn_dropout=float(config.attention_probs_dropout_prob), hidden_dropout=float(config.hidden_dropout_prob))
 
     def _params(self):
         a, o = self.attention, self.output
@@ -88,14 +92,12 @@ class BertLayer(nn.Module):
     def forward(self, hidden_states, attention_mask=None, head_mask=None):
         """hidden_states [B, N, d] bf16; attention_mask: additive key bias, [B, N] fp32 or the reference's
         extended [B, 1, 1, N] form."""
-        if self.training and self._p_drop > 0:
-            raise NotImplementedError("fused BertLayer: dropout p > 0 in training mode is not implemented on the HIP path")
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported on the HIP path")
         kb = None
         if attention_mask is not None:
             kb = attention_mask.reshape(attention_mask.shape[0], -1).float().contiguous()
-        return HF.transformer_layer(hidden_states, self._spec, self._params(), kb)
+        return HF.transformer_layer(hidden_states, self._spec_train if self.training else self._spec, self._params(), kb)
 
 
 class BertEncoder(nn.Module):

@@ -56,6 +56,11 @@ struct AttnArgs {
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, heads, Nq, Nk;
     float scale;
+    // attention-probability dropout (BertSelfAttention, modeling_bert.py:157): p_drop = 0 -> off.  The mask is a pure function of
+    // (seed, ((b * heads + h) * Nq + q) * Nk + k), regenerated identically by the forward and both backward kernels.
+    float drop_scale;       // 1 / (1 - p)
+    uint32_t drop_thr;      // 0 = no dropout
+    uint64_t drop_seed;
 };
 
 __device__ __forceinline__ int attn_swz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
@@ -142,7 +147,16 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[t][r] = EXP2F(s[t][r] - m); sum += s[t][r]; }
         sum = grp_sum(sum);
-        const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;  // applied to the 16 output values, not the Nk probabilities
+        float inv = sum > 0.f ? fast_rcp(sum) : 0.f;  // applied to the 16 output values, not the Nk probabilities
+        if (a.drop_thr) {  // workgroup-uniform: drop probabilities (the softmax denominator keeps every key, as in the reference)
+            const uint32_t base = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (!DROPOUT_KEEP(base + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr)) s[t][r] = 0.f;
+            inv *= a.drop_scale;
+        }
         bf16x8_t pf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) pf[c] = pack_frag(s[2 * c], s[2 * c + 1]);
@@ -202,6 +216,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
         const float lse = a.lse[((long)b * a.heads + h) * a.Nq + qrow];
         // fully masked query (lse = -inf): subtracting +inf makes every z = -inf and exp2(z) = 0 without per-element selects
         const float lse2 = lse == -INFINITY ? INFINITY : lse * LOG2E;
+        const uint32_t dbase = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
         bf16x8_t dsf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -220,7 +235,9 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = EXP2F(sa[r] * scale2 + bb[r] - lse2);  // masked key: bias = -inf -> p = 0
-                    ds[hh][r] = p * (da[r] - dsum);
+                    float dp = da[r];
+                    if (a.drop_thr) dp = DROPOUT_KEEP(dbase + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr) ? dp * a.drop_scale : 0.f;
+                    ds[hh][r] = p * (dp - dsum);
                 }
             }
             dsf[c] = pack_frag(ds[0], ds[1]);
@@ -302,8 +319,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pr = EXP2F(sa[r] * scale2 + kbias - ll[r]);  // masked / padding key or query: -inf -> 0
-                    p[hh][r] = pr;
-                    ds[hh][r] = pr * (da[r] - dd[r]);
+                    float pd = pr, dp = da[r];
+                    if (a.drop_thr) {
+                        const int qq = q0 + 4 * grp + r;
+                        const bool keep = DROPOUT_KEEP((uint32_t)((((long)b * a.heads + h) * a.Nq + (qq < a.Nq ? qq : a.Nq - 1)) * a.Nk) + krow, a.drop_seed, a.drop_thr);
+                        pd = keep ? pr * a.drop_scale : 0.f;
+                        dp = keep ? dp * a.drop_scale : 0.f;
+                    }
+                    p[hh][r] = pd;                     // dV uses the dropped probabilities
+                    ds[hh][r] = pr * (dp - dd[r]);     // dS uses the softmax probabilities
                 }
             }
             const bf16x8_t pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
@@ -335,8 +359,10 @@ static void set_lds(K kern, size_t bytes) { (void)hipFuncSetAttribute(reinterpre
 
 extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
                                     int B, int heads, int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, float scale,
-                                    hipStream_t stream) {
+                                    float dropout_p, uint64_t dropout_seed, hipStream_t stream) {
     AttnArgs a{};
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
+    a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)o; a.lse = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (!q || !k || !v || !o || !lse || !attn_args_ok(a)) return ANTMMF_EINVAL;
@@ -351,8 +377,11 @@ extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v,
 
 extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
                                     const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq, int Nk, long ldq, long ldk,
-                                    long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, hipStream_t stream) {
+                                    long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, float dropout_p,
+                                    uint64_t dropout_seed, hipStream_t stream) {
     AttnArgs a{};
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
+    a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)const_cast<void*>(o);
     a.lse = const_cast<float*>(lse); a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;

@@ -153,6 +153,20 @@ __device__ __forceinline__ bf16x4_t lds_read_tr16_raw(const char* p) {
 #define WAVE_LDS_ORDER() __builtin_amdgcn_wave_barrier()
 #endif
 
+// Counter-based dropout mask: keep(seed, idx) is a pure function, so forward and backward (and the separate attention backward
+// kernels) regenerate the same mask without storing it.  murmur3's 32-bit finaliser over (idx, seed); idx < 2^32 on this path
+// (B * heads * Nq * Nk and tokens * 4d both stay below it at the bench size).  tests/kernel_cases.py holds the numpy twin.
+__host__ __device__ __forceinline__ uint32_t dropout_hash(uint32_t idx, uint64_t seed) {
+    uint32_t h = idx * 0x9E3779B1u + (uint32_t)seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    h ^= (uint32_t)(seed >> 32);
+    h *= 0x27d4eb2fu; h ^= h >> 15;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return p <= 0.f ? 0u : (uint32_t)((double)p * 4294967296.0); }
+// keep iff hash >= threshold  (P[drop] = p)
+#define DROPOUT_KEEP(idx, seed, thr) (dropout_hash((uint32_t)(idx), (seed)) >= (thr))
+
 // activation ids shared with the host side (include/antmmf_hip.h)
 #define ANTMMF_ACT_NONE 0
 #define ANTMMF_ACT_GELU_ERF 1    // 0.5 x (1 + erf(x/sqrt2))   (BERT, torchscale)

@@ -387,3 +387,31 @@ extern "C" int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, 
     hipLaunchKernelGGL(ema_kernel, dim3(ew_grid((n >> 2) + 1)), dim3(256), 0, s, k, q, (bf16_t*)k_shadow_bf16, n, m);
     return antmmf_check_launch();
 }
+
+
+// ---- hidden-state dropout of the BERT blocks (modeling_bert.py:175-186,227-238: LayerNorm(dropout(dense(x)) + residual)):
+// y = x * keep / (1 - p) (+ residual);  backward dx = dy * keep / (1 - p) with the same counter-based mask.  Only launched when
+// p > 0 in training (the flagship M2 encoder has p = 0 everywhere).  HBM-bound elementwise pass.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long n, float scale,
+                                                          uint32_t thr, uint64_t seed) {
+    const long nvec = n >> 3;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float a[8], r[8];
+        ld8<T>(x + v * 8, a);
+        if (res) ld8<T>(res + v * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (DROPOUT_KEEP(v * 8 + e, seed, thr) ? a[e] * scale : 0.f) + (res ? r[e] : 0.f);
+        st8<T>(y + v * 8, a);
+    }
+}
+extern "C" int antmmf_dropout_add(const void* x, const void* residual, void* y, long n, float p, uint64_t seed, int dtype, hipStream_t s) {
+    if (!x || !y || n < 0 || (n & 7) || !(p >= 0.f && p < 1.f)) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    const float scale = 1.0f / (1.0f - p);
+    const uint32_t thr = dropout_threshold(p);
+    if (dtype == ANTMMF_BF16) hipLaunchKernelGGL(dropout_add_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, scale, thr, seed);
+    else if (dtype == ANTMMF_F32) hipLaunchKernelGGL(dropout_add_kernel<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const float*)x, (const float*)residual, (float*)y, n, scale, thr, seed);
+    else return ANTMMF_EINVAL;
+    return antmmf_check_launch();
+}

@@ -145,12 +145,16 @@ int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tok
  * is two calls with the streams swapped.  lse [B, heads, Nq] fp32 is saved for the backward. */
 int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
                          int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                         float scale, antmmf_stream_t stream);
+                         float scale, float dropout_p, uint64_t dropout_seed, antmmf_stream_t stream);
 /* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs. */
 int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
                          const float* lse, const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq,
                          int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
-                         int64_t lddk, int64_t lddv, float scale, antmmf_stream_t stream);
+                         int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed,
+                         antmmf_stream_t stream);
+/* dropout_p > 0: attention-probability dropout (BertSelfAttention, modeling_bert.py:157) with a counter-based mask
+ * keep(seed, ((b * heads + h) * Nq + q) * Nk + k) that forward and backward regenerate identically (nothing is stored);
+ * pass the same (dropout_p, dropout_seed) to both calls. */
 
 /* ---- row-sharded MIL-NCE (get_mil_nce_loss, univl_video_ret.py:146-197) on fp32 similarity slabs:
  *   Rm[i][c] = <text_i, clip_c> (c over all Wr = B_g*n clips),  Cm[i][t] = <centre clip of video_i, text_t> (Wc = B_g),
@@ -200,6 +204,10 @@ int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V, const floa
  * gt_idx[gt_off[i] .. gt_off[i+1]) of #{ j : S[i][j] > S[i][g] } (0 = first).  S fp32 [rows, cols] with row stride ld. */
 int antmmf_rank_rows(const float* S, int64_t ld, int rows, int cols, const int* gt_off, const int* gt_idx, int* rank,
                      antmmf_stream_t stream);
+/* ---- hidden-state dropout of the BERT blocks (modeling_bert.py:175-186,227-238): y = x * keep / (1 - p) (+ residual), keep from the
+ * same counter-based mask family (index = element offset).  The backward is the same call on dy with residual = NULL. n % 8 == 0. */
+int antmmf_dropout_add(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, int dtype,
+                       antmmf_stream_t stream);
 /* ---- momentum update of a MoCo key tower laid out flat: k = m k + (1 - m) q, k_shadow_bf16 (nullable) = bf16(k).
  * Replaces momentum_update_key_encoder's per-parameter loop (moco_utils.py:55-69). */
 int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, float m, antmmf_stream_t stream);

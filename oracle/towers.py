@@ -93,19 +93,30 @@ def bert_embeddings(P, input_ids=None, inputs_embeds=None, token_type_ids=None, 
     return ops.layer_norm(inputs_embeds + pos + typ, P["LayerNorm.weight"], P["LayerNorm.bias"], eps)
 
 
-def bert_layer(P, x, key_bias, heads, eps=1e-12):
+def bert_layer(P, x, key_bias, heads, eps=1e-12, drop=None):
     """Post-LN BERT layer (modeling_bert.py:134-270): self-attention with additive key mask,
-    LN(dense(ctx) + x), LN(dense(gelu(dense(y))) + y)."""
+    LN(dense(ctx) + x), LN(dense(gelu(dense(y))) + y).
+    drop (training with dropout): dict of MULTIPLIERS (mask / (1 - p)) applied where the reference applies nn.Dropout --
+    "attn" [B, h, N, N] on the attention probabilities (:157), "hid1" / "hid2" [B, N, d] on the two dense outputs before the
+    residual add (:183, :235)."""
     q = ops.linear(x, P["attention.self.query.weight"], P["attention.self.query.bias"])
     k = ops.linear(x, P["attention.self.key.weight"], P["attention.self.key.bias"])
     v = ops.linear(x, P["attention.self.value.weight"], P["attention.self.value.bias"])
     dh = x.shape[-1] // heads
-    ctx = ops.merge_heads(ops.attention_core(ops.split_heads(q, heads), ops.split_heads(k, heads),
-                                             ops.split_heads(v, heads), dh ** -0.5, key_bias))
-    a = ops.linear(ctx, P["attention.output.dense.weight"], P["attention.output.dense.bias"]) + x
+    if drop is None:
+        ctx = ops.attention_core(ops.split_heads(q, heads), ops.split_heads(k, heads), ops.split_heads(v, heads), dh ** -0.5, key_bias)
+    else:
+        s = torch.matmul(ops.split_heads(q, heads), ops.split_heads(k, heads).transpose(-1, -2)) * dh ** -0.5
+        if key_bias is not None:
+            s = s + key_bias[:, None, None, :]
+        ctx = torch.matmul(torch.softmax(s, dim=-1) * drop["attn"], ops.split_heads(v, heads))
+    ctx = ops.merge_heads(ctx)
+    d1 = ops.linear(ctx, P["attention.output.dense.weight"], P["attention.output.dense.bias"])
+    a = (d1 if drop is None else d1 * drop["hid1"]) + x
     a = ops.layer_norm(a, P["attention.output.LayerNorm.weight"], P["attention.output.LayerNorm.bias"], eps)
     u = ops.gelu_erf(ops.linear(a, P["intermediate.dense.weight"], P["intermediate.dense.bias"]))
-    o = ops.linear(u, P["output.dense.weight"], P["output.dense.bias"]) + a
+    d2 = ops.linear(u, P["output.dense.weight"], P["output.dense.bias"])
+    o = (d2 if drop is None else d2 * drop["hid2"]) + a
     return ops.layer_norm(o, P["output.LayerNorm.weight"], P["output.LayerNorm.bias"], eps)
 
 

@@ -462,3 +462,55 @@ def case_retrieval_metrics(dev, golden):
     m.collect(None, {"l1_simi": g["rect.sim"][9:].to(dev)}, 1, 0, t2v=t2v[9:])
     summ = m.summarize()
     assert abs(float(summ["l1_simi_t2v-mr"]) - float(g["rect.t2v-mr"])) < 1e-6 and abs(float(summ["l1_simi_v2t-r@5"]) - float(g["rect.v2t-r@5"])) < 1e-6
+
+
+# ------------------------------------------------------------------------------ dropout (counter-based masks)
+def dropout_keep_np(idx, seed, p):
+    """numpy twin of csrc/common.h::dropout_hash / DROPOUT_KEEP."""
+    import numpy as np
+
+    idx = np.asarray(idx, dtype=np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    h = (idx * np.uint64(0x9E3779B1) + np.uint64(seed & 0xFFFFFFFF)) & M
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85ebca6b)) & M
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xc2b2ae35)) & M
+    h ^= h >> np.uint64(16)
+    h ^= np.uint64((seed >> 32) & 0xFFFFFFFF)
+    h = (h * np.uint64(0x27d4eb2f)) & M
+    h ^= h >> np.uint64(15)
+    thr = np.uint64(0 if p <= 0 else int(float(np.float32(p)) * 4294967296.0))
+    return torch.from_numpy((h >= thr))
+
+
+def case_dropout(ops, dev):
+    """dropout_add vs the numpy twin of the mask (exact), keep rate, residual path; attention with probability dropout vs the
+    oracle attention with the same explicit mask (forward and all three gradients)."""
+    import numpy as np
+
+    n, p, seed = 8 * 1000, 0.25, (123456789 << 32) | 987654321
+    x, r = rnd((n,), 501), rnd((n,), 502)
+    keep = dropout_keep_np(np.arange(n), seed, p)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    want = x * keep / (1 - p) + r
+    check("dropout.add", ops.dropout_add(x.to(dev), p, seed, residual=r.to(dev)), want, 1e-6, 1e-6)
+    check("dropout.bwd", ops.dropout_add(x.to(dev), p, seed), x * keep / (1 - p), 1e-6, 1e-6)
+    check("dropout.bf16", ops.dropout_add(q(x).to(dev, BF), p, seed, residual=q(r).to(dev, BF)), q(x) * keep / (1 - p) + q(r), 2e-2, 2e-2)
+    # attention
+    B, heads, N, D = 2, 2, 21, 128
+    scale, pa, seed = 0.125, 0.2, (77 << 32) | 4242
+    qt, kt, vt, d_o = (q(rnd((B, N, D), 510 + i)) for i in range(4))
+    lengths = torch.tensor([N, 9])
+    key_bias = torch.zeros(B, N).masked_fill(~(torch.arange(N)[None, :] < lengths[:, None]), -10000.0)
+    idx = np.arange(B * heads * N * N).reshape(B, heads, N, N)
+    mask = dropout_keep_np(idx, seed, pa).float() / (1 - pa)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qt, kt, vt))
+    s = torch.matmul(oops.split_heads(qr, heads), oops.split_heads(kr, heads).transpose(-1, -2)) * scale + key_bias[:, None, None, :]
+    ref = oops.merge_heads(torch.matmul(torch.softmax(s, -1) * mask, oops.split_heads(vr, heads)))
+    ref.backward(d_o)
+    qd, kd, vd = qt.to(dev, BF), kt.to(dev, BF), vt.to(dev, BF)
+    o, lse = ops.attention_fwd(qd, kd, vd, heads, scale, key_bias.to(dev), dropout_p=pa, dropout_seed=seed)
+    check("attn.drop.o", o, ref, 2e-2, 2e-2)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, key_bias.to(dev), dropout_p=pa, dropout_seed=seed)
+    check("attn.drop.dq", dq, qr.grad, 3e-2, 3e-2)
+    check("attn.drop.dk", dk, kr.grad, 3e-2, 3e-2)
+    check("attn.drop.dv", dv, vr.grad, 3e-2, 3e-2)

@@ -86,6 +86,57 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
 
 
+def case_bert_layer_dropout(dev):
+    """Fused BERT layer in training mode with attention / hidden dropout vs the oracle layer with the SAME masks (rebuilt on the
+    host by the numpy twin of the counter-based hash): forward, input gradient, parameter gradients."""
+    import numpy as np
+
+    from antmmf.hip import functional as HF
+    from antmmf.modules.vision.backbone.clip.configuration_bert import BertConfig
+    from antmmf.modules.vision.backbone.clip.modeling_bert import BertLayer
+    from kernel_cases import dropout_keep_np
+    from oracle import towers as otowers
+
+    pa, ph, seed = 0.2, 0.1, (31 << 32) | 2718
+    cfg = BertConfig(vocab_size_or_config_json_file=50, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=512,
+                     hidden_act="gelu", hidden_dropout_prob=ph, attention_probs_dropout_prob=pa, layer_norm_eps=1e-12)
+    layer = BertLayer(cfg)
+    W.fill_module_(layer)
+    layer = layer.to(dev).train()
+    B, N, d, heads = 3, 12, 128, 2
+    x0 = W.data_tensor("bertdrop.x", (B, N, d))
+    w = W.data_tensor("bertdrop.w", (B, N, d))
+    lengths = torch.tensor([12, 7, 3])
+    key_bias = (1.0 - (torch.arange(N)[None, :] < lengths[:, None]).float()) * -10000.0
+    x = x0.to(dev, torch.bfloat16).requires_grad_(True)
+    y = HF.transformer_layer(x, layer._spec_train, layer._params(), key_bias.to(dev), seed=seed)
+    (y.float() * w.to(dev)).sum().backward()
+    drop = dict(attn=dropout_keep_np(np.arange(B * heads * N * N).reshape(B, heads, N, N), seed, pa).float() / (1 - pa),
+                hid1=dropout_keep_np(np.arange(B * N * d).reshape(B, N, d), seed + 1, ph).float() / (1 - ph),
+                hid2=dropout_keep_np(np.arange(B * N * d).reshape(B, N, d), seed + 2, ph).float() / (1 - ph))
+    P = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in layer.named_parameters()}
+    xr = x0.to(torch.bfloat16).float().requires_grad_(True)
+    ref = otowers.bert_layer(P, xr, key_bias, heads, drop=drop)
+    (ref * w).sum().backward()
+    check("bertdrop.y", y, ref, 5e-2, 3e-2)
+    check("bertdrop.dx", x.grad, xr.grad, 1e-1, 5e-2)
+    named = dict(layer.named_parameters())
+    top = max(float(v.grad.norm()) for v in P.values())
+    n = 0
+    for k, v in P.items():
+        rn = float(v.grad.norm())
+        if rn > 1e-4 * top:
+            assert abs(float(named[k].grad.float().norm()) - rn) <= 0.1 * rn, (k, float(named[k].grad.float().norm()), rn)
+            n += 1
+    assert n >= 14
+    # eval mode: no dropout, deterministic
+    layer.eval()
+    y1 = layer(x.detach(), key_bias.to(dev))
+    y2 = layer(x.detach(), key_bias.to(dev))
+    assert torch.equal(y1, y2)
+    return dict(checked=n)
+
+
 def case_temporal_head(dev):
     """UnivlForVideo.get_temporal_output ([cls] + clip features through a 3-layer BERT, inputs_embeds path) vs the CPU oracle's
     BERT restatement on the same weights, forward and input / parameter gradients."""

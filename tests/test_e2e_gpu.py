@@ -62,6 +62,10 @@ def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(DEV, golden))
 
 
+def test_bert_layer_dropout_vs_oracle_same_masks():
+    print(mc.case_bert_layer_dropout(DEV))
+
+
 def test_temporal_head_vs_oracle():
     print(mc.case_temporal_head(DEV))
 

@@ -118,6 +118,10 @@ def test_retrieval_metrics(ops, golden):
     kc.case_retrieval_metrics(DEV, golden)
 
 
+def test_dropout_masks(ops):
+    kc.case_dropout(ops, DEV)
+
+
 def test_milnce(ops):
     kc.case_milnce(ops, DEV, Bg=6, n=2, world=2)
     kc.case_milnce(ops, DEV, Bg=4, n=1, world=1)
