@@ -8,7 +8,10 @@ Built:
     :85-184,229-278): split GEMM -> [A*T, B*V] slab -> one fused max / arg-max reduction kernel (antmmf_wti_reduce_*), in blocks of
     text rows -- the reference's [B_t, B_v, N_t, N_v] einsum tensor (96 GB at B_g = 8192) is never materialised;
   * CrossEn (:528-537) and NegNCE (:539-563) on fused row kernels.
-Not built: TPM-CL (get_partial_similarity, :280-463; l3_partial_type > 0 raises NotImplementedError) and wti_arch 2 / 3."""
+  * TPM-CL, the partial-order margin losses (get_partial_similarity / _get_partial_output / wti_interaction_row, :280-523, with
+    tpmcl_utils.py's LinearXWeightPredictor and TokenImportanceSelector): a small head over 8 x 16 caption/video blocks, composed
+    from torch device ops (no custom kernel: per block it touches ~128 pairs x 30 tokens; the towers dominate the step).
+Not built: the attention-based predictor variant (xwp_type "attention"; the reference hard-codes "linear") and wti_arch 2 / 3."""
 from collections import OrderedDict
 
 import torch
@@ -88,6 +91,47 @@ class NegNCE(nn.Module):
         return contrastive.neg_nce(sim_matrix, logit_scale, self.c_pos_w, self.c_neg_w, self.margin)
 
 
+class LinearXWeightPredictor(nn.Module):
+    """Token-importance predictor (reference: tpmcl_utils.py:6-50): the query tokens are mapped along their token axis onto the key's
+    token count, concatenated with the key tokens, LayerNorm over the [tokens, 2D] slab, a 2-layer MLP and a sigmoid; weights are
+    normalised to sum 1 over the tokens.  Same parameter names as the reference (q_proj / k_proj are only used when the input widths
+    differ from embed_dim, which never happens on this path)."""
+
+    def __init__(self, num_frames: int, num_tokens: int, embed_dim: int, qk_bias: bool = False, qdim: int = None, kdim: int = None):
+        super().__init__()
+        self.num_frames, self.num_tokens, self.embed_dim = num_frames, num_tokens, embed_dim
+        self.qdim = qdim if qdim is not None else embed_dim
+        self.kdim = kdim if kdim is not None else embed_dim
+        self._qk_same_embed_dim = self.qdim == embed_dim and self.kdim == embed_dim
+        self.q_proj = nn.Linear(self.qdim, embed_dim, bias=qk_bias)
+        self.k_proj = nn.Linear(self.kdim, embed_dim, bias=qk_bias)
+        self.qk_proj = nn.Linear(self.num_frames, self.num_tokens, bias=qk_bias)
+        self.attn_proj = nn.Sequential(nn.LayerNorm([num_tokens, embed_dim * 2]), nn.Linear(embed_dim * 2, embed_dim // 2, bias=False), nn.GELU(),
+                                       nn.Linear(embed_dim // 2, 1, bias=False), nn.Sigmoid())
+
+    def forward(self, q, k):
+        if not self._qk_same_embed_dim:
+            q, k = self.q_proj(q), self.k_proj(k)
+        q = self.qk_proj(q.float().transpose(-2, -1)).transpose(-1, -2)
+        w = self.attn_proj(torch.cat([q, k.float()], dim=-1)).squeeze(-1)
+        return w / w.sum(dim=1, keepdim=True)
+
+
+class TokenImportanceSelector(nn.Module):
+    """Zero the most important tokens: those whose cumulative weight (descending order) is still below `thresh`
+    (reference: tpmcl_utils.py:101-121).  Returns (masked tokens, keep policy)."""
+
+    def __init__(self, thresh):
+        super().__init__()
+        self.register_buffer("thresh", thresh * torch.ones(1))
+
+    def forward(self, x, attn_weight):
+        w_sorted, order = attn_weight.sort(dim=1, descending=True)
+        drop = torch.zeros_like(attn_weight).scatter(1, order, (w_sorted.cumsum(dim=1) < self.thresh).to(attn_weight.dtype))
+        keep = 1.0 - drop
+        return x * keep.unsqueeze(-1).to(x.dtype), keep
+
+
 class DmaeUtils(nn.Module):
     def __init__(self, config=dict()):
         super().__init__()
@@ -104,7 +148,7 @@ class DmaeUtils(nn.Module):
         hidden_size = g("hidden_size", 768)
         assert self.sim_header in ["meanP", "seqTransf"]
         if self.partial_type > 0:
-            raise NotImplementedError("TPM-CL partial-order loss (l3_partial_type > 0): SURVEY.md 8a row L6, not built; set l3_partial_type: -1")
+            self._run_init_tpmcl()
         if "wti" in self.interaction:
             if self.wti_arch != 1:
                 raise NotImplementedError("l3_wti_arch 2 / 3 (MLP weight heads)")
@@ -113,6 +157,14 @@ class DmaeUtils(nn.Module):
         if self.sim_header == "seqTransf":
             self.frame_position_embeddings = nn.Embedding(77, hidden_size)
             self.transformerClip = TransformerClip(width=hidden_size, layers=self.cross_num_hidden_layers, heads=hidden_size // 64)
+
+    def _run_init_tpmcl(self):
+        embed_dim, max_frames = self.config.hidden_size, self.max_frames + 1   # (+1: the [SEP] token appended to the clip tokens)
+        self.xwp_type = "linear"
+        self.t2v_linear_xwp = LinearXWeightPredictor(num_frames=1, num_tokens=max_frames, embed_dim=embed_dim)
+        self.v2t_linear_xwp = LinearXWeightPredictor(num_frames=max_frames, num_tokens=self.max_words, embed_dim=embed_dim)
+        self.tis_selector = TokenImportanceSelector(self.config.get("l3_cis_thresh", 0.6))
+        self.margin = float(self.config.get("l3_margin_loss_thresh", 0.6))
 
     def _agg_visual_feat(self, visual_output, video_mask, sim_header="meanP"):
         """[B, n*e, d] frame tokens + [B, n] mask -> (aggregated tokens, token mask, original tokens), one token per frame."""
@@ -189,5 +241,97 @@ class DmaeUtils(nn.Module):
             visual_mask = visual_mask.view(-1, visual_mask.shape[-1])
         if not loose_type:
             raise NotImplementedError("tight similarity header")
-        simi = self._loose_similarity((text_embed_l1.float().unsqueeze(1), cap_embed), visual_embed, cap_mask, visual_mask, sim_header=self.sim_header)
-        return simi, 0.0
+        cap_output = (text_embed_l1.float().unsqueeze(1), cap_embed)
+        simi = self._loose_similarity(cap_output, visual_embed, cap_mask, visual_mask, sim_header=self.sim_header)
+        margin_loss = 0.0
+        if self.training and self.partial_type > 0:
+            margin_loss = self.get_partial_similarity(cap_output, visual_embed, cap_mask, visual_mask, self.partial_type)
+        return simi, margin_loss
+
+    # ------------------------------------------------------------------ TPM-CL (reference :280-523)
+    def wti_interaction_row(self, text_feat, video_feat, text_mask, video_mask):
+        """One score per ALIGNED pair c (text_feat[c] vs video_feat[c]).  As in the reference, the token weights are contracted with
+        'ct,bt->c' / 'cv,bv->c': the per-token maxima of every pair are weighted by the softmax weights SUMMED over the pair batch."""
+        text_feat, video_feat = text_feat.float(), video_feat.float()
+        text_mask, video_mask = text_mask.float(), video_mask.float()
+        if video_mask.shape[1] > video_feat.shape[1]:
+            video_mask = video_mask[:, :1]
+        elif video_mask.shape[1] != video_feat.shape[1]:
+            video_mask = video_mask.repeat_interleave(video_feat.shape[1] // video_mask.shape[1], dim=1)
+        if text_mask.shape[1] != text_feat.shape[1]:
+            text_mask = text_mask[:, :1]
+        logits = torch.einsum("ctd,cvd->ctv", text_feat, video_feat) * text_mask[:, :, None] * video_mask[:, None, :]
+        t2v, v2t = logits.max(dim=-1).values, logits.max(dim=-2).values
+        if "wti" in self.interaction:
+            tw = self._masked_softmax(self.text_weight_fc, text_feat, text_mask)
+            vw = self._masked_softmax(self.video_weight_fc, video_feat, video_mask)
+            return ((t2v * tw.sum(0)).sum(1) + (v2t * vw.sum(0)).sum(1)) / 2.0
+        return (t2v.sum(1) / text_mask.sum(-1) + v2t.sum(1) / video_mask.sum(-1)) / 2.0
+
+    def _loose_similarity_row(self, sequence_output, visual_output, attention_mask, video_mask, sim_header="meanP"):
+        if "ti" not in self.interaction:
+            raise NotImplementedError(f"interaction:{self.interaction} not implemented")
+        return self.wti_interaction_row(sequence_output.contiguous(), visual_output.contiguous(), attention_mask, video_mask)
+
+    def _get_partial_output(self, sequence_output, visual_output, attention_mask, video_mask, xwp_type="linear", partial_type=-1):
+        """The five [bt, bv] score matrices of one caption x video block that the margin losses use (full vs importance-masked tokens,
+        sentence vs predicted global text feature).  Pair flattenings: "_i" = caption-major (p = i bv + j), "_j" = video-major
+        (p = j bt + i), which is what repeat_interleave / repeat produce in the reference."""
+        if xwp_type != "linear":
+            raise NotImplementedError("attention predictor (the reference passes xwp_type='linear')")
+        sent, words = sequence_output
+        bt, bv = sent.shape[0], visual_output.shape[0]
+        sent_j, wmask_j = sent.repeat(bv, 1, 1), attention_mask.repeat(bv, 1)
+        words_i, wmask_i = words.repeat_interleave(bv, 0), attention_mask.repeat_interleave(bv, 0)
+        vis_i, vmask_i = visual_output.repeat(bt, 1, 1), video_mask.repeat(bt, 1)
+        vis_j, vmask_j = visual_output.repeat_interleave(bt, 0), video_mask.repeat_interleave(bt, 0)
+        word_w = self.v2t_linear_xwp(vis_i, words_i)            # word importance given the video   [bt*bv, Nw]
+        frame_w = self.t2v_linear_xwp(sent_j, vis_j)            # frame importance given the caption [bt*bv, V]
+        glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)
+        glob = (glob / glob.norm(dim=-1, keepdim=True)).unsqueeze(1)
+        out = dict.fromkeys(("t2vh", "t2vhh", "tg2vh", "tg2vhh", "tgh2vh"))
+        if self.training and partial_type >= 2:
+            words_masked, _ = self.tis_selector(words_i.float(), word_w)
+            glob_partial = torch.einsum("abd,ab->ad", words_masked, word_w).unsqueeze(1)
+            vis_masked, _ = self.tis_selector(vis_j.float(), frame_w)
+            vis_partial, vmask_p, _ = self._agg_visual_feat(vis_masked, vmask_j, sim_header=self.sim_header)
+            row = lambda a, b, ma, mb: self._loose_similarity_row(a, b, ma, mb, sim_header=self.sim_header)  # noqa: E731
+            out["t2vhh"] = row(sent_j, vis_partial, wmask_j, vmask_p).reshape(bv, bt).t()
+            out["t2vh"] = row(sent_j, vis_i, wmask_j, vmask_i).reshape(bt, bv)
+            out["tg2vh"] = row(glob, vis_i, wmask_i, vmask_i).reshape(bt, bv)
+            out["tg2vhh"] = row(glob, vis_partial, wmask_i, vmask_p).reshape(bv, bt).t()
+            out["tgh2vh"] = row(glob_partial, vis_i, wmask_i, vmask_i).reshape(bt, bv)
+        return out
+
+    def _get_partial_loss(self, sim_matrix, sim_matrix_bar):
+        """MarginRankingLoss(margin)(diag(anchor), diag(partial), +1): the full-token score of a true pair must beat its
+        importance-masked score by the margin."""
+        if sim_matrix.shape[1] != sim_matrix_bar.shape[1]:
+            sim_matrix_bar = sim_matrix_bar.repeat(1, sim_matrix.shape[1] // sim_matrix_bar.shape[1])
+        return torch.clamp(self.margin - (torch.diagonal(sim_matrix) - torch.diagonal(sim_matrix_bar)), min=0).mean()
+
+    def get_partial_similarity(self, sequence_output, visual_output, attention_mask, video_mask, partial_type=1):
+        sent, words = sequence_output
+        if not (self.training and partial_type >= 2):
+            return 0.0
+        names = ("t2vh", "t2vhh", "tg2vh", "tg2vhh", "tgh2vh")
+        rows = {n: [] for n in names}
+        for t0 in range(0, sent.shape[0], 8):          # the reference's block sizes: 8 captions x 16 videos
+            cols = {n: [] for n in names}
+            blk = (sent[t0:t0 + 8], words[t0:t0 + 8])
+            for v0 in range(0, visual_output.shape[0], 16):
+                o = self._get_partial_output(blk, visual_output[v0:v0 + 16], attention_mask[t0:t0 + 8], video_mask[v0:v0 + 16],
+                                             xwp_type="linear", partial_type=partial_type)
+                for n in names:
+                    cols[n].append(o[n])
+            for n in names:
+                rows[n].append(torch.cat(cols[n], dim=-1))
+        M = {n: torch.cat(rows[n], dim=0) for n in names}
+        if get_world_size() > 1:
+            M = {n: gather_tensor(m.contiguous(), method="cat", back_gradient=True, pad_tensors=True) for n, m in M.items()}
+        loss = 0.0
+        if partial_type in (2, 4):
+            loss = loss + self._get_partial_loss(M["t2vh"], M["t2vhh"]) + self._get_partial_loss(M["tg2vh"], M["tg2vhh"])
+        if partial_type in (3, 4):
+            loss = loss + self._get_partial_loss(M["tg2vh"], M["tgh2vh"])
+        return loss

@@ -118,3 +118,101 @@ def dmae_wti_interaction(P, text_feat, word_feat, video_feat, word_mask, video_m
     if interaction in ("att_ti", "att_wti"):
         out = (out + dmae_wti_similarity(word_feat, video_feat, word_mask, video_mask, ww, vw, with_va, weighted)) / 2.0
     return out
+
+
+# ------------------------------------------------------------------------------ DMAE TPM-CL (partial-order margin losses)
+def _tpm_predictor(Pp, q, k):
+    """LinearXWeightPredictor.forward with qdim = kdim = embed_dim (prj/dmae_vtp/roi_univl/univl/model/tpmcl_utils.py:6-50):
+    q [P, F, D] is mapped along its token axis F -> T by a bias-free Linear, concatenated with k [P, T, D], LayerNorm over the whole
+    [T, 2D] slab, Linear(2D, D/2) -> GELU(erf) -> Linear(D/2, 1) -> sigmoid, then normalised to sum 1 over the T tokens."""
+    qq = torch.matmul(q.transpose(-2, -1), Pp["qk_proj.weight"].t()).transpose(-1, -2)
+    qk = torch.cat([qq, k], dim=-1)
+    h = torch.nn.functional.layer_norm(qk, qk.shape[-2:], Pp["attn_proj.0.weight"], Pp["attn_proj.0.bias"], 1e-5)
+    h = torch.nn.functional.gelu(torch.matmul(h, Pp["attn_proj.1.weight"].t()))
+    w = torch.sigmoid(torch.matmul(h, Pp["attn_proj.3.weight"].t())).squeeze(-1)
+    return w / w.sum(dim=1, keepdim=True)
+
+
+def _tpm_drop_important(x, w, thresh):
+    """TokenImportanceSelector (tpmcl_utils.py:101-121): zero the most important tokens -- those whose cumulative weight, in
+    descending order, is still below `thresh` -- and keep the rest."""
+    sw, order = w.sort(dim=1, descending=True)
+    drop_sorted = (sw.cumsum(dim=1) < thresh).to(w.dtype)
+    drop = torch.zeros_like(w).scatter(1, order, drop_sorted)
+    return x * (1.0 - drop).unsqueeze(-1)
+
+
+def _tpm_row_similarity(P, text, video, tmask, vmask, weighted):
+    """DmaeUtils.wti_interaction_row (dmae_utils.py:476-523): one score per aligned pair c (text[c] vs video[c]).
+    NOTE the reference contracts the token weights with 'ct,bt->c' / 'cv,bv->c': every pair's max-logits are weighted by the SUM over
+    the whole pair batch of the softmax weights -- restated as written."""
+    if vmask.shape[1] != video.shape[1] and vmask.shape[1] > video.shape[1]:
+        vmask = vmask[:, :1]
+    elif vmask.shape[1] != video.shape[1]:
+        vmask = vmask.repeat_interleave(video.shape[1] // vmask.shape[1], dim=1)
+    if tmask.shape[1] != text.shape[1]:
+        tmask = tmask[:, :1]
+    logits = torch.einsum("ctd,cvd->ctv", text, video) * tmask[:, :, None] * vmask[:, None, :]
+    t2v, v2t = logits.max(dim=-1).values, logits.max(dim=-2).values
+    if weighted:
+        def w(fcw, fcb, feat, mask):
+            z = (feat @ fcw.t()).squeeze(-1) + fcb
+            return torch.softmax(z.masked_fill(mask < 0.5, float("-inf")), dim=-1)
+        tw = w(P["text_weight_fc.weight"], P["text_weight_fc.bias"], text, tmask)
+        vw = w(P["video_weight_fc.weight"], P["video_weight_fc.bias"], video, vmask)
+        return ((t2v * tw.sum(0)[None]).sum(1) + (v2t * vw.sum(0)[None]).sum(1)) / 2.0
+    return (t2v.sum(1) / tmask.sum(-1) + v2t.sum(1) / vmask.sum(-1)) / 2.0
+
+
+def dmae_tpmcl_margin_loss(P, text, word, video, word_mask, video_mask, partial_type, cis_thresh=0.6, margin=0.6, interaction="wti"):
+    """DmaeUtils.get_partial_similarity in training mode (dmae_utils.py:280-388 with _get_partial_output :390-463), single process,
+    meanP header, linear predictors.  text [B, 1, D] sentence, word [B, Nw, D], video [B, V, D].
+    Blocks of 8 captions x 16 videos; inside a block every (caption i, video j) pair is formed in two flattenings
+    ("row": p = i * bv + j, "batch": p = j * bt + i, exactly as repeat_interleave / repeat produce them).  Five block matrices are
+    concatenated and only their DIAGONALS enter MarginRankingLoss(margin)(anchor, partial, +1):
+      type 2: (t2vh, t2vhh) + (tg2vh, tg2vhh);  type 3: (tg2vh, tgh2vh);  type 4: all three."""
+    weighted = "wti" in interaction
+    B = text.shape[0]
+    names = ("t2vh", "t2vhh", "tg2vh", "tg2vhh", "tgh2vh")
+    rows = {n: [] for n in names}
+    for t0 in range(0, B, 8):
+        txt, wrd, wmask = text[t0:t0 + 8], word[t0:t0 + 8], word_mask[t0:t0 + 8]
+        bt = txt.shape[0]
+        cols = {n: [] for n in names}
+        for v0 in range(0, B, 16):
+            vid, vmask = video[v0:v0 + 16], video_mask[v0:v0 + 16]
+            bv = vid.shape[0]
+            txt_b, wmask_b = txt.repeat(bv, 1, 1), wmask.repeat(bv, 1)                        # p = j * bt + i
+            wrd_r, wmask_r = wrd.repeat_interleave(bv, 0), wmask.repeat_interleave(bv, 0)      # p = i * bv + j
+            vid_b, vmask_b = vid.repeat(bt, 1, 1), vmask.repeat(bt, 1)                         # p = i * bv + j
+            vid_r, vmask_r = vid.repeat_interleave(bt, 0), vmask.repeat_interleave(bt, 0)      # p = j * bt + i
+            t_w = _tpm_predictor(towers_sub(P, "v2t_linear_xwp."), vid_b, wrd_r)                # word weights given the video
+            v_w = _tpm_predictor(towers_sub(P, "t2v_linear_xwp."), txt_b, vid_r)                # frame weights given the caption
+            seq_g = torch.einsum("abd,ab->ad", wrd_r, t_w)
+            seq_g = (seq_g / seq_g.norm(dim=-1, keepdim=True)).unsqueeze(1)                    # [bt*bv, 1, D], p = i * bv + j
+            seq_gp = torch.einsum("abd,ab->ad", _tpm_drop_important(wrd_r, t_w, cis_thresh), t_w).unsqueeze(1)
+            vid_p = _tpm_drop_important(vid_r, v_w, cis_thresh)                                 # p = j * bt + i
+            sim = lambda a, b, ma, mb: _tpm_row_similarity(P, a, b, ma, mb, weighted)          # noqa: E731
+            cols["t2vhh"].append(sim(txt_b, vid_p, wmask_b, vmask_r).reshape(bv, bt).t())
+            cols["t2vh"].append(sim(txt_b, vid_b, wmask_b, vmask_b).reshape(bt, bv))
+            cols["tg2vh"].append(sim(seq_g, vid_b, wmask_r, vmask_b).reshape(bt, bv))
+            cols["tg2vhh"].append(sim(seq_g, vid_p, wmask_r, vmask_r).reshape(bv, bt).t())
+            cols["tgh2vh"].append(sim(seq_gp, vid_b, wmask_r, vmask_b).reshape(bt, bv))
+        for n in names:
+            rows[n].append(torch.cat(cols[n], dim=-1))
+    M = {n: torch.cat(rows[n], dim=0) for n in names}
+
+    def rank_loss(anchor, partial):
+        return torch.clamp(margin - (torch.diagonal(anchor) - torch.diagonal(partial)), min=0).mean()
+
+    loss = 0.0
+    if partial_type in (2, 4):
+        loss = loss + rank_loss(M["t2vh"], M["t2vhh"]) + rank_loss(M["tg2vh"], M["tg2vhh"])
+    if partial_type in (3, 4):
+        loss = loss + rank_loss(M["tg2vh"], M["tgh2vh"])
+    return loss
+
+
+def towers_sub(P, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in P.items() if k.startswith(prefix)}

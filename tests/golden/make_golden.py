@@ -14,6 +14,7 @@ Fixtures and the reference symbols that produced them:
   loss_mil_nce.pt      get_mil_nce_loss                   prj/base_vtp/roi_univl/univl/model/univl_video_ret.py:146-197
   loss_misc.pt         moco_loss / CrossEn / NegNCE       moco_utils.py:71-81, prj/dmae_vtp/.../dmae_utils.py:528-563
   ops_dmae_seqtransf.pt DmaeUtils._agg_visual_feat(seqTransf)  prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:186-227,574-619
+  ops_dmae_tpmcl.pt    DmaeUtils.get_partial_similarity (TPM-CL margin losses, partial types 2 / 3 / 4)   dmae_utils.py:280-523, tpmcl_utils.py
   ops_dmae_wti.pt      DmaeUtils.wti_interaction (wti / att_wti, with and without the 2nd-frame term)   dmae_utils.py:85-184
   metric_recall.pt     _cal_recall / _cal_sym_recall (retrieval evaluation)   antmmf/modules/metrics/global_retrieval_recall.py:13-103
   m2_ckpt_convert.pt   convert_pl_ckpt / convert_deepspeed_ckpt (position-table resize)   prj/M2_Encoder/vlmo/modules/vlmo_module.py:22-106
@@ -214,6 +215,37 @@ def gen_m2_ckpt_convert():
     save("m2_ckpt_convert.pt", d)
 
 
+def gen_dmae_tpmcl():
+    vtp = L.load_vtp("dmae_vtp")
+    d = {}
+    B, Nw, V, D = 18, 12, 5, 128
+    nrm = torch.nn.functional.normalize
+    text = nrm(W.data_tensor("tpm.text", (B, 1, D)), dim=-1)
+    word = nrm(W.data_tensor("tpm.word", (B, Nw, D)), dim=-1)
+    video = nrm(W.data_tensor("tpm.video", (B, V, D)), dim=-1)
+    wlen = W.data_ints("tpm.wlen", (B,), 3, Nw + 1)
+    word_mask = (torch.arange(Nw)[None, :] < wlen[:, None]).float()
+    video_mask = torch.ones(B, V)
+    d.update(dict(text=text, word=word, video=video, word_mask=word_mask, video_mask=video_mask))
+    for ptype in (2, 3, 4):
+        du = vtp["dmae"].DmaeUtils(L.AttrDict(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header="meanP", l3_partial_type=ptype,
+                                                   l3_max_frames=V - 1, l3_max_words=Nw)))
+        W.fill_module_(du)
+        du.tis_selector.thresh.fill_(0.6)   # the name-keyed fill also hits this buffer: restore the configured l3_cis_thresh
+        du.train()
+        t, w_, v = (x.clone().requires_grad_(True) for x in (text, word, video))
+        loss = du.get_partial_similarity((t, w_), v, word_mask.clone(), video_mask.clone(), ptype)
+        loss.backward()
+        d[f"p{ptype}.loss"] = loss
+        for nm, x in (("dtext", t), ("dword", w_), ("dvideo", v)):   # norms + a probe keep the fixture small
+            g_ = x.grad if x.grad is not None else torch.zeros_like(x)
+            d[f"p{ptype}.{nm}.norm"] = g_.norm()
+            d[f"p{ptype}.{nm}.probe"] = g_.flatten()[:256].clone()
+        for k, g_ in grads_of(du).items():
+            d[f"p{ptype}.{k.replace('grad.', 'gnorm.', 1)}"] = g_.norm()
+    save("ops_dmae_tpmcl.pt", d)
+
+
 def gen_losses():
     vtp = L.load_vtp("base_vtp")
     Ret = vtp["ret"].UnivlForVideoTextRetrieval
@@ -359,6 +391,18 @@ def gen_e2e_dmae_stage3():
         for n, p in model.named_parameters():
             if p.grad is not None:
                 d[f"s3.{loss_type}.gnorm.{n}"] = p.grad.norm()
+    # the same step with TPM-CL switched on (l3_partial_type 4): losses + the new head's gradient norms only
+    cfg = dict(TINY_CLIP_CFG, training_stage="stage1+stage3", l3_loss_type="negNCE", **dict(DMAE_E2E, l3_partial_type=4))
+    model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
+    W.fill_module_(model)
+    model.dmae_utils.tis_selector.thresh.fill_(0.6)
+    model.train()
+    out = model(batch["image"], batch["caption"])
+    (out["losses"]["level1_similarity_loss"] + out["losses"]["level3_similarity_loss"]).backward()
+    d["s3.tpm4.loss3"] = out["losses"]["level3_similarity_loss"]
+    for n, p in model.named_parameters():
+        if p.grad is not None and ("xwp" in n or "weight_fc" in n or n.endswith("text_projection") or n.endswith("visual.proj")):
+            d[f"s3.tpm4.gnorm.{n}"] = p.grad.norm()
     save("e2e_dmae_stage3.pt", d)
 
 
@@ -499,8 +543,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

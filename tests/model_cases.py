@@ -356,6 +356,46 @@ DMAE_E2E = dict(l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_he
                 l3_max_words=12, l3_sim_header_hidden_layer=2)
 
 
+def case_dmae_stage3_tpm(dev_str):
+    """Same model with TPM-CL on (l3_partial_type 4): level-3 loss and the gradient norms of the new head / the tower projections."""
+    return r"""
+import os, sys, torch
+ROOT = %r
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "ant-multi-modal-framework_amd"),
+                os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "dmae_vtp"), ROOT]
+import weightgen as W
+import roi_univl
+from antmmf.common.configuration import Configuration
+from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+dev = torch.device(%r)
+g = torch.load(os.path.join(ROOT, "tests", "golden", "e2e_dmae_stage3.pt"))
+model = UnivlForVideoTextRetrieval(Configuration(dict(%r, training_stage="stage1+stage3", l3_loss_type="negNCE", **dict(%r, l3_partial_type=4))))
+W.fill_module_(model)
+model.dmae_utils.tis_selector.thresh.fill_(0.6)
+model = model.to(dev).train()
+img, ids, mask = g["s3.image_data"].to(dev), g["s3.input_ids"].to(dev), g["s3.input_mask"].to(dev)
+bsz, n_clips = img.shape[0], 4
+img_input = dict(image_data=img, image_pad_mask=torch.zeros(bsz, img.shape[1], 32, 32, dtype=torch.bool, device=dev),
+                 image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz)
+cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
+out = model(img_input, cap_input)
+l3 = out["losses"]["level3_similarity_loss"]
+(out["losses"]["level1_similarity_loss"] + l3).backward()
+r3 = float(g["s3.tpm4.loss3"])
+assert abs(float(l3) - r3) <= 2e-2 * abs(r3), (float(l3), r3)
+named = dict(model.named_parameters())
+bad = []
+for k in g:
+    if k.startswith("s3.tpm4.gnorm."):
+        n = k[len("s3.tpm4.gnorm."):]
+        ref = float(g[k]); got = float(named[n].grad.float().norm()) if named[n].grad is not None else 0.0
+        if ref > 1e-4 and abs(got - ref) > 0.25 * ref:
+            bad.append((n, got, ref))
+assert not bad, bad
+print("okdmae", float(l3), r3)
+""" % (ROOT, dev_str, TINY_CLIP_CFG, DMAE_E2E)
+
+
 def case_dmae_stage3(loss_type="negNCE"):
     """dmae_vtp product model (stage1 + stage3) vs the reference run -- executed in a subprocess because dmae_vtp's package is
     also called roi_univl (it overlays base_vtp's).  Returns the child's output; the caller asserts on "okdmae"."""
@@ -400,6 +440,38 @@ assert len(rel) > 40 and rel[0][0] < 0.25, rel[:5]
 print("okdmae", float(l1), r1, float(l3), r3, rel[:2])
 """
     return code
+
+
+def case_dmae_tpmcl(dev, golden):
+    """DmaeUtils.get_partial_similarity (TPM-CL margin losses, types 2 / 3 / 4) on the device vs the reference run."""
+    from antmmf.common.configuration import Configuration
+
+    g = golden("ops_dmae_tpmcl.pt")
+    mod = load_dmae_utils()
+    res = {}
+    for ptype in (2, 3, 4):
+        du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header="meanP", l3_partial_type=ptype,
+                                              l3_max_frames=4, l3_max_words=12)))
+        W.fill_module_(du)
+        du.tis_selector.thresh.fill_(0.6)
+        du = du.to(dev).train()
+        t, w_, v = (g[k].detach().clone().to(dev).requires_grad_(True) for k in ("text", "word", "video"))
+        loss = du.get_partial_similarity((t, w_), v, g["word_mask"].to(dev), g["video_mask"].to(dev), ptype)
+        ref = float(g[f"p{ptype}.loss"])
+        assert abs(float(loss) - ref) <= 1e-3 * abs(ref), (ptype, float(loss), ref)
+        loss.backward()
+        for nm, x in (("dtext", t), ("dword", w_), ("dvideo", v)):
+            gr = x.grad if x.grad is not None else torch.zeros_like(x)
+            rn = float(g[f"p{ptype}.{nm}.norm"])
+            assert abs(float(gr.norm()) - rn) <= 5e-3 * max(rn, 1e-6), (ptype, nm, float(gr.norm()), rn)
+        named = dict(du.named_parameters())
+        for k in g:
+            if k.startswith(f"p{ptype}.gnorm."):
+                n = k[len(f"p{ptype}.gnorm."):]
+                gn = float(named[n].grad.norm()) if named[n].grad is not None else 0.0
+                assert abs(gn - float(g[k])) <= 5e-3 * max(float(g[k]), 1e-5), (ptype, n, gn, float(g[k]))
+        res[ptype] = (float(loss), ref)
+    return res
 
 
 def case_dmae_wti(dev, golden):

@@ -81,6 +81,20 @@ def test_dmae_stage3_vs_reference(loss_type):
     print(out.stdout[-400:])
 
 
+@SLOW
+def test_dmae_stage3_with_tpmcl_vs_reference():
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", mc.case_dmae_stage3_tpm("cpu")], capture_output=True, text=True, timeout=1500, env=dict(os.environ))
+    assert "okdmae" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    print(out.stdout[-300:])
+
+
+def test_dmae_tpmcl_vs_reference(golden):
+    print(mc.case_dmae_tpmcl(torch.device("cpu"), golden))
+
+
 def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(torch.device("cpu"), golden))
 

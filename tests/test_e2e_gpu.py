@@ -58,6 +58,19 @@ def test_dmae_stage3_vs_reference(loss_type):
     print(out.stdout[-400:])
 
 
+def test_dmae_stage3_with_tpmcl_vs_reference():
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", mc.case_dmae_stage3_tpm("cuda:0")], capture_output=True, text=True, timeout=1500, env=dict(os.environ))
+    assert "okdmae" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    print(out.stdout[-300:])
+
+
+def test_dmae_tpmcl_vs_reference(golden):
+    print(mc.case_dmae_tpmcl(DEV, golden))
+
+
 def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(DEV, golden))
 

@@ -218,6 +218,36 @@ def test_e2e_dmae_stage3(golden):
         assert checked > 55
 
 
+def test_dmae_tpmcl(golden):
+    """DmaeUtils.get_partial_similarity (TPM-CL margin losses, partial types 2 / 3 / 4) vs the reference run, incl. gradients."""
+    import weightgen as W
+
+    g = golden("ops_dmae_tpmcl.pt")
+    D, Nw, V = 128, 12, 5
+    shapes = {"text_weight_fc.weight": (1, D), "text_weight_fc.bias": (1,), "video_weight_fc.weight": (1, D), "video_weight_fc.bias": (1,)}
+    for nm, F_, T_ in (("t2v_linear_xwp", 1, V), ("v2t_linear_xwp", V, Nw)):
+        shapes.update({f"{nm}.q_proj.weight": (D, D), f"{nm}.k_proj.weight": (D, D), f"{nm}.qk_proj.weight": (T_, F_),
+                       f"{nm}.attn_proj.0.weight": (T_, 2 * D), f"{nm}.attn_proj.0.bias": (T_, 2 * D),
+                       f"{nm}.attn_proj.1.weight": (D // 2, 2 * D), f"{nm}.attn_proj.3.weight": (1, D // 2)})
+    for ptype in (2, 3, 4):
+        P = W.fill_dict(shapes)
+        for v in P.values():
+            v.requires_grad_(True)
+        t, w_, v = (g[k].clone().requires_grad_(True) for k in ("text", "word", "video"))
+        loss = losses.dmae_tpmcl_margin_loss(P, t, w_, v, g["word_mask"], g["video_mask"], ptype, cis_thresh=0.6)
+        close(loss, g[f"p{ptype}.loss"], 1e-4, 1e-6)
+        loss.backward()
+        for nm, x in (("dtext", t), ("dword", w_), ("dvideo", v)):
+            gr = x.grad if x.grad is not None else torch.zeros_like(x)
+            close(gr.norm(), g[f"p{ptype}.{nm}.norm"], 2e-3, 1e-6)
+            close(gr.flatten()[:256], g[f"p{ptype}.{nm}.probe"], 2e-3, 1e-6)
+        for k in g:
+            if k.startswith(f"p{ptype}.gnorm."):
+                n = k[len(f"p{ptype}.gnorm."):]
+                gn = P[n].grad.norm() if P[n].grad is not None else torch.tensor(0.0)
+                close(gn, g[k], 3e-3, 1e-6)
+
+
 def moco_queue(name, dim, K):
     import weightgen as W
 
