@@ -176,6 +176,86 @@ void runstag(const char* name, const uint16_t* P, const uint16_t* Q, float* out,
     printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
 }
 
+// ---- next-generation candidate: ONE wave per SIMD (256 threads), 128 x 128 per wave (64 accumulator tiles = 256 registers, in
+// AGPRs), fragments of step k+1 read from LDS while the 64 MFMAs of step k issue (register double buffer), 4-stage DMA ring, one
+// barrier per step.  LDS -> register traffic per step drops from 96 KB (8 waves x (128 + 64) rows) to 64 KB (4 x (128 + 128)).
+template <int INTERLEAVE>
+__global__ __launch_bounds__(256) void k1w(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, T = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[T][T];
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    // DMA: stage = 32 pieces of 1 KiB (16 P + 16 Q), 8 per wave: piece pc = wave * 8 + q
+    const uint16_t* src[8]; int dst[8];
+    for (int q = 0; q < 8; ++q) {
+        const int pc = wave * 8 + q, row = (pc & 15) * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        src[q] = ((pc >> 4) ? Q + (long)(j0 + row) * ld : P + (long)(i0 + row) * ld) + sl;
+        dst[q] = pc * 1024;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 8; ++q) glds16(src[q] + (kt << 5), buf + dst[q]);
+    };
+    bf16x8_t pa[2], qb[2][T];   // P fragments roll through two registers sets; Q fragments are double-buffered across steps
+    auto read_p = [&](int slot, int kt, int t) {
+        const char* ps = smem + (kt % STAGES) * 32768;
+        const int rp = wi * 128 + t * 16 + l15;
+        pa[slot] = *(const bf16x8_t*)(ps + rp * 64 + ((grp ^ swz32(rp)) << 4));
+    };
+    auto read_q = [&](int buf, int kt, int t) {
+        const char* qs = smem + (kt % STAGES) * 32768 + 16384;
+        const int rq = wj * 128 + t * 16 + l15;
+        qb[buf][t] = *(const bf16x8_t*)(qs + rq * 64 + ((grp ^ swz32(rq)) << 4));
+    };
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t);
+    wait_le<16>(); bar();
+    for (int t = 0; t < T; ++t) read_q(0, 0, t);
+    read_p(0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt+1 must have landed before its fragments are read during this step
+        if (kt + 2 < nk) wait_le<8>(); else wait_le<0>();
+        bar();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const bool more = kt + 1 < nk;
+#pragma unroll
+        for (int it = 0; it < T; ++it) {
+            if (INTERLEAVE) {
+                if (it + 1 < T) read_p((it + 1) & 1, kt, it + 1);
+                else if (more) read_p(0, kt + 1, 0);
+                if (more) read_q(cur ^ 1, kt + 1, it);
+            }
+#pragma unroll
+            for (int jt = 0; jt < T; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[cur][jt], pa[it & 1], acc[it][jt], 0, 0, 0);
+            if (!INTERLEAVE) {   // same reads, but after the row's MFMAs (exposes their latency at the next row)
+                if (it + 1 < T) read_p((it + 1) & 1, kt, it + 1);
+                else if (more) read_p(0, kt + 1, 0);
+                if (more) read_q(cur ^ 1, kt + 1, it);
+            }
+        }
+        cur ^= 1;
+    }
+    float s = 0;
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int INTERLEAVE>
+void run1w(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k1w<INTERLEAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k1w<INTERLEAVE>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k1w<INTERLEAVE>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+}
+
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <int MODE>
 __global__ __launch_bounds__(512) void k32(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
@@ -275,6 +355,8 @@ int main() {
         run<0 + 32>("mfma only + LDS-staged store tail", P, Q, out, I, J2, R2);
         runstag<0>("STAGGERED two-group loop (no store)", P, Q, out, I, J2, R2);
         runstag<1>("STAGGERED two-group loop + staged store", P, Q, out, I, J2, R2);
+        run1w<0>("1 wave/SIMD 128x128: reads then 64 mfma", P, Q, out, I, J2, R2);
+        run1w<1>("1 wave/SIMD 128x128: reads interleaved", P, Q, out, I, J2, R2);
         run32<0>("32x32x16: mfma only", P, Q, out, I, J2, R2);
         run32<1>("32x32x16: mfma + lds fragment reads", P, Q, out, I, J2, R2);
         run32<7>("32x32x16: full loop (ring + barrier + reads)", P, Q, out, I, J2, R2);
