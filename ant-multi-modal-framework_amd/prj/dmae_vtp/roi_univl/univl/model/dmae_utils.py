@@ -11,7 +11,7 @@ Built:
   * TPM-CL, the partial-order margin losses (get_partial_similarity / _get_partial_output / wti_interaction_row, :280-523, with
     tpmcl_utils.py's LinearXWeightPredictor and TokenImportanceSelector): a small head over 8 x 16 caption/video blocks, composed
     from torch device ops (no custom kernel: per block it touches ~128 pairs x 30 tokens; the towers dominate the step).
-Not built: the attention-based predictor variant (xwp_type "attention"; the reference hard-codes "linear") and wti_arch 2 / 3."""
+Not built: the attention-based predictor variant (xwp_type "attention"; the reference hard-codes "linear")."""
 from collections import OrderedDict
 
 import torch
@@ -150,10 +150,14 @@ class DmaeUtils(nn.Module):
         if self.partial_type > 0:
             self._run_init_tpmcl()
         if "wti" in self.interaction:
-            if self.wti_arch != 1:
-                raise NotImplementedError("l3_wti_arch 2 / 3 (MLP weight heads)")
-            self.text_weight_fc = nn.Linear(hidden_size, 1)
-            self.video_weight_fc = nn.Linear(hidden_size, 1)
+            def weight_head():  # l3_wti_arch 1: Linear(D, 1); 2 / 3: one / two hidden Linear(D, D) + ReLU in front (reference :35-53)
+                layers = []
+                for _ in range(int(self.wti_arch) - 1):
+                    layers += [nn.Linear(hidden_size, hidden_size), nn.ReLU(inplace=True)]
+                layers.append(nn.Linear(hidden_size, 1))
+                return layers[0] if len(layers) == 1 else nn.Sequential(*layers)
+            assert self.wti_arch in (1, 2, 3)
+            self.text_weight_fc, self.video_weight_fc = weight_head(), weight_head()
         if self.sim_header == "seqTransf":
             self.frame_position_embeddings = nn.Embedding(77, hidden_size)
             self.transformerClip = TransformerClip(width=hidden_size, layers=self.cross_num_hidden_layers, heads=hidden_size // 64)
@@ -183,7 +187,13 @@ class DmaeUtils(nn.Module):
 
     @staticmethod
     def _masked_softmax(fc, feat, mask):
-        z = torch.nn.functional.linear(feat.float(), fc.weight.float(), fc.bias.float()).squeeze(2)   # Linear(D, 1): a [*, D] x [D] reduction
+        x = feat.float()
+        layers = list(fc) if isinstance(fc, nn.Sequential) else [fc]
+        for m in layers[:-1]:   # wti_arch 2 / 3: hidden D x D layers on the fused GEMM; ReLU folded into its epilogue
+            if isinstance(m, nn.Linear):
+                x = HF.linear(x.to(torch.bfloat16).contiguous(), m.weight, m.bias, act="relu").float()
+        last = layers[-1]
+        z = torch.nn.functional.linear(x, last.weight.float(), last.bias.float()).squeeze(2)   # Linear(D, 1): a [*, D] x [D] reduction
         return torch.softmax(z.masked_fill(mask.float() < 0.5, float("-inf")), dim=-1)
 
     def _get_wti_similarity(self, text_feat, video_feat, text_mask, video_mask, text_weight=None, video_weight=None, self_weight=False):
