@@ -287,7 +287,7 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     k_in = X.shape[1]
     if X.shape[0] != tokens or tuple(dW.shape) != (n_out, k_in) or dW.stride(1) != 1:
         raise ValueError("gemm_wgrad_: shape mismatch")
-    need = 16 * n_out * k_in
+    need = 32 * n_out * k_in
     key = dW.device
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < need:

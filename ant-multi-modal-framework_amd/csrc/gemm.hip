@@ -1085,7 +1085,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         static const char* wgs_env = getenv("ANTMMF_WGRAD_WGS");  // experiments only
         const int want_wgs = wgs_env ? atoi(wgs_env) : 256;
         int sp = (want_wgs + tiles - 1) / tiles;
-        if (sp > 16) sp = 16;
+        if (sp > 32) sp = 32;  // (d = 768 towers: 9 output tiles per 768 x 768 weight need 28 splits to fill the 256 CUs)
         if (sp > nk32 / 8) sp = nk32 / 8 > 0 ? nk32 / 8 : 1;
         g.ksteps_per_split = (nk32 + sp - 1) / sp;
         const int zs = (nk32 + g.ksteps_per_split - 1) / g.ksteps_per_split;
@@ -1119,7 +1119,7 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
 }
 
 // dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in]  (fp32 accumulate), with a caller-owned fp32 workspace for the token-split
-// partial sums (the kernel picks the split; workspace_bytes >= 16 * n_out * k_in * 4 always suffices; NULL -> fp32 atomics).
+// partial sums (the kernel picks the split; workspace_bytes >= 32 * n_out * k_in * 4 always suffices; NULL -> fp32 atomics).
 extern "C" int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, long tokens, int n_out, int k_in, long ld_dy, long ld_x,
                                       long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
     if (tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;

@@ -129,7 +129,7 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
 
 /* ---- wgrad: dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in] (fp32 accumulate; both operands token-major bf16).
  * Large 256-aligned problems run a 4-stage LDS-DMA ring with hardware transpose reads, split over the token range;
- * the per-split partial sums go to the caller-owned fp32 `workspace` (>= 16 * n_out * k_in * 4 bytes always suffices;
+ * the per-split partial sums go to the caller-owned fp32 `workspace` (>= 32 * n_out * k_in * 4 bytes always suffices;
  * NULL -> fp32 atomics) and are reduced into dW by a second launch on the same stream.  Replaces the cuBLAS wgrad
  * GEMMs autograd issues for every nn.Linear / in_proj on the path. */
 int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tokens, int n_out, int k_in, int64_t ld_dy,
