@@ -1084,7 +1084,8 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         const int tiles = (I / 256) * (J / 256), nk32 = R / 32;
         static const char* wgs_env = getenv("ANTMMF_WGRAD_WGS");  // experiments only
         const int want_wgs = wgs_env ? atoi(wgs_env) : 256;
-        int sp = (want_wgs + tiles - 1) / tiles;
+        int sp = want_wgs / tiles;  // floor: one resident round of workgroups (36 tiles x 8 splits = 288 would need a second, 12 % full round)
+        if (sp < 1) sp = 1;
         if (sp > 32) sp = 32;  // (d = 768 towers: 9 output tiles per 768 x 768 weight need 28 splits to fill the 256 CUs)
         if (sp > nk32 / 8) sp = nk32 / 8 > 0 ? nk32 / 8 : 1;
         g.ksteps_per_split = (nk32 + sp - 1) / sp;
