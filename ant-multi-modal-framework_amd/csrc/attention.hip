@@ -105,7 +105,9 @@ __device__ __forceinline__ void stage_key_bias(float* kb, const AttnArgs& a, int
 }
 
 // ---- forward ----------------------------------------------------------------------------------------
-template <int NCH>  // keys padded to 32 * NCH
+// DROP: attention-probability dropout compiled in (a separate instantiation: the mask arithmetic in the inner loops costs registers
+// -- with it folded in at run time the no-dropout backward dropped from 3 to 2 waves per SIMD and ran 1.7x slower)
+template <int NCH, bool DROP>  // keys padded to 32 * NCH
 __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int NKP = 32 * NCH, NT = 2 * NCH;
@@ -121,11 +123,19 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
 
     const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
+    // the query fragments of a tile come straight from global memory: the NEXT tile's are requested before the current tile is
+    // processed (PMC: 68 % of the wave cycles were spent parked on s_waitcnt with the loads issued at the point of use)
+    auto q_ptr = [&](int qt) {
+        const int qi = qt * 16 + l15;
+        return a.q + ((long)b * a.Nq + (qi < a.Nq ? qi : a.Nq - 1)) * a.ldq + h * 64 + grp * 8;
+    };
+    bf16x8_t nq0 = {}, nq1 = {};
+    if (wave < nqt) { const bf16_t* p0 = q_ptr(wave); nq0 = load_frag_global(p0); nq1 = load_frag_global(p0 + 32); }
     for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
-        const bf16_t* qp = a.q + ((long)b * a.Nq + qrow) * a.ldq + h * 64 + grp * 8;
-        const bf16x8_t qf0 = load_frag_global(qp), qf1 = load_frag_global(qp + 32);
+        const bf16x8_t qf0 = nq0, qf1 = nq1;
+        if (qt + ATTN_THREADS / 64 < nqt) { const bf16_t* p1 = q_ptr(qt + ATTN_THREADS / 64); nq0 = load_frag_global(p1); nq1 = load_frag_global(p1 + 32); }
         float s[NT][4];
         float m = -INFINITY;
 #pragma unroll
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
             for (int r = 0; r < 4; ++r) { s[t][r] = EXP2F(s[t][r] - m); sum += s[t][r]; }
         sum = grp_sum(sum);
         float inv = sum > 0.f ? fast_rcp(sum) : 0.f;  // applied to the 16 output values, not the Nk probabilities
-        if (a.drop_thr) {  // workgroup-uniform: drop probabilities (the softmax denominator keeps every key, as in the reference)
+        if (DROP) {  // drop probabilities (the softmax denominator keeps every key, as in the reference)
             const uint32_t base = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
 }
 
 // ---- backward 1: dQ (one workgroup per (b, h); K and V token tiles in LDS; waves walk query tiles) ----
-template <int NCH>
+template <int NCH, bool DROP>
 __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int NKP = 32 * NCH;
@@ -192,28 +202,40 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
 
     const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
+    // (unlike the forward / dK-dV kernels this one loads its tile operands at the point of use: with a one-tile-ahead prefetch hipcc
+    // hoists the unrolled LDS fragment reads as well and lands at 256 VGPRs + scratch, i.e. 2 waves per SIMD -- measured slower)
+    bf16x8_t nq0 = {}, nq1 = {}, nd0 = {}, nd1 = {};
+    float nlse = 0.f;
+#define DQ_FETCH(QT)                                                                                      \
+    do {                                                                                                  \
+        const int qi_ = (QT) * 16 + l15;                                                                  \
+        const long tok_ = (long)b * a.Nq + (qi_ < a.Nq ? qi_ : a.Nq - 1);                                 \
+        const bf16_t* qp_ = a.q + tok_ * a.ldq + h * 64 + grp * 8;                                        \
+        const bf16_t* dop_ = a.d_o + tok_ * a.lddo + h * 64 + grp * 8;                                    \
+        nq0 = load_frag_global(qp_); nq1 = load_frag_global(qp_ + 32);                                    \
+        nd0 = load_frag_global(dop_); nd1 = load_frag_global(dop_ + 32);                                  \
+        nlse = a.lse[((long)b * a.heads + h) * a.Nq + (qi_ < a.Nq ? qi_ : a.Nq - 1)];                     \
+    } while (0)
     for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
-        const long tok = (long)b * a.Nq + qrow;
-        const bf16_t* qp = a.q + tok * a.ldq + h * 64 + grp * 8;
-        const bf16_t* dop = a.d_o + tok * a.lddo + h * 64 + grp * 8;
-        const bf16_t* op = a.o + tok * a.ldo + h * 64 + grp * 8;
-        const bf16x8_t qf0 = load_frag_global(qp), qf1 = load_frag_global(qp + 32);
-        const bf16x8_t df0 = load_frag_global(dop), df1 = load_frag_global(dop + 32);
-        // D_q = <dO[q], O[q]> : this lane covers dh 8g..8g+7 and 32+8g..32+8g+7
+        DQ_FETCH(qt);
+        const bf16x8_t qf0 = nq0, qf1 = nq1, df0 = nd0, df1 = nd1;
+        const float lse = nlse;
+        // D_q = <dO[q], O[q]> : this lane covers dh 8g..8g+7 and 32+8g..32+8g+7.  (O is fetched here, not a tile ahead: prefetching it
+        // as well pushes the kernel over the 3-waves-per-SIMD register budget; its latency hides behind the first score MFMAs.)
+        const bf16_t* op = a.o + ((long)b * a.Nq + qrow) * a.ldo + h * 64 + grp * 8;
         float dsum = 0.f;
         {
-            float x[8], y[8];
-            ld8<bf16_t>(dop, x); ld8<bf16_t>(op, y);
+            union { bf16x8_t f; uint4 u; } d0, d1;
+            d0.f = df0; d1.f = df1;
+            const uint4 o0 = *reinterpret_cast<const uint4*>(op), o1 = *reinterpret_cast<const uint4*>(op + 32);
+            const uint32_t dw[8] = {d0.u.x, d0.u.y, d0.u.z, d0.u.w, d1.u.x, d1.u.y, d1.u.z, d1.u.w};
+            const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dsum += x[e] * y[e];
-            ld8<bf16_t>(dop + 32, x); ld8<bf16_t>(op + 32, y);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dsum += x[e] * y[e];
+            for (int e = 0; e < 8; ++e) dsum += bf_lo(dw[e]) * bf_lo(ow[e]) + bf_hi(dw[e]) * bf_hi(ow[e]);
         }
         dsum = grp_sum(dsum);
-        const float lse = a.lse[((long)b * a.heads + h) * a.Nq + qrow];
         // fully masked query (lse = -inf): subtracting +inf makes every z = -inf and exp2(z) = 0 without per-element selects
         const float lse2 = lse == -INFINITY ? INFINITY : lse * LOG2E;
         const uint32_t dbase = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
@@ -236,12 +258,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
                 for (int r = 0; r < 4; ++r) {
                     const float p = EXP2F(sa[r] * scale2 + bb[r] - lse2);  // masked key: bias = -inf -> p = 0
                     float dp = da[r];
-                    if (a.drop_thr) dp = DROPOUT_KEEP(dbase + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr) ? dp * a.drop_scale : 0.f;
+                    if (DROP) dp = DROPOUT_KEEP(dbase + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr) ? dp * a.drop_scale : 0.f;
                     ds[hh][r] = p * (dp - dsum);
                 }
             }
             dsf[c] = pack_frag(ds[0], ds[1]);
         }
+        // request the next tile's operands now: the register-hungry score phase is over, the dQ phase (36 MFMAs) covers the latency
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             LDS_FENCE();
@@ -257,6 +280,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
 }
 
 // ---- backward 2: dK, dV (one workgroup per (b, h); Q and dO token tiles, lse, D in LDS; waves own key tiles) ----
+template <bool DROP>
 __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const AttnArgs a, int NQP) {
     ANTMMF_DYN_LDS(char, smem);
     char* Qs = smem;
@@ -291,14 +315,28 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
 
     const float scale2 = a.scale * LOG2E;
     const int nkt = (a.Nk + 15) >> 4, nqc = NQP >> 5;
-    for (int kt = wave; kt < nkt; kt += ATTN_THREADS / 64) {
+    // next key tile's K / V fragments and key bias are requested one tile ahead (see attn_fwd_kernel)
+    struct KeyIn { bf16x8_t k0, k1, v0, v1; float bias; };
+    auto fetch = [&](int kt) {
         const int ki = kt * 16 + l15;
         const int krow = ki < a.Nk ? ki : a.Nk - 1;
         const bf16_t* kp = a.k + ((long)b * a.Nk + krow) * a.ldk + h * 64 + grp * 8;
         const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
-        const bf16x8_t kf0 = load_frag_global(kp), kf1 = load_frag_global(kp + 32);
-        const bf16x8_t vf0 = load_frag_global(vp), vf1 = load_frag_global(vp + 32);
-        const float kbias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        KeyIn t;
+        t.k0 = load_frag_global(kp); t.k1 = load_frag_global(kp + 32);
+        t.v0 = load_frag_global(vp); t.v1 = load_frag_global(vp + 32);
+        t.bias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        return t;
+    };
+    KeyIn nxt = {};
+    if (wave < nkt) nxt = fetch(wave);
+    for (int kt = wave; kt < nkt; kt += ATTN_THREADS / 64) {
+        const int ki = kt * 16 + l15;
+        const int krow = ki < a.Nk ? ki : a.Nk - 1;
+        const KeyIn cur = nxt;
+        if (kt + ATTN_THREADS / 64 < nkt) nxt = fetch(kt + ATTN_THREADS / 64);
+        const bf16x8_t kf0 = cur.k0, kf1 = cur.k1, vf0 = cur.v0, vf1 = cur.v1;
+        const float kbias = cur.bias;
         f32x4_t dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -320,7 +358,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
                 for (int r = 0; r < 4; ++r) {
                     const float pr = EXP2F(sa[r] * scale2 + kbias - ll[r]);  // masked / padding key or query: -inf -> 0
                     float pd = pr, dp = da[r];
-                    if (a.drop_thr) {
+                    if (DROP) {
                         const int qq = q0 + 4 * grp + r;
                         const bool keep = DROPOUT_KEEP((uint32_t)((((long)b * a.heads + h) * a.Nq + (qq < a.Nq ? qq : a.Nq - 1)) * a.Nk) + krow, a.drop_seed, a.drop_thr);
                         pd = keep ? pr * a.drop_scale : 0.f;
@@ -369,7 +407,8 @@ extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v,
     const int nch = (Nk + 31) / 32;
     const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
 #define FWD(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
-        set_lds(attn_fwd_kernel<N>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N>), grid, block, lds, stream, a); } while (0)
+        if (a.drop_thr) { set_lds(attn_fwd_kernel<N, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, true>), grid, block, lds, stream, a); } \
+        else { set_lds(attn_fwd_kernel<N, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, false>), grid, block, lds, stream, a); } } while (0)
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
     return antmmf_check_launch();
@@ -391,14 +430,15 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
     const int nch = (Nk + 31) / 32;
     const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
 #define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
-        set_lds(attn_bwd_dq_kernel<N>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N>), grid, block, lds, stream, a); } while (0)
+        if (a.drop_thr) { set_lds(attn_bwd_dq_kernel<N, true>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N, true>), grid, block, lds, stream, a); } \
+        else { set_lds(attn_bwd_dq_kernel<N, false>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N, false>), grid, block, lds, stream, a); } } while (0)
     if (nch <= 1) BWDQ(1); else if (nch <= 3) BWDQ(3); else if (nch <= 7) BWDQ(7); else BWDQ(9);
 #undef BWDQ
     int rc = antmmf_check_launch();
     if (rc) return rc;
     const int nqp = ((Nq + 31) / 32) * 32;
     const size_t lds2 = (size_t)nqp * 256 + (size_t)nqp * 8;
-    set_lds(attn_bwd_dkv_kernel, lds2);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, lds2, stream, a, nqp);
+    if (a.drop_thr) { set_lds(attn_bwd_dkv_kernel<true>, lds2); hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, lds2, stream, a, nqp); }
+    else { set_lds(attn_bwd_dkv_kernel<false>, lds2); hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, lds2, stream, a, nqp); }
     return antmmf_check_launch();
 }
