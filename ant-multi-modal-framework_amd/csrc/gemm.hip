@@ -697,6 +697,23 @@ __device__ __forceinline__ void epilogue_store_bf16_staged_raw(const GemmArgs& g
 // prologue does not touch, 4 KiB per wave, four row blocks), so the DMA fill and most of the store drain overlap instead of
 // leaving the CU idle between workgroups (one 128-KiB workgroup per CU: nothing else can hide them).  Ring slots follow a
 // step counter that runs across tiles.  Same tile order as the non-persistent kernel (4 x 8 patches per XCD).
+#ifdef ANTMMF_GEMM_PROF
+// tools/gemm_prof.py: cycles wave 0 of every persistent workgroup spends in {K loops, operand fetch, next-tile prologue, store, tiles}
+__device__ unsigned long long g_gemm_prof[256 * 8];
+extern "C" int antmmf_debug_gemm_prof(unsigned long long* host) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_prof), sizeof(g_gemm_prof)) != hipSuccess) return -1;
+    return 0;
+}
+#define PROF_DECL unsigned long long pt_[5] = {0, 0, 0, 0, 0}, pc_ = 0, pn_
+#define PROF_START() (pc_ = __builtin_readcyclecounter())
+#define PROF_MARK(i) (pn_ = __builtin_readcyclecounter(), pt_[i] += pn_ - pc_, pc_ = pn_)
+#define PROF_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 256) { for (int i_ = 0; i_ < 5; ++i_) g_gemm_prof[blockIdx.x * 8 + i_] = pt_[i_]; } } while (0)
+#else
+#define PROF_DECL
+#define PROF_START() ((void)0)
+#define PROF_MARK(i) ((void)0)
+#define PROF_FLUSH() ((void)0)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, int ntiles) {
     ANTMMF_DYN_LDS(char, smem);
@@ -747,12 +764,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nk) issue(t);
     const bool late = wave >= 4;
+    PROF_DECL;
     for (;;) {
         f32x4_t acc[TI][TJ];
 #pragma unroll
         for (int a = 0; a < TI; ++a)
 #pragma unroll
             for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        PROF_START();
         int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
         // counted vmcnt: conservative when epilogue stores of the previous tile are still in flight (they are younger than the
         // prologue pieces, so "at most N outstanding" still implies the awaited pieces have landed)
@@ -791,6 +810,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
             SCHED_FENCE();
         }
         if (!late) wg_barrier_lds_only();  // every wave has read its last fragments: all four ring slots are free
+        PROF_MARK(0);
         const int ci0 = i0, cj0 = j0;
         if (EPI > 0) epilogue_apply_operands<TI, TJ, EPI>(g, acc, ci0, cj0, wi, wj, lane);
         // the operand loads must be CONSUMED before any DMA piece is issued (else their wait would cover the pieces): an empty asm
@@ -804,6 +824,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
         }
 #endif
         SCHED_FENCE();
+        PROF_MARK(1);
         gs += nk;
         local += per_xcd;
         const bool more = local < xcount;
@@ -814,9 +835,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
             for (int t = 0; t < STAGES - 1; ++t)
                 if (t < nk) issue(t);  // slots gs .. gs+2; the epilogue below stages through slot gs+3
         }
+        PROF_MARK(2);
         char* stage = smem + ((gs + STAGES - 1) & (STAGES - 1)) * 32768 + wave * 4096;
         epilogue_store_bf16_staged_raw<TI, TJ, 4>(g, acc, ci0, cj0, wi, wj, lane, stage);
-        if (!more) return;
+        PROF_MARK(3);
+#ifdef ANTMMF_GEMM_PROF
+        pt_[4] += 1;
+#endif
+        if (!more) { PROF_FLUSH(); return; }
     }
 }
 

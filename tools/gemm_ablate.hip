@@ -1,3 +1,4 @@
+#include <type_traits>
 // gemm_ablate.hip -- ablation of the 256x256x32 4-stage ring GEMM inner loop on gfx950: which component
 // (MFMA issue, LDS fragment reads, workgroup barrier, LDS-DMA stream) bounds it?  Standalone: prints TFLOP/s per variant.
 // Build: hipcc --offload-arch=gfx950 -O3 gemm_ablate.hip -o gemm_ablate
@@ -180,7 +181,7 @@ void runstag(const char* name, const uint16_t* P, const uint16_t* Q, float* out,
 // AGPRs), fragments of step k+1 read from LDS while the 64 MFMAs of step k issue (register double buffer), 4-stage DMA ring, one
 // barrier per step.  LDS -> register traffic per step drops from 96 KB (8 waves x (128 + 64) rows) to 64 KB (4 x (128 + 128)).
 template <int INTERLEAVE>
-__global__ __launch_bounds__(256) void k1w(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+__global__ __launch_bounds__(256) void k1w(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j, int check = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGES = 4, T = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
@@ -214,13 +215,15 @@ __global__ __launch_bounds__(256) void k1w(const uint16_t* __restrict__ P, const
     wait_le<16>(); bar();
     for (int t = 0; t < T; ++t) read_q(0, 0, t);
     read_p(0, 0, 0);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    // the two fragment buffers alternate by step PARITY, unrolled by hand: a run-time buffer index would put qb[][] in scratch
+    auto step = [&](auto curc, auto tailc, int kt) {
+        constexpr int cur = decltype(curc)::value;
+        constexpr bool TAIL = decltype(tailc)::value;   // the last 4 steps carry the end-of-K conditions; the main loop is branch-free
         // stage kt+1 must have landed before its fragments are read during this step
-        if (kt + 2 < nk) wait_le<8>(); else wait_le<0>();
+        if (!TAIL || kt + 2 < nk) wait_le<8>(); else wait_le<0>();
         bar();
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
-        const bool more = kt + 1 < nk;
+        if (!TAIL || kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const bool more = !TAIL || kt + 1 < nk;
 #pragma unroll
         for (int it = 0; it < T; ++it) {
             if (INTERLEAVE) {
@@ -229,19 +232,324 @@ __global__ __launch_bounds__(256) void k1w(const uint16_t* __restrict__ P, const
                 if (more) read_q(cur ^ 1, kt + 1, it);
             }
 #pragma unroll
-            for (int jt = 0; jt < T; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[cur][jt], pa[it & 1], acc[it][jt], 0, 0, 0);
+            for (int jt = 0; jt < T; ++jt) {
+                if (INTERLEAVE == 2)   // accumulator pinned in AGPRs, dst tied to srcC: nothing for the register allocator to shuffle
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[it][jt]) : "v"(qb[cur][jt]), "v"(pa[it & 1]));
+                else acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[cur][jt], pa[it & 1], acc[it][jt], 0, 0, 0);
+            }
             if (!INTERLEAVE) {   // same reads, but after the row's MFMAs (exposes their latency at the next row)
                 if (it + 1 < T) read_p((it + 1) & 1, kt, it + 1);
                 else if (more) read_p(0, kt + 1, 0);
                 if (more) read_q(cur ^ 1, kt + 1, it);
             }
         }
-        cur ^= 1;
-    }
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) { step(C0{}, std::false_type{}, kt); step(C1{}, std::false_type{}, kt + 1); }
+    for (; kt < nk; kt += 2) { step(C0{}, std::true_type{}, kt); step(C1{}, std::true_type{}, kt + 1); }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");   // MFMA -> accumulator read hazard is software-managed for asm MFMAs
     float s = 0;
     for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-    if (s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (check || s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+
+// Fully hand-ordered version of k1w: asm ds_read_b128 (invisible to hipcc's waitcnt pass), asm MFMA with the accumulators pinned in
+// AGPRs, counted lgkmcnt waits.  Step kt multiplies the fragments of stage kt (Q: 8 fragments read during step kt-1; P: fragment
+// `it` read one MFMA row earlier) while it reads the Q fragments of stage kt+1 -> every LDS read has >= one row (8 MFMAs = 128
+// cycles) of cover and the only full drains are the per-step barrier.
+template <int OFF> __device__ __forceinline__ void ldsr128(bf16x8_t& d, uint32_t a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
+__device__ __forceinline__ void mfma_agpr(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+template <int N> __device__ __forceinline__ void lgkm_le(bf16x8_t& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_le8(bf16x8_t& x, bf16x8_t (&q)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%9)" : "+v"(x), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N));
+}
+__global__ __launch_bounds__(256) void k1wa(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j, int check = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, T = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[T][T];
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* src[8]; int dst[8];
+    for (int q = 0; q < 8; ++q) {
+        const int pc = wave * 8 + q, row = (pc & 15) * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        src[q] = ((pc >> 4) ? Q + (long)(j0 + row) * ld : P + (long)(i0 + row) * ld) + sl;
+        dst[q] = pc * 1024;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 8; ++q) glds16(src[q] + (kt << 5), buf + dst[q]);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    // lane part of a fragment address: row (16 t + l15) of the wave's 128-row slab, 16-B slot grp (swizzle depends on l15 only)
+    const uint32_t lp = lds0 + (wi * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    const uint32_t lq = lds0 + 16384 + (wj * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    bf16x8_t pa[2], qb[2][T];
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t);
+    wait_le<16>(); bar();
+    {
+        const uint32_t aq = lq, ap = lp;
+        ldsr128<0>(qb[0][0], aq); ldsr128<1024>(qb[0][1], aq); ldsr128<2048>(qb[0][2], aq); ldsr128<3072>(qb[0][3], aq);
+        ldsr128<4096>(qb[0][4], aq); ldsr128<5120>(qb[0][5], aq); ldsr128<6144>(qb[0][6], aq); ldsr128<7168>(qb[0][7], aq);
+        ldsr128<0>(pa[0], ap);
+    }
+#define K1_ROW(IT, CUR, MORE)                                                                                   \
+    {                                                                                                           \
+        if (MORE) ldsr128<(IT) * 1024>(qb[(CUR) ^ 1][IT], aqn);                                                 \
+        if ((IT) + 1 < T) ldsr128<(((IT) + 1) & 7) * 1024>(pa[((IT) + 1) & 1], apc);                            \
+        else if (MORE) ldsr128<0>(pa[0], apn);                                                                  \
+        /* reads younger than pa[IT]: this row's (0, 1 or 2) */                                                 \
+        if ((IT) == 0) { if (MORE) lgkm_le8<2>(pa[0], qb[CUR]); else lgkm_le8<1>(pa[0], qb[CUR]); }            \
+        else if ((IT) + 1 < T) { if (MORE) lgkm_le<2>(pa[(IT) & 1]); else lgkm_le<1>(pa[(IT) & 1]); }           \
+        else { if (MORE) lgkm_le<2>(pa[(IT) & 1]); else lgkm_le<0>(pa[(IT) & 1]); }                             \
+        mfma_agpr(acc[IT][0], qb[CUR][0], pa[(IT) & 1]); mfma_agpr(acc[IT][1], qb[CUR][1], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][2], qb[CUR][2], pa[(IT) & 1]); mfma_agpr(acc[IT][3], qb[CUR][3], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][4], qb[CUR][4], pa[(IT) & 1]); mfma_agpr(acc[IT][5], qb[CUR][5], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][6], qb[CUR][6], pa[(IT) & 1]); mfma_agpr(acc[IT][7], qb[CUR][7], pa[(IT) & 1]);       \
+    }
+#define K1_STEP(CUR, ISSUE, WAITN, KT)                                                                          \
+    {                                                                                                           \
+        const int kt_ = (KT);                                                                                   \
+        wait_le<WAITN>();                                                                                       \
+        bar();                                                                                                  \
+        if (ISSUE) issue(kt_ + STAGES - 1);                                                                     \
+        const uint32_t apc = lp + (kt_ % STAGES) * 32768, apn = lp + ((kt_ + 1) % STAGES) * 32768, aqn = lq + ((kt_ + 1) % STAGES) * 32768; \
+        /* the last step's look-ahead reads a stale ring slot: harmless, never multiplied */                    \
+        K1_ROW(0, CUR, true) K1_ROW(1, CUR, true) K1_ROW(2, CUR, true) K1_ROW(3, CUR, true) K1_ROW(4, CUR, true) K1_ROW(5, CUR, true) K1_ROW(6, CUR, true) K1_ROW(7, CUR, true) \
+    }
+    int kt = 0;   // nk even, >= 4: branch-free main loop, then the last four steps (one more DMA stage, then none: drain)
+    for (; kt + 4 < nk; kt += 2) { K1_STEP(0, true, 8, kt) K1_STEP(1, true, 8, kt + 1) }
+    K1_STEP(0, true, 8, kt) K1_STEP(1, false, 0, kt + 1) K1_STEP(0, false, 0, kt + 2) K1_STEP(1, false, 0, kt + 3)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float s = 0;
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (check || s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void run1wa(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k1wa), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k1wa, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k1wa, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+    // per-thread accumulator sums must equal the compiler-ordered kernel's bit for bit (same MFMA order over K)
+    const size_t n = (size_t)tiles * 256;
+    std::vector<float> ra(n), rb(n);
+    hipLaunchKernelGGL(k1w<1>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(ra.data(), out, n * 4, hipMemcpyDeviceToHost);
+    hipMemset(out, 0, n * 4);
+    hipLaunchKernelGGL(k1wa, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(rb.data(), out, n * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < n; ++i) bad += (ra[i] != rb[i]) || !(ra[i] == ra[i]);
+    printf("    check vs compiler-ordered kernel: %zu / %zu thread sums differ (sample %.6g %.6g)\n", bad, n, ra[12345], rb[12345]);
+}
+
+__global__ __launch_bounds__(256) void k1wb(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j, int check = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, T = 8;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[T][T];
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* src[8]; int dst[8];
+    for (int q = 0; q < 8; ++q) {
+        const int pc = wave * 8 + q, row = (pc & 15) * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        src[q] = ((pc >> 4) ? Q + (long)(j0 + row) * ld : P + (long)(i0 + row) * ld) + sl;
+        dst[q] = pc * 1024;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 8; ++q) glds16(src[q] + (kt << 5), buf + dst[q]);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    // lane part of a fragment address: row (16 t + l15) of the wave's 128-row slab, 16-B slot grp (swizzle depends on l15 only)
+    const uint32_t lp = lds0 + (wi * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    const uint32_t lq = lds0 + 16384 + (wj * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    bf16x8_t pa[2], qb[2][T];
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t);
+    wait_le<16>(); bar();
+    {
+        const uint32_t aq = lq, ap = lp;
+        ldsr128<0>(qb[0][0], aq); ldsr128<1024>(qb[0][1], aq); ldsr128<2048>(qb[0][2], aq); ldsr128<3072>(qb[0][3], aq);
+        ldsr128<4096>(qb[0][4], aq); ldsr128<5120>(qb[0][5], aq); ldsr128<6144>(qb[0][6], aq); ldsr128<7168>(qb[0][7], aq);
+        ldsr128<0>(pa[0], ap);
+    }
+#define K1_ROWB(IT, CUR, MORE, ISSUE)                                                                                  \
+    {                                                                                                           \
+        if (MORE) ldsr128<(IT) * 1024>(qb[(CUR) ^ 1][IT], aqn);                                                 \
+        if ((IT) + 1 < T) ldsr128<(((IT) + 1) & 7) * 1024>(pa[((IT) + 1) & 1], apc);                            \
+        else if (MORE) ldsr128<0>(pa[0], apn);                                                                  \
+        /* reads younger than pa[IT]: this row's (0, 1 or 2) */                                                 \
+        if ((IT) == 0) { if (MORE) lgkm_le8<2>(pa[0], qb[CUR]); else lgkm_le8<1>(pa[0], qb[CUR]); }            \
+        else if ((IT) + 1 < T) { if (MORE) lgkm_le<2>(pa[(IT) & 1]); else lgkm_le<1>(pa[(IT) & 1]); }           \
+        else { if (MORE) lgkm_le<2>(pa[(IT) & 1]); else lgkm_le<0>(pa[(IT) & 1]); }                             \
+        mfma_agpr(acc[IT][0], qb[CUR][0], pa[(IT) & 1]); mfma_agpr(acc[IT][1], qb[CUR][1], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][2], qb[CUR][2], pa[(IT) & 1]); mfma_agpr(acc[IT][3], qb[CUR][3], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][4], qb[CUR][4], pa[(IT) & 1]); mfma_agpr(acc[IT][5], qb[CUR][5], pa[(IT) & 1]);       \
+        mfma_agpr(acc[IT][6], qb[CUR][6], pa[(IT) & 1]); mfma_agpr(acc[IT][7], qb[CUR][7], pa[(IT) & 1]);       \
+        if (ISSUE) glds16(src[IT] + ((kt_ + STAGES - 1) << 5), smem + ((kt_ + STAGES - 1) % STAGES) * 32768 + dst[IT]); \
+    }
+#define K1_STEPB(CUR, ISSUE, WAITN, KT)                                                                          \
+    {                                                                                                           \
+        const int kt_ = (KT);                                                                                   \
+        wait_le<WAITN>();                                                                                       \
+        bar();                                                                                                  \
+        const uint32_t apc = lp + (kt_ % STAGES) * 32768, apn = lp + ((kt_ + 1) % STAGES) * 32768, aqn = lq + ((kt_ + 1) % STAGES) * 32768; \
+        /* the last step's look-ahead reads a stale ring slot: harmless, never multiplied */                    \
+        K1_ROWB(0, CUR, true, ISSUE) K1_ROWB(1, CUR, true, ISSUE) K1_ROWB(2, CUR, true, ISSUE) K1_ROWB(3, CUR, true, ISSUE) K1_ROWB(4, CUR, true, ISSUE) K1_ROWB(5, CUR, true, ISSUE) K1_ROWB(6, CUR, true, ISSUE) K1_ROWB(7, CUR, true, ISSUE) \
+    }
+    int kt = 0;   // nk even, >= 4: branch-free main loop, then the last four steps (one more DMA stage, then none: drain)
+    for (; kt + 4 < nk; kt += 2) { K1_STEPB(0, true, 8, kt) K1_STEPB(1, true, 8, kt + 1) }
+    K1_STEPB(0, true, 8, kt) K1_STEPB(1, false, 0, kt + 1) K1_STEPB(0, false, 0, kt + 2) K1_STEPB(1, false, 0, kt + 3)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float s = 0;
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (check || s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void run1wb(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k1wb), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k1wb, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k1wb, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+    // per-thread accumulator sums must equal the compiler-ordered kernel's bit for bit (same MFMA order over K)
+    const size_t n = (size_t)tiles * 256;
+    std::vector<float> ra(n), rb(n);
+    hipLaunchKernelGGL(k1w<1>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(ra.data(), out, n * 4, hipMemcpyDeviceToHost);
+    hipMemset(out, 0, n * 4);
+    hipLaunchKernelGGL(k1wb, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(rb.data(), out, n * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < n; ++i) bad += (ra[i] != rb[i]) || !(ra[i] == ra[i]);
+    printf("    check vs compiler-ordered kernel: %zu / %zu thread sums differ (sample %.6g %.6g)\n", bad, n, ra[12345], rb[12345]);
+}
+
+template <int ABL>   // ablations: 1 no DMA in the loop, 2 no barrier, 4 no LDS reads, 8 no waits
+__global__ __launch_bounds__(256) void k1wc(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j, int check = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, T = 8;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
+    const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    f32x4_t acc[T][T];
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* src[8]; int dst[8];
+    for (int q = 0; q < 8; ++q) {
+        const int pc = wave * 8 + q, row = (pc & 15) * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        src[q] = ((pc >> 4) ? Q + (long)(j0 + row) * ld : P + (long)(i0 + row) * ld) + sl;
+        dst[q] = pc * 1024;
+    }
+    auto issue = [&](int kt) {
+        char* buf = smem + (kt % STAGES) * 32768;
+        for (int q = 0; q < 8; ++q) glds16(src[q] + (kt << 5), buf + dst[q]);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    // lane part of a fragment address: row (16 t + l15) of the wave's 128-row slab, 16-B slot grp (swizzle depends on l15 only)
+    const uint32_t lp = lds0 + (wi * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    const uint32_t lq = lds0 + 16384 + (wj * 128 + l15) * 64 + ((grp ^ swz32(l15)) << 4);
+    bf16x8_t pa[4], qb[2][T];
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    for (int t = 0; t < STAGES - 1; ++t) if (t < nk) issue(t);
+    wait_le<16>(); bar();
+    {
+        const uint32_t aq = lq, ap = lp;
+        ldsr128<0>(qb[0][0], aq); ldsr128<1024>(qb[0][1], aq); ldsr128<2048>(qb[0][2], aq); ldsr128<3072>(qb[0][3], aq);
+        ldsr128<4096>(qb[0][4], aq); ldsr128<5120>(qb[0][5], aq); ldsr128<6144>(qb[0][6], aq); ldsr128<7168>(qb[0][7], aq);
+        ldsr128<0>(pa[0], ap); ldsr128<1024>(pa[1], ap); ldsr128<2048>(pa[2], ap);
+    }
+#define K1_ROWC(IT, CUR, ISSUE)                                                                                 \
+    {                                                                                                           \
+        if (!(ABL & 4)) { ldsr128<(IT) * 1024>(qb[(CUR) ^ 1][IT], aqn);                                         \
+        if ((IT) + 3 < T) ldsr128<(((IT) + 3) & 7) * 1024>(pa[((IT) + 3) & 3], apc);                            \
+        else ldsr128<(((IT) + 3) & 7) * 1024>(pa[((IT) + 3) & 3], apn); }                                       \
+        /* P fragments are read three rows ahead; row 0 also needs the previous step's last Q reads */          \
+        if (!(ABL & 8)) { if ((IT) == 0) lgkm_le8<2>(pa[0], qb[CUR]); else lgkm_le<6>(pa[(IT) & 3]); }                              \
+        mfma_agpr(acc[IT][0], qb[CUR][0], pa[(IT) & 3]); mfma_agpr(acc[IT][1], qb[CUR][1], pa[(IT) & 3]);       \
+        mfma_agpr(acc[IT][2], qb[CUR][2], pa[(IT) & 3]); mfma_agpr(acc[IT][3], qb[CUR][3], pa[(IT) & 3]);       \
+        mfma_agpr(acc[IT][4], qb[CUR][4], pa[(IT) & 3]); mfma_agpr(acc[IT][5], qb[CUR][5], pa[(IT) & 3]);       \
+        mfma_agpr(acc[IT][6], qb[CUR][6], pa[(IT) & 3]); mfma_agpr(acc[IT][7], qb[CUR][7], pa[(IT) & 3]);       \
+        if (ISSUE && !(ABL & 1)) glds16(src[IT] + (((kt_ + STAGES - 1) & kmask) << 5), smem + ((kt_ + STAGES - 1) % STAGES) * 32768 + dst[IT]); \
+    }
+#define K1_STEPC(CUR, ISSUE, WAITN, KT)                                                                          \
+    {                                                                                                           \
+        const int kt_ = (KT);                                                                                   \
+        if (!(ABL & 8)) wait_le<WAITN>();                                                                       \
+        if (!(ABL & 2)) bar();                                                                                                  \
+        const uint32_t apc = lp + (kt_ % STAGES) * 32768, apn = lp + ((kt_ + 1) % STAGES) * 32768, aqn = lq + ((kt_ + 1) % STAGES) * 32768; \
+        /* the last step's look-ahead reads a stale ring slot: harmless, never multiplied */                    \
+        K1_ROWC(0, CUR, ISSUE) K1_ROWC(1, CUR, ISSUE) K1_ROWC(2, CUR, ISSUE) K1_ROWC(3, CUR, ISSUE) K1_ROWC(4, CUR, ISSUE) K1_ROWC(5, CUR, ISSUE) K1_ROWC(6, CUR, ISSUE) K1_ROWC(7, CUR, ISSUE) \
+    }
+    const int kmask = check == 3 ? 3 : -1;   // 3: refetch the same four K-slices (cache-hot DMA: isolates memory latency)
+    const unsigned long long c0_ = __builtin_readcyclecounter(), r0_ = __builtin_amdgcn_s_memrealtime();
+    int kt = 0;   // nk even, >= 4: branch-free main loop, then the last four steps (one more DMA stage, then none: drain)
+    for (; kt + 4 < nk; kt += 2) { K1_STEPC(0, true, 8, kt) K1_STEPC(1, true, 8, kt + 1) }
+    K1_STEPC(0, true, 8, kt) K1_STEPC(1, false, 0, kt + 1) K1_STEPC(0, false, 0, kt + 2) K1_STEPC(1, false, 0, kt + 3)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (check >= 2) {
+        const unsigned long long c1_ = __builtin_readcyclecounter(), r1_ = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) { out[blockIdx.x * 2] = (float)(c1_ - c0_); out[blockIdx.x * 2 + 1] = (float)(r1_ - r0_); }
+        return;
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float s = 0;
+    for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (check || s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void run1wc(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k1wc<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k1wc<0>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(k1wc<0>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
+    // per-thread accumulator sums must equal the compiler-ordered kernel's bit for bit (same MFMA order over K)
+    const size_t n = (size_t)tiles * 256;
+    std::vector<float> ra(n), rb(n);
+    hipLaunchKernelGGL(k1w<1>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(ra.data(), out, n * 4, hipMemcpyDeviceToHost);
+    hipMemset(out, 0, n * 4);
+    hipLaunchKernelGGL(k1wc<0>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 1);
+    hipMemcpy(rb.data(), out, n * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < n; ++i) bad += (ra[i] != rb[i]) || !(ra[i] == ra[i]);
+    for (int mode = 2; mode <= 3; ++mode) {
+        hipLaunchKernelGGL(k1wc<0>, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, mode);
+        std::vector<float> cc((size_t)tiles * 2);
+        hipMemcpy(cc.data(), out, cc.size() * 4, hipMemcpyDeviceToHost);
+        double cs = 0, rs = 0; for (int t = 0; t < tiles; ++t) { cs += cc[2 * t]; rs += cc[2 * t + 1]; }
+        printf("    K loop%s: %.0f cycles per step (ideal 1024 = 64 MFMA x 16), shader clock %.2f GHz (cycles / 100 MHz realtime)\n", mode == 3 ? " [cache-hot DMA]" : "", cs / tiles / nk, cs / rs * 0.1);
+    }
+    {
+        auto abl = [&](auto kern, const char* what) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R, nk, J / 256, 2);
+            std::vector<float> cc((size_t)tiles * 2);
+            hipMemcpy(cc.data(), out, cc.size() * 4, hipMemcpyDeviceToHost);
+            double cs = 0; for (int t = 0; t < tiles; ++t) cs += cc[2 * t];
+            printf("    K loop, %-34s %.0f cycles per step\n", what, cs / tiles / nk);
+        };
+        abl(&k1wc<1>, "no DMA issue:"); abl(&k1wc<2>, "no barrier:"); abl(&k1wc<4>, "no LDS reads:"); abl(&k1wc<8>, "no waits:");
+        abl(&k1wc<3>, "no DMA, no barrier:"); abl(&k1wc<6>, "no barrier, no reads:"); abl(&k1wc<15>, "MFMA only:");
+    }
+    printf("    check vs compiler-ordered kernel: %zu / %zu thread sums differ (sample %.6g %.6g)\n", bad, n, ra[12345], rb[12345]);
+}
+
 template <int INTERLEAVE>
 void run1w(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
     const int tiles = (I / 256) * (J / 256), nk = R / 32;
@@ -357,6 +665,10 @@ int main() {
         runstag<1>("STAGGERED two-group loop + staged store", P, Q, out, I, J2, R2);
         run1w<0>("1 wave/SIMD 128x128: reads then 64 mfma", P, Q, out, I, J2, R2);
         run1w<1>("1 wave/SIMD 128x128: reads interleaved", P, Q, out, I, J2, R2);
+        run1w<2>("1 wave/SIMD 128x128: interleaved, asm mfma (AGPR)", P, Q, out, I, J2, R2);
+        run1wa("1 wave/SIMD 128x128: hand-ordered asm loop", P, Q, out, I, J2, R2);
+        run1wb("1 wave/SIMD 128x128: + DMA between MFMA rows", P, Q, out, I, J2, R2);
+        run1wc("1 wave/SIMD 128x128: + P reads 3 rows ahead", P, Q, out, I, J2, R2);
         run32<0>("32x32x16: mfma only", P, Q, out, I, J2, R2);
         run32<1>("32x32x16: mfma + lds fragment reads", P, Q, out, I, J2, R2);
         run32<7>("32x32x16: full loop (ring + barrier + reads)", P, Q, out, I, J2, R2);
