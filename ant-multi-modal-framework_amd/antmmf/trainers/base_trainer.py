@@ -11,8 +11,11 @@ keys the loop reads, `_forward_pass / _extract_loss / _backward / _update_meter`
   * `current_iteration` advances ONCE per batch (the reference increments it twice, base_trainer.py:551,589, so its
     max_iterations / lr steps count half-steps; documented deviation, see DESIGN.md);
   * the per-iteration reduce_dict of losses is skipped when the model already returns globally reduced losses.
-Data loading (task_loader), checkpointing, validation and early stopping are outside the step path: `load_task()` takes a
-user-supplied iterable of SampleLists (tests / bench feed synthetic ones).
+Checkpointing (antmmf.common.checkpoint.Checkpoint, same files and keys as the reference's) is active when
+`training_parameters.save_dir` / `resume_file` / `resume` is set: `load()` restores, `train()` snapshots every
+`snapshot_interval` iterations and writes `<model>_final.pth` at the end (reference: base_trainer.py:184-218,373-397,555-607).
+Data loading (task_loader), validation and early stopping are outside the step path: `load_task()` takes a user-supplied
+iterable of SampleLists (tests / bench feed synthetic ones).
 """
 import math
 import os
@@ -37,6 +40,7 @@ class BaseTrainer:
         self.current_iteration = 0
         self.current_epoch = 0
         self.meters = {}
+        self.checkpoint = None
 
     # ------------------------------------------------------------------ load
     def load(self):
@@ -49,6 +53,19 @@ class BaseTrainer:
         self.gradient_accumulation_steps = max(1, int(tp.get("update_frequency", 1)))
         self.should_clip_gradients = bool(tp.get("clip_gradients", False))
         self.max_grad_l2_norm = tp.get("max_grad_l2_norm", None)
+        self.snapshot_interval = tp.get("snapshot_interval", None)
+        self.load_extras()
+
+    def load_extras(self):
+        """Checkpoint restore (reference: base_trainer.py:373-397).  Opt-in: without save_dir / resume* nothing touches the disk."""
+        tp = self.config.training_parameters
+        self.checkpoint = None
+        if tp.get("save_dir", None) or tp.get("resume_file", None) or tp.get("resume", False):
+            from antmmf.common.checkpoint import Checkpoint
+
+            self.checkpoint = Checkpoint(self, load_only=not tp.get("save_dir", None))
+            self.checkpoint.load_state_dict()
+            synchronize()
 
     def _init_process_group(self):
         tp = self.config.training_parameters
@@ -108,7 +125,13 @@ class BaseTrainer:
             if self.current_iteration % self.log_interval == 0 and is_main_process():
                 dt = time.perf_counter() - t0
                 print(f"iter {self.current_iteration}: " + ", ".join(f"{k}={v:.5f}" for k, v in self.meters.items()) + f" ({dt:.1f}s)", flush=True)
+            if (self.checkpoint is not None and self.snapshot_interval and self.checkpoint.save_dir_enabled
+                    and self.current_iteration % self.snapshot_interval == 0
+                    and self.current_iteration % self.gradient_accumulation_steps == 0):
+                self.checkpoint.save(self.current_iteration)
         synchronize()
+        if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
+            self.checkpoint.finalize()
         return self.meters
 
     def _forward_pass(self, batch, enable_amp=False):

@@ -1,0 +1,163 @@
+"""antmmf.common.checkpoint (reference antmmf/common/checkpoint.py:79-356): file layout, reference-style key
+handling, pretrained_mapping, and bit-exact resume of the flat-arena optimizer.  Runs the fused AdamW / cast kernels on the CPU lane
+emulator."""
+import os
+import subprocess
+import warnings
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu():
+    from test_kernels_emu import _stale
+
+    if _stale():
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    from antmmf.hip import _lib
+
+    old = os.environ.get("ANTMMF_HIP_LIB")
+    os.environ["ANTMMF_HIP_LIB"] = EMU_LIB
+    _lib.reset_for_tests()
+    yield
+    if old is None:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+    else:
+        os.environ["ANTMMF_HIP_LIB"] = old
+    _lib.reset_for_tests()
+
+
+def _toy():
+    from antmmf.common.registry import registry
+    from antmmf.models.base_model import BaseModel
+    from antmmf.optimizer import build_optimizer
+    from antmmf.trainers.base_trainer import BaseTrainer
+
+    @registry.register_model("toy_ckpt")
+    class Toy(BaseModel):
+        def build(self):
+            self.enc_a = torch.nn.Linear(8, 8)
+            self.enc_b = torch.nn.Linear(8, 8)
+            self.norm = torch.nn.LayerNorm(8)
+
+        def forward(self, sample_list):
+            y = self.norm(self.enc_b(torch.tanh(self.enc_a(sample_list["image_data"]))))
+            return {"losses": {"toy_loss": ((y - sample_list["caption_target"]) ** 2).mean()}}
+
+    class ArenaTrainer(BaseTrainer):  # CPU tensors, but the MI355X optimizer path: flat arena + fused AdamW (emulated)
+        def load_optimizer(self):
+            self.optimizer = build_optimizer(self.model, self.config, use_hip_arena=True)
+            self.arena = self.optimizer.arena
+            self.lr_scheduler = None
+
+    return ArenaTrainer
+
+
+def _cfg(tmp, **tp):
+    from antmmf.common.configuration import Configuration
+
+    base = {"trainer": "base_trainer", "device": "cpu", "max_iterations": 4, "log_interval": 100, "seed": 7, "save_dir": str(tmp),
+            "snapshot_interval": 2}
+    base.update(tp)
+    return Configuration({"training_parameters": base, "task_attributes": {"toy_task": {}},
+                          "optimizer_attributes": {"type": "AdamW", "params": {"lr": 0.05, "weight_decay": 0.01}},
+                          "model_attributes": {"toy_ckpt": {}}})
+
+
+def _batches():
+    from antmmf.structures.sample import SampleList
+
+    g = torch.Generator().manual_seed(11)
+    return [SampleList(image_data=torch.randn(6, 8, generator=g), caption_target=torch.randn(6, 8, generator=g)) for _ in range(4)]
+
+
+def test_layout_and_bit_exact_resume(tmp_path):
+    Trainer = _toy()
+    batches = _batches()
+    full = Trainer(_cfg(tmp_path / "a"), batches)
+    full.load()
+    full.train()
+    folder = tmp_path / "a" / "toy_task_toy_ckpt_7"
+    assert (folder / "config.yaml").is_file() and (folder / "toy_ckpt_final.pth").is_file()
+    assert sorted(os.listdir(folder / "models")) == ["model_2.ckpt", "model_4.ckpt"]
+    ck = torch.load(folder / "models" / "model_2.ckpt", weights_only=False)
+    assert set(ck) >= {"model", "optimizer", "current_iteration", "current_epoch", "best_iteration", "best_metric_value"}
+    assert ck["current_iteration"] == 2 and set(ck["model"]) == set(full.model.state_dict())
+    final = torch.load(folder / "toy_ckpt_final.pth", weights_only=False)
+    for k, v in full.model.state_dict().items():
+        assert torch.equal(final[k], v)
+
+    # resume from iteration 2 with the optimizer state, run the remaining batches: identical weights and moments, bit for bit
+    resumed = Trainer(_cfg(tmp_path / "b", resume_file=str(folder / "models" / "model_2.ckpt")), batches[2:])
+    resumed.load()
+    assert resumed.current_iteration == 2 and resumed.optimizer._step == 2
+    for p in resumed.model.parameters():  # the bf16 compute shadow follows the loaded masters
+        assert torch.equal(p._antmmf_bf16, p.data.to(torch.bfloat16))
+    resumed.train()
+    assert resumed.current_iteration == 4
+    assert torch.equal(resumed.arena.master, full.arena.master)
+    assert torch.equal(resumed.optimizer.exp_avg, full.optimizer.exp_avg) and torch.equal(resumed.optimizer.exp_avg_sq, full.optimizer.exp_avg_sq)
+
+    # restart: weights only, iteration counter and moments start over
+    fresh = Trainer(_cfg(tmp_path / "c", resume_file=str(folder / "models" / "model_2.ckpt"), restart=True, max_ckpt_num=1), batches)
+    fresh.load()
+    assert fresh.current_iteration == 0 and fresh.optimizer._step == 0 and float(fresh.optimizer.exp_avg.abs().sum()) == 0.0
+    assert torch.equal(fresh.model.enc_a.weight, ck["model"]["enc_a.weight"])
+    fresh.train()
+    assert os.listdir(tmp_path / "c" / "toy_task_toy_ckpt_7" / "models") == ["model_4.ckpt"]  # max_ckpt_num prunes the older snapshot
+
+
+def test_reference_style_keys_and_pretrained_mapping(tmp_path):
+    Trainer = _toy()
+    tr = Trainer(_cfg(tmp_path / "m", load_pretrained=True, pretrained_mapping={"enc_a": "enc_b"}), _batches())
+    tr.load()
+    g = torch.Generator().manual_seed(5)
+    src = {
+        "module.enc_a.weight": torch.randn(8, 8, generator=g),   # written by a DDP-wrapped reference run
+        "module.enc_a.bias": torch.randn(8, generator=g),
+        "module.norm.weight": torch.randn(9, generator=g),       # shape mismatch: skipped
+        "module.head.weight": torch.randn(2, 2, generator=g),    # not in the model: skipped
+    }
+    path = tmp_path / "ref_style.ckpt"
+    torch.save({"model": src}, path)
+    before_norm = tr.model.norm.weight.detach().clone()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr.checkpoint.load_model_weights(str(path))
+    msgs = " ".join(str(x.message) for x in w)
+    assert "module.head.weight" not in msgs and "head.weight" in msgs and "norm.weight" in msgs
+    assert torch.equal(tr.model.enc_a.weight, src["module.enc_a.weight"]) and torch.equal(tr.model.enc_a.bias, src["module.enc_a.bias"])
+    assert torch.equal(tr.model.norm.weight, before_norm)
+    # pretrained_mapping {"enc_a": "enc_b"}: the enc_a sub-tree of the checkpoint is also copied onto enc_b
+    assert torch.equal(tr.model.enc_b.weight, src["module.enc_a.weight"]) and torch.equal(tr.model.enc_b.bias, src["module.enc_a.bias"])
+    assert torch.equal(tr.model.enc_b.weight._antmmf_bf16, src["module.enc_a.weight"].to(torch.bfloat16))
+    # a bare state_dict (the *_final.pth form) loads the same way; force=True ignores the mapping
+    torch.save({"enc_a.weight": torch.zeros(8, 8)}, tmp_path / "bare.pth")
+    tr.checkpoint.load_model_weights(str(tmp_path / "bare.pth"), force=True)
+    assert float(tr.model.enc_a.weight.abs().sum()) == 0.0 and torch.equal(tr.model.enc_b.weight, src["module.enc_a.weight"])
+    with pytest.raises(RuntimeError):
+        bad = Trainer(_cfg(tmp_path / "x", resume_file=str(tmp_path / "missing.ckpt")), _batches())
+        bad.load()
+
+
+def test_reference_parameter_names_exist_in_this_build(golden):
+    """State-dict compatibility (8(f1)): every trainable parameter name the REFERENCE models expose (recorded by
+    tests/golden/make_golden.py next to the gradient norms) is a key of this build's state_dict for the same configuration."""
+    import model_cases as mc
+
+    dev = torch.device("cpu")
+    g = golden("e2e_clip_arch.pt")
+    ref = {k.split(".gnorm.", 1)[1] for k in g if ".gnorm." in k}
+    own = set(mc.build_tiny_univl(dev).state_dict())
+    assert len(ref) > 50 and ref <= own, sorted(ref - own)[:5]
+    g = golden("e2e_clip_moco.pt")
+    ref = {k.split(".gnorm1.", 1)[1] for k in g if ".gnorm1." in k}
+    assert len(ref) > 50 and ref <= own, sorted(ref - own)[:5]
+    g = golden("e2e_m2.pt")
+    ref = {k.split("gnorm.", 1)[1] for k in g if k.startswith("gnorm.")}
+    own = set(mc.build_tiny_m2(dev).state_dict())
+    assert len(ref) > 50 and ref <= own, sorted(ref - own)[:5]
