@@ -1,0 +1,99 @@
+"""Input-pipeline step in front of the image tower: batched, Pillow-exact bicubic resize on the device.
+
+Reference: `square_transform(size)` = torchvision Resize((size, size), BICUBIC) + ToTensor, applied per image on the CPU
+(prj/M2_Encoder/vlmo/transforms/square_transform.py:8-14; prj/M2_Encoder/m2_encoder.py:61-68); the arithmetic is Pillow's
+src/libImaging/Resample.c.  Here the host only builds the coefficient tables (a few KB per distinct image extent, cached) and one
+descriptor row per image; the byte work for the whole ragged batch is two kernel launches (csrc/resize.hip).
+"""
+import functools
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _rc, _stream
+
+PRECISION_BITS = 22  # Resample.c: 32 - 8 - 2
+
+
+@functools.lru_cache(maxsize=4096)
+def bicubic_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter (a = -0.5, support 2) over the full extent, in
+    the same double-precision statement order (the per-pixel weight sum is accumulated tap by tap, not pairwise).
+    -> (taps per output, bounds int32 [out, 2] = (first tap, tap count), coeffs int32 [out, taps])"""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    a = -0.5
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.abs((np.arange(xmax, dtype=np.float64) + xmin - center + 0.5) * ss)
+        w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+        ww = float(np.cumsum(w)[-1]) if xmax > 0 else 0.0  # sequential sum, like the C loop
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = np.trunc(np.where(w < 0, -0.5 + w * (1 << PRECISION_BITS), 0.5 + w * (1 << PRECISION_BITS))).astype(np.int32)
+        bounds[xx] = (xmin, xmax)
+    return ksize, bounds, kk
+
+
+def resize_bicubic_u8(images, out_h, out_w, out_f32=True, device=None):
+    """images: sequence of uint8 [h, w, C] tensors (any sizes, same C; host tensors are uploaded) ->
+    float32 [n, C, out_h, out_w] = resized / 255 (out_f32, what Resize + ToTensor returns) or uint8 [n, out_h, out_w, C]
+    (byte-identical to PIL `Image.resize((out_w, out_h), BICUBIC)`)."""
+    if len(images) == 0:
+        raise ValueError("resize_bicubic_u8: empty batch")
+    C = images[0].shape[2]
+    for t in images:
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != C or t.shape[0] < 1 or t.shape[1] < 1:
+            raise ValueError("resize_bicubic_u8: images must be uint8 [h, w, C] with a common channel count")
+    if device is None:
+        if _lib.backend() == 1:  # decoded frames arrive in host memory: they are uploaded, the resize runs on the GPU
+            device = next((t.device for t in images if t.is_cuda), torch.device("cuda", torch.cuda.current_device()))
+        else:
+            device = torch.device("cpu")  # CPU lane emulator (tests)
+    if (torch.device(device).type == "cuda") != (_lib.backend() == 1):
+        raise RuntimeError("resize_bicubic_u8: device does not match the loaded library (gfx950 library <-> cuda tensors; no CPU fallback)")
+    desc = np.zeros((len(images), 10), dtype=np.int64)
+    tabs, btabs, where = [], [], {}
+    n_coef = n_bound = 0
+
+    def table(in_size, out_size):
+        nonlocal n_coef, n_bound
+        if in_size == out_size:  # Pillow skips a pass whose extent does not change
+            return 0, 0, 0
+        key = (in_size, out_size)
+        if key not in where:
+            ks, b, k = bicubic_coeffs(in_size, out_size)
+            where[key] = (n_coef, ks, n_bound)
+            tabs.append(k.reshape(-1)); btabs.append(b.reshape(-1))
+            n_coef += k.size; n_bound += b.size
+        return where[key]
+
+    src_off = tmp_off = 0
+    for i, t in enumerate(images):
+        h, w = int(t.shape[0]), int(t.shape[1])
+        kx_off, kx, bx_off = table(w, out_w)
+        ky_off, ky, by_off = table(h, out_h)
+        desc[i] = (src_off, h, w, tmp_off, kx_off, kx, bx_off, ky_off, ky, by_off)
+        src_off += h * w * C
+        tmp_off += h * out_w * C
+    src = torch.cat([t.reshape(-1).to(device, non_blocking=True) for t in images])
+    coeffs = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, np.int32)).to(device)
+    bounds = torch.from_numpy(np.concatenate(btabs) if btabs else np.zeros(2, np.int32)).to(device)
+    desc_d = torch.from_numpy(desc).to(device)
+    tmp = torch.empty(max(tmp_off, 4), dtype=torch.uint8, device=device)
+    n = len(images)
+    out = (torch.empty(n, C, out_h, out_w, dtype=torch.float32, device=device) if out_f32
+           else torch.empty(n, out_h, out_w, C, dtype=torch.uint8, device=device))
+    _rc(_lib.load().antmmf_resize_bicubic_u8(_p(src), src.numel(), _p(desc_d), n, int(desc[:, 1].max()), int(desc[:, 2].max()), C, out_h, out_w,
+                                            _p(coeffs), _p(bounds), _p(tmp), _p(out), 1 if out_f32 else 0, _stream()), "antmmf_resize_bicubic_u8")
+    return out

@@ -133,3 +133,18 @@ def test_milnce(ops):
 def test_softmax_ce(ops):
     kc.case_softmax_ce(ops, DEV)
     kc.case_softmax_ce(ops, DEV, Bg=640, world=4)
+
+
+def test_resize_bicubic_vs_pillow_goldens(ops, golden):
+    import resize_cases as rc
+
+    print(rc.case_goldens(DEV, golden))
+
+
+def test_resize_bicubic_full_size_ragged_batch_vs_oracle(ops):
+    """Photo-sized, ragged batch to the 224 x 224 tower input: every byte equal to the oracle (= Pillow); includes extents that skip a
+    pass, an upscale, a 1-pixel-high strip and a row longer than 64 KB."""
+    import resize_cases as rc
+
+    sizes = [(1080, 1920), (1920, 1080), (480, 640), (224, 224), (224, 600), (700, 224), (100, 150), (1, 300), (300, 1), (64, 23000), (2160, 3840)]
+    print(rc.case_vs_oracle(DEV, sizes, 224, seed=5))

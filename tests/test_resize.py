@@ -1,0 +1,82 @@
+"""Image resize step: oracle vs Pillow goldens, host coefficient tables, and the kernels on the CPU lane emulator."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import resize_cases as rc
+from resize_cases import oresize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+
+
+def test_oracle_equals_pillow_goldens(golden):
+    g = golden("resize_bicubic.pt")
+    for i, (h, w, c, oh, ow) in enumerate(g["cases"]):
+        got = oresize.resize_bicubic_u8(g[f"in{i}"].numpy(), oh, ow)
+        assert np.array_equal(got, g[f"out{i}"].numpy()), (i, h, w, c, oh, ow)
+
+
+def test_oracle_equals_pillow_live():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    for h, w, s in ((480, 640, 224), (224, 500, 224), (77, 31, 224), (1080, 1920, 224)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((s, s), Image.BICUBIC))
+        assert np.array_equal(oresize.resize_bicubic_u8(img, s, s), ref), (h, w)
+
+
+def test_host_coefficient_tables_equal_the_oracles():
+    from antmmf.hip.image import bicubic_coeffs
+
+    for n_in, n_out in ((640, 224), (100, 224), (225, 224), (1, 8), (4000, 224), (37, 32), (2, 16)):
+        ks, b, k = bicubic_coeffs(n_in, n_out)
+        oks, ob, ok = oresize.precompute_coeffs(n_in, n_out)
+        assert ks == oks and np.array_equal(b, ob) and np.array_equal(k, ok), (n_in, n_out)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from test_kernels_emu import _stale
+
+    if _stale():
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    from antmmf.hip import _lib
+
+    old = os.environ.get("ANTMMF_HIP_LIB")
+    os.environ["ANTMMF_HIP_LIB"] = EMU_LIB
+    _lib.reset_for_tests()
+    yield
+    if old is None:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+    else:
+        os.environ["ANTMMF_HIP_LIB"] = old
+    _lib.reset_for_tests()
+
+
+def test_kernels_emulated_vs_pillow_goldens(emu, golden):
+    print(rc.case_goldens(torch.device("cpu"), golden))
+
+
+def test_kernels_emulated_vs_oracle_ragged(emu):
+    print(rc.case_vs_oracle(torch.device("cpu"), [(40, 56), (24, 24), (5, 90), (24, 31)], 24))
+
+
+def test_square_transform_mirror(emu, golden):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder"))
+    from vlmo.transforms import keys_to_transforms
+
+    g = golden("resize_bicubic.pt")
+    tf = keys_to_transforms(["square_transform"], size=32)[0]
+    out = tf(g["in0"].numpy())  # ndarray / PIL.Image / tensor are accepted
+    assert out.shape == (3, 32, 32) and out.dtype == torch.float32
+    assert torch.equal(out, g["out0"].permute(2, 0, 1).float().div(255))
+    with pytest.raises(TypeError):
+        tf(torch.zeros(4, 4, 3))
+    with pytest.raises(NotImplementedError):
+        keys_to_transforms(["square_transform_randaug"])
