@@ -42,7 +42,64 @@ def bicubic_coeffs(in_size, out_size):
             w = w / ww
         kk[xx, :xmax] = np.trunc(np.where(w < 0, -0.5 + w * (1 << PRECISION_BITS), 0.5 + w * (1 << PRECISION_BITS))).astype(np.int32)
         bounds[xx] = (xmin, xmax)
+    if int(np.abs(kk).max()) >= 1 << 23:  # the kernels multiply with v_mad_i32_i24
+        raise ValueError(f"bicubic_coeffs({in_size}, {out_size}): coefficient outside the 24-bit range")
     return ksize, bounds, kk
+
+
+class ResizePlan:
+    """Descriptor + coefficient tables of one ragged batch, on the device.  Building it costs a few host microseconds per image and
+    three small uploads; a dataloader that sees the same frame sizes again can keep it."""
+
+    def __init__(self, sizes, channels, out_h, out_w, device):
+        desc = np.zeros((len(sizes), 10), dtype=np.int64)
+        tabs, btabs, where = [], [], {}
+        n_coef = n_bound = 0
+
+        def table(in_size, out_size, tap_major):
+            nonlocal n_coef, n_bound
+            if in_size == out_size:  # Pillow skips a pass whose extent does not change
+                return 0, 0, 0
+            key = (in_size, out_size, tap_major)
+            if key not in where:
+                ks, b, k = bicubic_coeffs(in_size, out_size)
+                where[key] = (n_coef, ks, n_bound)
+                if tap_major:  # [taps rounded up to 4, out] with zero rows: the RGB kernel consumes four taps per iteration
+                    kt = np.zeros(((ks + 3) // 4 * 4, k.shape[0]), dtype=np.int32)
+                    kt[:ks] = k.T
+                    k = kt
+                tabs.append(k.reshape(-1)); btabs.append(b.reshape(-1))
+                n_coef += k.size; n_bound += b.size
+            return where[key]
+
+        src_off = tmp_off = 0
+        for i, (h, w) in enumerate(sizes):
+            kx_off, kx, bx_off = table(w, out_w, True)    # horizontal pass: lanes = outputs -> tap-major table
+            ky_off, ky, by_off = table(h, out_h, False)   # vertical pass: a wave shares one output row
+            desc[i] = (src_off, h, w, tmp_off, kx_off, kx, bx_off, ky_off, ky, by_off)
+            src_off += h * w * channels
+            tmp_off += h * out_w * channels
+        self.n, self.channels, self.out_h, self.out_w = len(sizes), channels, out_h, out_w
+        self.src_bytes, self.tmp_bytes = src_off, tmp_off
+        self.max_h, self.max_w = int(desc[:, 1].max()), int(desc[:, 2].max())
+        self.coeffs = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, np.int32)).to(device)
+        self.bounds = torch.from_numpy(np.concatenate(btabs) if btabs else np.zeros(2, np.int32)).to(device)
+        self.desc = torch.from_numpy(desc).to(device)
+        self.device = torch.device(device)
+
+
+def resize_packed_u8(src, plan, out_f32=True, tmp=None):
+    """src: uint8 device buffer holding the plan's images back to back ([h_i, w_i, C]); two kernel launches."""
+    if src.dtype != torch.uint8 or not src.is_contiguous() or src.numel() != plan.src_bytes or src.device != plan.device:
+        raise ValueError("resize_packed_u8: src must be the contiguous uint8 buffer the plan describes, on the plan's device")
+    if tmp is None or tmp.numel() < plan.tmp_bytes:
+        tmp = torch.empty(max(plan.tmp_bytes, 4), dtype=torch.uint8, device=plan.device)
+    out = (torch.empty(plan.n, plan.channels, plan.out_h, plan.out_w, dtype=torch.float32, device=plan.device) if out_f32
+           else torch.empty(plan.n, plan.out_h, plan.out_w, plan.channels, dtype=torch.uint8, device=plan.device))
+    _rc(_lib.load().antmmf_resize_bicubic_u8(_p(src), src.numel(), _p(plan.desc), plan.n, plan.max_h, plan.max_w, plan.channels, plan.out_h,
+                                            plan.out_w, _p(plan.coeffs), _p(plan.bounds), _p(tmp), _p(out), 1 if out_f32 else 0, _stream()),
+        "antmmf_resize_bicubic_u8")
+    return out
 
 
 def resize_bicubic_u8(images, out_h, out_w, out_f32=True, device=None):
@@ -62,38 +119,6 @@ def resize_bicubic_u8(images, out_h, out_w, out_f32=True, device=None):
             device = torch.device("cpu")  # CPU lane emulator (tests)
     if (torch.device(device).type == "cuda") != (_lib.backend() == 1):
         raise RuntimeError("resize_bicubic_u8: device does not match the loaded library (gfx950 library <-> cuda tensors; no CPU fallback)")
-    desc = np.zeros((len(images), 10), dtype=np.int64)
-    tabs, btabs, where = [], [], {}
-    n_coef = n_bound = 0
-
-    def table(in_size, out_size):
-        nonlocal n_coef, n_bound
-        if in_size == out_size:  # Pillow skips a pass whose extent does not change
-            return 0, 0, 0
-        key = (in_size, out_size)
-        if key not in where:
-            ks, b, k = bicubic_coeffs(in_size, out_size)
-            where[key] = (n_coef, ks, n_bound)
-            tabs.append(k.reshape(-1)); btabs.append(b.reshape(-1))
-            n_coef += k.size; n_bound += b.size
-        return where[key]
-
-    src_off = tmp_off = 0
-    for i, t in enumerate(images):
-        h, w = int(t.shape[0]), int(t.shape[1])
-        kx_off, kx, bx_off = table(w, out_w)
-        ky_off, ky, by_off = table(h, out_h)
-        desc[i] = (src_off, h, w, tmp_off, kx_off, kx, bx_off, ky_off, ky, by_off)
-        src_off += h * w * C
-        tmp_off += h * out_w * C
+    plan = ResizePlan([(int(t.shape[0]), int(t.shape[1])) for t in images], C, out_h, out_w, device)
     src = torch.cat([t.reshape(-1).to(device, non_blocking=True) for t in images])
-    coeffs = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, np.int32)).to(device)
-    bounds = torch.from_numpy(np.concatenate(btabs) if btabs else np.zeros(2, np.int32)).to(device)
-    desc_d = torch.from_numpy(desc).to(device)
-    tmp = torch.empty(max(tmp_off, 4), dtype=torch.uint8, device=device)
-    n = len(images)
-    out = (torch.empty(n, C, out_h, out_w, dtype=torch.float32, device=device) if out_f32
-           else torch.empty(n, out_h, out_w, C, dtype=torch.uint8, device=device))
-    _rc(_lib.load().antmmf_resize_bicubic_u8(_p(src), src.numel(), _p(desc_d), n, int(desc[:, 1].max()), int(desc[:, 2].max()), C, out_h, out_w,
-                                            _p(coeffs), _p(bounds), _p(tmp), _p(out), 1 if out_f32 else 0, _stream()), "antmmf_resize_bicubic_u8")
-    return out
+    return resize_packed_u8(src, plan, out_f32)

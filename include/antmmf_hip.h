@@ -215,11 +215,12 @@ int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, 
 /* ---- input pipeline: Pillow-exact antialiased bicubic resize of a batch of RAGGED 8-bit interleaved images,
  * replacing the per-image CPU `square_transform(size)` = Resize((size, size), BICUBIC) + ToTensor
  * (prj/M2_Encoder/vlmo/transforms/square_transform.py:8-14, called from prj/M2_Encoder/m2_encoder.py:61-68; arithmetic =
- * Pillow src/libImaging/Resample.c, 8bpc path).  src: images packed back to back ([h_i, w_i, channels] uint8), src_bytes its size.
+ * Pillow src/libImaging/Resample.c, 8bpc path).  src (16-byte aligned): images packed back to back ([h_i, w_i, channels] uint8,
+ * channels 1 / 3 / 4), src_bytes its size.
  * desc [n_images, 10] int64 (DEVICE): src byte offset, h, w, tmp byte offset, horizontal coeff offset, taps kx (0 = pass skipped),
  * horizontal bounds offset, vertical coeff offset, taps ky (0 = skipped), vertical bounds offset; coeffs = 22-bit fixed-point
- * tables [out, taps] int32 and bounds [out, 2] = (first tap, tap count), both computed by the host in double precision exactly as
- * Pillow's precompute_coeffs does.  tmp: scratch for the [h_i, out_w, channels] intermediates.  out: uint8 [n, out_h, out_w, C]
+ * int32 tables (horizontal: tap-major [kx rounded up to a multiple of 4, out_w], zero-padded; vertical: output-major [out_h, ky]) and bounds [out, 2] = (first tap, tap
+ * count), both computed by the host in double precision exactly as Pillow's precompute_coeffs does.  tmp: scratch for the [h_i, out_w, channels] intermediates.  out: uint8 [n, out_h, out_w, C]
  * (out_f32 = 0, byte-identical to PIL) or float32 [n, C, out_h, out_w] = u8 / 255 (out_f32 = 1, ToTensor).  max_h / max_w: the
  * largest input height / width in the batch (max_w * channels <= 160 KiB: one row is staged in LDS). */
 int antmmf_resize_bicubic_u8(const void* src, int64_t src_bytes, const int64_t* desc, int n_images, int max_h, int max_w,

@@ -63,6 +63,9 @@ def test_kernels_emulated_vs_pillow_goldens(emu, golden):
 
 def test_kernels_emulated_vs_oracle_ragged(emu):
     print(rc.case_vs_oracle(torch.device("cpu"), [(40, 56), (24, 24), (5, 90), (24, 31)], 24))
+    # output rows that are not a whole number of dwords (byte path of the vertical kernel); a row wider than 8 KB (fewer rows staged per workgroup)
+    print(rc.case_vs_oracle(torch.device("cpu"), [(33, 47), (25, 60), (9, 25)], 25, seed=1))
+    print(rc.case_vs_oracle(torch.device("cpu"), [(10, 3100), (3, 40)], 16, seed=2))
 
 
 def test_square_transform_mirror(emu, golden):
