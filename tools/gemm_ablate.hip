@@ -177,6 +177,106 @@ void runstag(const char* name, const uint16_t* P, const uint16_t* Q, float* out,
     printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
 }
 
+
+// Two-group staggered loop with the Q operand BYPASSING LDS: each wave loads its 64 x 32 Q fragments straight from global memory
+// in MFMA layout (16 B per lane, three K-steps ahead, register ring of four), only P goes through the LDS-DMA ring.  Per K-step the
+// LDS port then sees 8 instead of 12 fragment reads per wave and 16 instead of 32 KB of DMA writes (the product loop saturates it).
+// MODE 0: as described; MODE 1: the plain staggered loop (both operands through LDS) with the same cycle stamps, for comparison.
+template <int MODE>
+__global__ __launch_bounds__(512) void kstagq(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q, float* __restrict__ out, int ld, int nk, int ntiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 4, TI = 8, TJ = 4, SB = MODE ? 32768 : 16384;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wi = wave >> 2, wj = wave & 3, l15 = lane & 15, grp = lane >> 4;
+    const bool late = wave >= 4;
+    const int ntj_ = ntiles_j < 0 ? -ntiles_j : ntiles_j;
+    const int i0 = (blockIdx.x / ntj_) * 256, j0 = (blockIdx.x % ntj_) * 256;
+    f32x4_t acc[TI][TJ];
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
+    const uint16_t* psrc[2]; const uint16_t* qsrc[2]; const uint16_t* qdir[TJ];
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2), sl = ((lane & 3) ^ swz32(row)) << 3;
+        psrc[q] = P + (long)(i0 + row) * ld + sl; qsrc[q] = Q + (long)(j0 + row) * ld + sl;
+    }
+    for (int t = 0; t < TJ; ++t) qdir[t] = Q + (long)(j0 + wj * 64 + t * 16 + l15) * ld + grp * 8;
+    bf16x8_t qr[4][TJ], pb[TI];
+    // VMEM ops per wave per stage, in issue order: the wave's DMA pieces, then (MODE 0) its four Q fragment loads
+    constexpr int NDMA = MODE ? 4 : 2, NQ = MODE ? 0 : 4, PER = NDMA + NQ;
+#define KQ_ISSUE(KT, SLOT)                                                                                              \
+    {                                                                                                                   \
+        char* buf_ = smem + ((KT) % STAGES) * SB;                                                                       \
+        if (MODE) { for (int q = 0; q < 2; ++q) { glds16(psrc[q] + ((KT) << 5), buf_ + (wave * 2 + q) * 1024); glds16(qsrc[q] + ((KT) << 5), buf_ + 16384 + (wave * 2 + q) * 1024); } } \
+        else {                                                                                                          \
+            for (int q = 0; q < 2; ++q) glds16(psrc[q] + ((KT) << 5), buf_ + (wave * 2 + q) * 1024);                    \
+            for (int t = 0; t < TJ; ++t) qr[SLOT][t] = *(const bf16x8_t*)(qdir[t] + ((KT) << 5));                       \
+        }                                                                                                               \
+    }
+    // the DMA pieces of stage kt have landed when at most (ops issued after them) remain outstanding
+#define KQ_WAIT(KT)                                                                                                     \
+    {                                                                                                                   \
+        const int ahead_ = issued - (KT);                                                                               \
+        if (ahead_ >= 2) wait_le<NQ + 2 * PER>(); else if (ahead_ == 1) wait_le<NQ + PER>(); else wait_le<NQ>();        \
+    }
+    KQ_ISSUE(0, 0) KQ_ISSUE(1, 1) KQ_ISSUE(2, 2)
+    int issued = 2;
+    auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    if (late) { KQ_WAIT(0) bar(); }
+    const unsigned long long c0_ = __builtin_readcyclecounter();
+#define KQ_STEP(SLOT, KT)                                                                                               \
+    {                                                                                                                   \
+        const int kt_ = (KT);                                                                                           \
+        if (!late) KQ_WAIT(kt_)                                                                                         \
+        bar();                                                                                                          \
+        if (kt_ + STAGES - 1 < nk) { KQ_ISSUE(kt_ + STAGES - 1, ((SLOT) + 3) & 3) issued = kt_ + STAGES - 1; }          \
+        const char* ps = smem + (kt_ % STAGES) * SB;                                                                    \
+        if (MODE) { const char* qs = ps + 16384;                                                                        \
+            for (int t = 0; t < TJ; ++t) { const int row = wj * 64 + t * 16 + l15; qr[SLOT][t] = *(const bf16x8_t*)(qs + row * 64 + ((grp ^ swz32(row)) << 4)); } } \
+        for (int t = 0; t < TI; ++t) { const int row = wi * 128 + t * 16 + l15; pb[t] = *(const bf16x8_t*)(ps + row * 64 + ((grp ^ swz32(row)) << 4)); } \
+        if (late && kt_ + 1 < nk) KQ_WAIT(kt_ + 1)                                                                      \
+        bar();                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        _Pragma("unroll") for (int it = 0; it < TI; ++it)                                                               \
+            _Pragma("unroll") for (int jt = 0; jt < TJ; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[SLOT][jt], pb[it], acc[it][jt], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+    for (int kt = 0; kt < nk; kt += 4) { KQ_STEP(0, kt) KQ_STEP(1, kt + 1) KQ_STEP(2, kt + 2) KQ_STEP(3, kt + 3) }
+    if (!late) bar();
+    const unsigned long long c1_ = __builtin_readcyclecounter();
+    float s = 0;
+    for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (ntiles_j < 0) out[blockIdx.x * 512 + threadIdx.x] = s;                       // check run: per-thread sums
+    else if (threadIdx.x == 0) out[blockIdx.x] = (float)(c1_ - c0_);                 // timing run: K-loop cycles of wave 0
+}
+template <int MODE>
+void runstagq(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&kstagq<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kstagq<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e0);
+    const int iters = 5;
+    for (int w = 0; w < iters; ++w) hipLaunchKernelGGL(kstagq<MODE>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R, nk, J / 256);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+    std::vector<float> cc(tiles);
+    hipMemcpy(cc.data(), out, (size_t)tiles * 4, hipMemcpyDeviceToHost);
+    double cs = 0; for (int t = 0; t < tiles; ++t) cs += cc[t];
+    printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s   K loop %.0f cycles per step (ideal 1024)\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12, cs / tiles / nk);
+}
+// the two variants must produce identical per-thread sums (same MFMA order)
+void checkstagq(const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
+    const int tiles = (I / 256) * (J / 256), nk = R / 32;
+    const size_t n = (size_t)tiles * 512;
+    std::vector<float> ra(n), rb(n);
+    // ntiles_j < 0 selects the check output; the tile mapping needs |ntiles_j|, so run a single column of tiles
+    hipLaunchKernelGGL(kstagq<1>, dim3(I / 256), dim3(512), 131072, 0, P, Q, out, R, nk, -1);
+    hipMemcpy(ra.data(), out, (size_t)(I / 256) * 512 * 4, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(kstagq<0>, dim3(I / 256), dim3(512), 131072, 0, P, Q, out, R, nk, -1);
+    hipMemcpy(rb.data(), out, (size_t)(I / 256) * 512 * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0; for (size_t i = 0; i < (size_t)(I / 256) * 512; ++i) bad += ra[i] != rb[i] || !(ra[i] == ra[i]);
+    printf("    Q-direct vs LDS loop: %zu thread sums differ (sample %.6g %.6g)\n", bad, ra[777], rb[777]);
+    (void)J;
+}
+
 // ---- next-generation candidate: ONE wave per SIMD (256 threads), 128 x 128 per wave (64 accumulator tiles = 256 registers, in
 // AGPRs), fragments of step k+1 read from LDS while the 64 MFMAs of step k issue (register double buffer), 4-stage DMA ring, one
 // barrier per step.  LDS -> register traffic per step drops from 96 KB (8 waves x (128 + 64) rows) to 64 KB (4 x (128 + 128)).
@@ -663,6 +763,9 @@ int main() {
         run<0 + 32>("mfma only + LDS-staged store tail", P, Q, out, I, J2, R2);
         runstag<0>("STAGGERED two-group loop (no store)", P, Q, out, I, J2, R2);
         runstag<1>("STAGGERED two-group loop + staged store", P, Q, out, I, J2, R2);
+        runstagq<1>("STAGGERED (stamped)", P, Q, out, I, J2, R2);
+        runstagq<0>("STAGGERED, Q fragments direct from global", P, Q, out, I, J2, R2);
+        checkstagq(P, Q, out, I, J2, R2);
         run1w<0>("1 wave/SIMD 128x128: reads then 64 mfma", P, Q, out, I, J2, R2);
         run1w<1>("1 wave/SIMD 128x128: reads interleaved", P, Q, out, I, J2, R2);
         run1w<2>("1 wave/SIMD 128x128: interleaved, asm mfma (AGPR)", P, Q, out, I, J2, R2);
