@@ -837,6 +837,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
         }
         PROF_MARK(2);
         char* stage = smem + ((gs + STAGES - 1) & (STAGES - 1)) * 32768 + wave * 4096;
+#ifdef ANTMMF_GEMM_PROF
+        if (g.raster & 8) {  // experiment: no store tail (does the store traffic slow the next tile's K loop?)
+            float sacc = 0.f;
+            for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = sacc;
+        } else
+#endif
         epilogue_store_bf16_staged_raw<TI, TJ, 4>(g, acc, ci0, cj0, wi, wj, lane, stage);
         PROF_MARK(3);
 #ifdef ANTMMF_GEMM_PROF

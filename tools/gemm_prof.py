@@ -25,7 +25,7 @@ def run(name, n, k, bias, res):
     v = torch.tensor(list(buf), dtype=torch.float64).view(256, 8)
     tot = v[:, :4].sum(1)
     frac = (v[:, :4].sum(0) / tot.sum()).tolist()
-    print(json.dumps(dict(case=name, ms=round(ms, 3), tflops=round(2.0 * tokens * n * k / ms / 1e9, 1), tiles_per_wg=v[:, 4].mean().item(),
+    print(json.dumps(dict(raster=os.environ.get("ANTMMF_GEMM_RASTER", "1"), case=name, ms=round(ms, 3), tflops=round(2.0 * tokens * n * k / ms / 1e9, 1), tiles_per_wg=v[:, 4].mean().item(),
                           frac_kloop=round(frac[0], 3), frac_operands=round(frac[1], 3), frac_prologue=round(frac[2], 3), frac_store=round(frac[3], 3),
                           cycles_per_tile=round((tot.sum() / v[:, 4].sum()).item()), stamped_over_elapsed=round(tot.mean().item() / (ms * 1e-3) / 1e9, 3))), flush=True)
 run("fc1 (J=4096,R=1024) +bias", 4096, 1024, True, False)
