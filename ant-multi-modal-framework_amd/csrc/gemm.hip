@@ -714,7 +714,13 @@ extern "C" int antmmf_debug_gemm_prof(unsigned long long* host) {
 #define PROF_MARK(i) ((void)0)
 #define PROF_FLUSH() ((void)0)
 #endif
-template <int EPI>
+// CONT (default): the DMA ring runs CONTINUOUSLY across tiles -- the first three K-stages of the next tile are issued during the
+// last three K-steps of the current one (the slots they free), not as a burst in front of the epilogue.  Measured reasons
+// (tools/gemm_prof.py): the burst's 96 KB queued in the vector-memory path ahead of the epilogue's stores (store phase 5.7 k cycles
+// per tile against a 2 k floor), and the next tile's first counted vmcnt wait had to drain those just-issued stores (loads and
+// stores share the counter).  Now stages 0 and 1 of the next tile are waited for BEFORE the stores are issued, the first two steps
+// of the next tile wait for nothing, and the first wait that covers the stores comes two K-steps later.
+template <int EPI, bool CONT>
 __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, int ntiles) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int STAGES = 4, BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, G = 4;
@@ -746,14 +752,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
             qsrc[q] = g.Q + (long)gj2 * g.ldq + sl;
         }
     };
-    int gs = 0;  // ring step counter at the start of the current tile
-    auto issue = [&](int kt) {
-        char* buf = smem + ((gs + kt) & (STAGES - 1)) * 32768;
+    int gs = 0;         // ring step counter at the start of the current tile
+    int issued_g = -1;  // ring step of the youngest stage this wave has issued
+    // K-slice `k` of the tile psrc / qsrc point at -> ring slot of (global) step `step`
+    auto issue = [&](int k, int step) {
+        char* buf = smem + (step & (STAGES - 1)) * 32768;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(psrc[q] + (kt << 5), buf + (wave * 2 + q) * 1024);
-            glds16(qsrc[q] + (kt << 5), buf + 16384 + (wave * 2 + q) * 1024);
+            glds16(psrc[q] + (k << 5), buf + (wave * 2 + q) * 1024);
+            glds16(qsrc[q] + (k << 5), buf + 16384 + (wave * 2 + q) * 1024);
         }
+        issued_g = step;
     };
     int local = lx;
     if (local >= xcount) return;
@@ -762,8 +771,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
     set_sources(i0, j0);
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nk) issue(t);
+        if (t < nk) issue(t, t);
     const bool late = wave >= 4;
+    int prelanded = 0;  // CONT: leading stages of this tile already known to have landed (waited for before the previous tile's stores)
     PROF_DECL;
     for (;;) {
         f32x4_t acc[TI][TJ];
@@ -772,11 +782,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
 #pragma unroll
             for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         PROF_START();
-        int issued = (STAGES - 1 < nk ? STAGES - 1 : nk) - 1;
-        // counted vmcnt: conservative when epilogue stores of the previous tile are still in flight (they are younger than the
-        // prologue pieces, so "at most N outstanding" still implies the awaited pieces have landed)
+        const bool more = local + per_xcd < xcount;
+        int ni0 = 0, nj0 = 0;
+        // counted vmcnt: the pieces of stage kt have landed once at most the pieces of the younger stages are outstanding.  Conservative
+        // (never wrong) when stores of the previous epilogue are still in flight: loads complete in order among themselves.
         auto wait_tile = [&](int kt) {
-            const int ahead = issued - kt;
+            if (CONT && kt < prelanded) return;
+            const int ahead = issued_g - (gs + kt);
             if (ahead >= 2) glds_wait_le<2 * G>();
             else if (ahead == 1) glds_wait_le<G>();
             else glds_wait_le<0>();
@@ -785,7 +797,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
         for (int kt = 0; kt < nk; ++kt) {
             if (!late) wait_tile(kt);
             wg_barrier_lds_only();
-            if (kt + STAGES - 1 < nk) { issue(kt + STAGES - 1); issued = kt + STAGES - 1; }
+            if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, gs + kt + STAGES - 1);
+            else if (CONT && more) {  // the slot freed by step kt - 1 takes K-stage kt + 3 - nk of the NEXT tile
+                if (kt + STAGES - 1 == nk) { tile_origin(local + per_xcd, ni0, nj0); set_sources(ni0, nj0); }
+                issue(kt + STAGES - 1 - nk, gs + kt + STAGES - 1);
+            }
             const char* ps = smem + ((gs + kt) & (STAGES - 1)) * 32768;
             const char* qs = ps + 16384;
             bf16x8_t qa[TJ], pb[TI];
@@ -809,12 +825,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
             SCHED_FENCE();
         }
-        if (!late) wg_barrier_lds_only();  // every wave has read its last fragments: all four ring slots are free
+        if (!late) wg_barrier_lds_only();  // every wave has read its last fragments: the slot of the last stage is free
         PROF_MARK(0);
         const int ci0 = i0, cj0 = j0;
         if (EPI > 0) epilogue_apply_operands<TI, TJ, EPI>(g, acc, ci0, cj0, wi, wj, lane);
-        // the operand loads must be CONSUMED before any DMA piece is issued (else their wait would cover the pieces): an empty asm
-        // that "modifies" the accumulators pins the adds here (LLVM otherwise sinks them below the prologue)
+        // !CONT: the operand loads must be CONSUMED before any DMA piece is issued (else their wait would cover the pieces): an empty
+        // asm that "modifies" the accumulators pins the adds here (LLVM otherwise sinks them below the prologue).  CONT: same pin, so
+        // that the adds sit in front of the stage wait below and not inside the store passes.
 #ifndef ANTMMF_EMULATE
         if (EPI > 0) {
 #define ACC4(i) "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])
@@ -827,13 +844,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
         PROF_MARK(1);
         gs += nk;
         local += per_xcd;
-        const bool more = local < xcount;
         if (more) {
-            tile_origin(local, i0, j0);
-            set_sources(i0, j0);
+            if (CONT) {
+                i0 = ni0; j0 = nj0;
+                glds_wait_le<G>();  // stages 0 and 1 of the next tile (issued two and one K-steps ago) have landed; stage 2 may fly
+                prelanded = 2;
+            } else {
+                tile_origin(local, i0, j0);
+                set_sources(i0, j0);
 #pragma unroll
-            for (int t = 0; t < STAGES - 1; ++t)
-                if (t < nk) issue(t);  // slots gs .. gs+2; the epilogue below stages through slot gs+3
+                for (int t = 0; t < STAGES - 1; ++t)
+                    if (t < nk) issue(t, gs + t);  // slots gs .. gs+2; the epilogue below stages through slot gs+3
+            }
         }
         PROF_MARK(2);
         char* stage = smem + ((gs + STAGES - 1) & (STAGES - 1)) * 32768 + wave * 4096;
@@ -1083,19 +1105,24 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         const bool persist = force ? force[0] == 'p' : !(persist_env && persist_env[0] == '0');
         static const char* pwgs_env = getenv("ANTMMF_GEMM_PERSIST_WGS");  // tests only: a small grid makes every workgroup walk several tiles
         const unsigned pwgs = pwgs_env ? (unsigned)atoi(pwgs_env) : 256u;
+        static const char* cont_env = getenv("ANTMMF_GEMM_CONT");  // A/B knob: "0" = next-tile prologue as a burst in front of the epilogue
+        const bool cont = !(cont_env && cont_env[0] == '0');
         const int epi = (aux || gate || act != ANTMMF_ACT_NONE || alpha != 1.0f || c_dtype != ANTMMF_BF16) ? 4 : ((bias ? 1 : 0) | (residual ? 2 : 0));
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
         if (!once) {                                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
             once = true;                                                                                                          \
         }                                                                                                                         \
-        if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0)                                     \
-            hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0)>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);  \
+        if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                       \
+            if (cont) hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256); \
+            else hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);     \
+        }                                                                                                                         \
         else if (big && !(force && force[0] == '2')) hipLaunchKernelGGL((gemm_nt_ring_kernel<4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \

@@ -99,16 +99,21 @@ def test_gemm_large_tile_variants(ops, variant):
     assert "okbig" in out.stdout, out.stdout + out.stderr
 
 
-def test_gemm_persistent_ring():
-    """The persistent 256 x 256 ring kernel on a 3 x 3-tile problem with an 8-workgroup grid: one workgroup walks two tiles
-    (next-tile prologue issued before the epilogue, epilogue staged through the free ring slot)."""
+@pytest.mark.parametrize("cont", ["1", pytest.param("0", marks=pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="A/B variant: set ANTMMF_SLOW_TESTS=1"))])
+def test_gemm_persistent_ring(cont):
+    """The persistent 256 x 256 ring kernel on 3 x 3- and 3 x 5-tile problems with an 8-workgroup grid: workgroups walk two tiles
+    (cont = 1: the DMA ring runs on across the tile boundary; 0: next-tile prologue issued as a burst before the epilogue; the
+    epilogue is staged through the free ring slot either way)."""
     import subprocess
     import sys
 
     code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'p';"
             "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '8';"
-            "import kernel_cases as kc; from antmmf.hip import ops; kc.case_gemm_persistent(ops, torch.device('cpu')); print('okpersist')"
-            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+            "os.environ['ANTMMF_GEMM_CONT'] = %r;"
+            "import kernel_cases as kc; from antmmf.hip import ops; slow = bool(os.environ.get('ANTMMF_SLOW_TESTS'));"
+            "kc.case_gemm_persistent(ops, torch.device('cpu'), I=520, J=600, R=128, quick=not slow);"
+            "slow and kc.case_gemm_persistent(ops, torch.device('cpu'), I=700, J=1100, R=192); print('okpersist')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, cont))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
     assert "okpersist" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
