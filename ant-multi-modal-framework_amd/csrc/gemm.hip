@@ -609,24 +609,36 @@ __global__ __launch_bounds__(64 * NWI * NWJ) void gemm_tn_dma_kernel(const GemmA
 template <int TI, int TJ, int EPI>
 __device__ __forceinline__ void epilogue_apply_operands(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj, int lane) {
     const int l15 = lane & 15, grp = lane >> 4;
+    int jc[TJ];
 #pragma unroll
     for (int jt = 0; jt < TJ; ++jt) {
-        int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
-        j = j < g.J ? j : g.J - 4;
-        if (EPI & 1) {
-            const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+        const int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
+        jc[jt] = j < g.J ? j : g.J - 4;
+    }
+    if (EPI & 1) {
+#pragma unroll
+        for (int jt = 0; jt < TJ; ++jt) {
+            const float4 b = *reinterpret_cast<const float4*>(g.bias + jc[jt]);
 #pragma unroll
             for (int it = 0; it < TI; ++it) { acc[it][jt][0] += b.x; acc[it][jt][1] += b.y; acc[it][jt][2] += b.z; acc[it][jt][3] += b.w; }
         }
-        if (EPI & 2) {
-#ifndef ANTMMF_EMULATE
-            if (!(jt & 1)) asm volatile("" ::: "memory");  // two jt columns (16 loads) at a time: all 32 in flight would spill
-#endif
+    }
+    if (EPI & 2) {
+        // residual in the fragment layout: lane (l15, grp) reads 8 B of row it * 16 + l15 per column tile, so the TJ loads of one `it`
+        // cover whole 128-B lines of 16 rows.  `it` is the OUTER loop so that those loads are adjacent in time (L1 hits); with the
+        // column tile outside, every line came back from L2 once per column tile (the wave's footprint exceeds L1).  Four row tiles
+        // (16 loads) in flight at a time: all 32 would spill.
 #pragma unroll
-            for (int it = 0; it < TI; ++it) {
-                int i = i0 + wi * (16 * TI) + it * 16 + l15;
-                i = i < g.I ? i : g.I - 1;
-                const uint2 u = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+        for (int it = 0; it < TI; ++it) {
+#ifndef ANTMMF_EMULATE
+            if (!(it & 3)) asm volatile("" ::: "memory");
+#endif
+            int i = i0 + wi * (16 * TI) + it * 16 + l15;
+            i = i < g.I ? i : g.I - 1;
+            const bf16_t* rrow = g.residual + (long)i * g.ldr;
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) {
+                const uint2 u = *reinterpret_cast<const uint2*>(rrow + jc[jt]);
                 acc[it][jt][0] += bf_lo(u.x); acc[it][jt][1] += bf_hi(u.x); acc[it][jt][2] += bf_lo(u.y); acc[it][jt][3] += bf_hi(u.y);
             }
         }
