@@ -2,7 +2,7 @@
 """Where the persistent NT GEMM's time goes: in-kernel cycle stamps (build with -DANTMMF_GEMM_PROF -> lib/libantmmf_hip_prof.so)."""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "ant-multi-modal-framework_amd", "lib", "libantmmf_hip_prof.so")
+LIB = os.environ.get("ANTMMF_PROF_LIB") or os.path.join(ROOT, "ant-multi-modal-framework_amd", "lib", "libantmmf_hip_prof.so")
 os.environ["ANTMMF_HIP_LIB"] = LIB
 sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd"))
 import torch
