@@ -89,6 +89,25 @@ def test_gemm_large_linearity(ops):
     torch.testing.assert_close(y[rows], ref, rtol=2e-3, atol=2e-3)
 
 
+def test_gemm_persistent_uneven_rounds(ops):
+    """bf16 persistent path (532 tiles on 256 workgroups: 2 rounds + a nearly empty third, ragged last row tile), every compile-time
+    epilogue; rows sampled across the whole range, around row 128 * 256 and at the ragged end against an fp32 matmul of the same bf16
+    operands.  (Peeling the last row tiles off to a 128 x 128-tile launch was measured at the bench sizes: +0.1 % on the step, not kept.)"""
+    I, J, R = 132 * 256 + 100, 1024, 512
+    g = torch.Generator(device="cuda").manual_seed(11)
+    X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
+    W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
+    bias = torch.randn(J, generator=g, device=DEV)
+    res = torch.randn(I, J, generator=g, device=DEV).bfloat16()
+    rows = torch.cat([torch.randint(0, 128 * 256, (48,), device=DEV), torch.arange(128 * 256 - 3, 128 * 256 + 3, device=DEV),
+                      torch.randint(128 * 256, I, (48,), device=DEV), torch.tensor([I - 1], device=DEV)])
+    ref = X[rows].float() @ W.float().t()
+    for kw, extra in ((dict(), 0), (dict(bias=bias), bias), (dict(residual=res), res[rows].float()), (dict(bias=bias, residual=res), bias + res[rows].float())):
+        y = ops.gemm(X, W, **kw)
+        assert y.dtype == torch.bfloat16 and torch.isfinite(y.float()).all()
+        torch.testing.assert_close(y[rows].float(), ref + extra, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(B=2, heads=2, Nq=17, Nk=17, bias_kind="none"),
     dict(B=3, heads=2, Nq=12, Nk=12, bias_kind="bert"),
