@@ -29,14 +29,14 @@ def case_goldens(dev, golden):
     return f"{len(g['cases'])} golden cases + ragged batch of {len(idx)}: byte-identical to Pillow {g['pillow_version']}"
 
 
-def case_vs_oracle(dev, sizes, out_hw, seed=0):
+def case_vs_oracle(dev, sizes, out_hw, seed=0, channels=3):
     """Seeded images of the given (h, w) sizes as one ragged batch vs the oracle (float ToTensor output, exact)."""
     from antmmf.hip.image import resize_bicubic_u8
 
     rng = np.random.default_rng(seed)
-    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    imgs = [rng.integers(0, 256, (h, w, channels), dtype=np.uint8) for h, w in sizes]
     got = resize_bicubic_u8([torch.from_numpy(i).to(dev) for i in imgs], out_hw, out_hw, out_f32=True).cpu().numpy()
     for j, im in enumerate(imgs):
         want = oresize.square_transform(im, out_hw)
         assert np.array_equal(got[j], want), (sizes[j], float(np.abs(got[j] - want).max()))
-    return f"{len(sizes)} images -> {out_hw}: equal to the oracle"
+    return f"{len(sizes)} images x {channels} channels -> {out_hw}: equal to the oracle"

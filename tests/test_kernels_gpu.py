@@ -167,3 +167,5 @@ def test_resize_bicubic_full_size_ragged_batch_vs_oracle(ops):
 
     sizes = [(1080, 1920), (1920, 1080), (480, 640), (224, 224), (224, 600), (700, 224), (100, 150), (1, 300), (300, 1), (64, 23000), (2160, 3840)]
     print(rc.case_vs_oracle(DEV, sizes, 224, seed=5))
+    print(rc.case_vs_oracle(DEV, [(300, 400), (224, 500)], 224, seed=6, channels=4))
+    print(rc.case_vs_oracle(DEV, [(300, 400), (90, 64)], 224, seed=7, channels=1))

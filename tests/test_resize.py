@@ -66,6 +66,13 @@ def test_kernels_emulated_vs_oracle_ragged(emu):
     # output rows that are not a whole number of dwords (byte path of the vertical kernel); a row wider than 8 KB (fewer rows staged per workgroup)
     print(rc.case_vs_oracle(torch.device("cpu"), [(33, 47), (25, 60), (9, 25)], 25, seed=1))
     print(rc.case_vs_oracle(torch.device("cpu"), [(10, 3100), (3, 40)], 16, seed=2))
+    print(rc.case_vs_oracle(torch.device("cpu"), [(19, 30), (16, 41)], 16, seed=3, channels=4))  # RGBA: the generic per-byte path
+    from antmmf.hip.image import resize_bicubic_u8
+
+    with pytest.raises(RuntimeError):  # two-channel images are rejected by the library (L / RGB / RGBA only)
+        resize_bicubic_u8([torch.zeros(8, 8, 2, dtype=torch.uint8)], 4, 4)
+    with pytest.raises(ValueError):
+        resize_bicubic_u8([], 4, 4)
 
 
 def test_square_transform_mirror(emu, golden):
