@@ -893,6 +893,462 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
     }
 }
 
+// ---- BK = 64 "quarter-phase" ping-pong NT kernel ---------------------------------------------------------------------------
+// 256 x 256 output tile, K-tiles of 64 (LDS rows = whole 128-B cache lines: one LDS-DMA piece = 8 rows x 128 B instead of the
+// 16 half-lines of the BK = 32 ring), TWO 64-KiB K-tile stages.  A K-tile is consumed in FOUR phases of 16 MFMAs per wave: phase ph
+// multiplies the wave's P rows [32 ph, 32 ph + 32) (2 fragments x 2 k-halves, read in that phase) with all four Q fragments (read in
+// phase 0, kept for the tile).  Waves 0-3 / 4-7 (pairwise on the same SIMDs) run one barrier interval apart: while one group issues
+// its 16 MFMAs (s_setprio 1) the other issues 2 DMA pieces + its fragment reads, so the load side comes in bursts of 4-12 reads
+// and 2 pieces instead of 12 + 4 per 32 MFMAs.  Ring discipline (g = 4 t + ph counts phases):
+//   * the P quarter / Q quarter read in LOAD(g - 1) is refilled in LOAD(g) with the data of K-tile t + 2 (every wave has passed the
+//     lgkmcnt(0) of its reads before the barrier in front of that interval);
+//   * a piece is needed 7 phases after it was issued (Q's last quarter: 4), each LOAD issues exactly 2 pieces per wave, so the
+//     counted waits are the constants vmcnt(12) / vmcnt(6) in steady state and a fixed ladder in the last two K-tiles; every wave
+//     waits for ITS pieces of what LOAD(g + 1) reads before the barrier that closes LOAD(g).
+// Requires I % 256 == 0, J % 256 == 0, R % 64 == 0, R >= 128.
+#ifdef ANTMMF_EMULATE
+#define K64_READ(dst, addr, OFF) dst = *reinterpret_cast<const bf16x8_t*>(smem + (addr) + (OFF))
+#define K64_SETPRIO(n) do {} while (0)
+#define K64_FENCE8(a) do {} while (0)
+#define K64_FENCE4(a) do {} while (0)
+#else
+#define K64_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds0 + (addr)), "n"(OFF))
+#define K64_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define K64_FENCE4(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define K64_FENCE8(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+#endif
+
+template <int EPI, bool PRIO>
+__global__ __launch_bounds__(512) void gemm_nt_k64_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
+    constexpr int STAGE = 65536, QOFF = 32768;
+    const int lane = threadIdx.x & 63;
+#ifdef ANTMMF_EMULATE
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lds0 = 0;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#endif
+    (void)lds0;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int tiles_j = g.J / BN, tiles_i = g.I / BM;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+    const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+    const int i0 = (band * 4 + inb % rows_here) * BM, j0 = (inb / rows_here) * BN;
+    const int nk = g.R >> 6;
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read addresses: row r (16 rows per fragment, r0 = fragment origin), logical 16-B slot s = 4 ks + grp lives at
+    // byte r * 128 + ((s ^ lds_swz(r)) << 4); lds_swz(r0 + l15) = lds_swz(l15) ^ (((r0 >> 4) & 3) << 1), so four lane bases
+    // rb[x] (x = the XOR constant / 2) cover every fragment of both operands
+    uint32_t pbase[4], qbase[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const uint32_t lb = (uint32_t)(l15 * 128 + (((grp ^ lds_swz(l15)) ^ (2 * x)) << 4));
+        pbase[x] = lb + (uint32_t)(wi * 128 * 128);
+        qbase[x] = lb + (uint32_t)(QOFF + wj * 64 * 128);
+    }
+    // DMA pieces (1 KiB = 8 rows x 128 B): per phase this wave moves one piece of the P quarter and one of the Q quarter that were
+    // read in the previous phase.  P quarter pq = rows {wi' 128 + 32 pq + [0, 32)} (8 pieces, wave w: wi' = w >> 2, 8-row block w & 3);
+    // Q quarter pq = rows {wj' 64 + 16 pq + [0, 16)} (wave w: wj' = w >> 1, 8-row block w & 1).
+    const int pl = lane >> 3, pslot = lane & 7;
+    const int prow0 = (wave >> 2) * 128 + (wave & 3) * 8, qrow0 = (wave >> 1) * 64 + (wave & 1) * 8;  // + 32 pq / + 16 pq
+    const char* pg = reinterpret_cast<const char*>(g.P + (long)(i0 + prow0) * g.ldp);                  // wave-uniform
+    const char* qg = reinterpret_cast<const char*>(g.Q + (long)(j0 + qrow0) * g.ldq);
+    const uint32_t pvo = (uint32_t)(pl * (int)g.ldp * 2), qvo = (uint32_t)(pl * (int)g.ldq * 2);      // per-lane row offset (bytes)
+    auto dma = [&](int pq, int tt) {
+        const int pr = prow0 + 32 * pq + pl, qr = qrow0 + 16 * pq + pl;
+        const uint32_t ps = (uint32_t)((pslot ^ lds_swz(pr)) << 4), qs = (uint32_t)((pslot ^ lds_swz(qr)) << 4);
+        char* st = smem + (tt & 1) * STAGE;
+        glds16(pg + (long)pq * 32 * g.ldp * 2 + (long)tt * 128 + (pvo + ps), st + (prow0 + 32 * pq) * 128);
+        glds16(qg + (long)pq * 16 * g.ldq * 2 + (long)tt * 128 + (qvo + qs), st + QOFF + (qrow0 + 16 * pq) * 128);
+    };
+    // prologue: K-tiles 0 and 1 complete (16 pieces per wave), drained once
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) dma(pq, tt);
+    glds_wait_all();
+    wg_barrier_lds_only();
+
+    bf16x8_t qa[8], pb[4];  // qa[2 jt + ks], pb[2 f + ks]
+    const bool late = wave >= 4;
+    uint32_t so = 0;  // byte offset of the current stage
+    // TAILPOS: 0 steady state, 1 = K-tile nk - 2, 2 = K-tile nk - 1
+#define K64_PHASE(PH, TAILPOS, FIRST)                                                                                               \
+    do {                                                                                                                            \
+        /* LOAD interval */                                                                                                         \
+        if (PH == 0) {  /* qa[2 jt + ks]: ks = 0 -> x = jt, ks = 1 -> x = jt ^ 2 (slot bit 2) */                                   \
+            K64_READ(qa[0], so + qbase[0], 0);    K64_READ(qa[1], so + qbase[2], 0);                                                \
+            K64_READ(qa[2], so + qbase[1], 2048); K64_READ(qa[3], so + qbase[3], 2048);                                             \
+            K64_READ(qa[4], so + qbase[2], 4096); K64_READ(qa[5], so + qbase[0], 4096);                                             \
+            K64_READ(qa[6], so + qbase[3], 6144); K64_READ(qa[7], so + qbase[1], 6144);                                             \
+        }                                                                                                                           \
+        K64_READ(pb[0], so + pbase[((PH & 1) * 2 + 0)], PH * 4096);                                                                 \
+        K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
+        K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
+        K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
+        if (TAILPOS == 0 ? !(FIRST) : (TAILPOS == 1 && PH == 0 && !(FIRST))) dma((PH + 3) & 3, (PH == 0 ? t - 1 : t) + 2);         \
+        if (TAILPOS == 0) { if (PH == 3) glds_wait_le<6>(); else glds_wait_le<12>(); }                                              \
+        else if (TAILPOS == 1) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<10>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<0>(); } \
+        else { if (PH == 0) glds_wait_le<4>(); else if (PH == 1) glds_wait_le<2>(); else glds_wait_le<0>(); }                       \
+        K64_BARRIER();                                                                                                              \
+        /* MFMA interval */                                                                                                         \
+        if (PH == 0) K64_FENCE8(qa);                                                                                                \
+        K64_FENCE4(pb);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+        if (PRIO) K64_SETPRIO(1);                                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                            \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
+                _Pragma("unroll") for (int jt = 0; jt < 4; ++jt)                                                                    \
+                    acc[2 * PH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks], acc[2 * PH + f][jt], 0, 0, 0); \
+        if (PRIO) K64_SETPRIO(0);                                                                                                   \
+        SCHED_FENCE();                                                                                                              \
+        K64_BARRIER();                                                                                                              \
+    } while (0)
+#ifdef ANTMMF_EMULATE
+#define K64_BARRIER() __syncthreads()
+#else
+#define K64_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+    if (late) K64_BARRIER();
+    int t = 0;
+    for (; t < nk - 2; ++t) {
+        if (t == 0) K64_PHASE(0, 0, true); else K64_PHASE(0, 0, false);
+        K64_PHASE(1, 0, false);
+        K64_PHASE(2, 0, false);
+        K64_PHASE(3, 0, false);
+        so ^= STAGE;
+    }
+    {   // K-tile nk - 2 (t == nk - 2): only its phase 0 still issues (the last quarters of K-tile nk - 1) -- unless it is also tile 0
+        if (t == 0) K64_PHASE(0, 1, true); else K64_PHASE(0, 1, false);
+        K64_PHASE(1, 1, false);
+        K64_PHASE(2, 1, false);
+        K64_PHASE(3, 1, false);
+        so ^= STAGE;
+        ++t;
+        K64_PHASE(0, 2, false);
+        K64_PHASE(1, 2, false);
+        K64_PHASE(2, 2, false);
+        K64_PHASE(3, 2, false);
+    }
+    if (!late) K64_BARRIER();
+#undef K64_PHASE
+    // every wave is past its last fragment read and nothing is in flight: the stages are free for the store staging
+    gemm_epilogue_bf16_staged<TI, TJ, EPI>(g, acc, i0, j0, wi, wj, lane, smem + wave * (TI * 16 * TJ * 32));
+}
+
+// ---- persistent form of the BK = 64 quarter-phase kernel: the two-stage ring runs CONTINUOUSLY across the output tiles a workgroup
+// walks (its refills simply move on to the next tile's K-tiles), and the epilogue needs NO LDS: the Q fragment rows are read in the
+// order {0-3, 8-11, 4-7, 12-15}, so that after one v_permlane32_swap per accumulator register a lane holds 8 CONSECUTIVE columns
+// of its output row -- bias / residual / activation / store are then 16-B accesses of 64-B row segments straight from registers
+// (no staging pass, no barrier, the DMA ring is never touched).  DMA issue per phase {P q3 | P q0 + Q q0 q1 | P q1 + Q q2 q3 | P q2}
+// = 1 / 3 / 3 / 1 pieces beside 12 / 4 / 4 / 4 fragment reads; steady waits vmcnt {12, 12, 14, 9} (see the derivation in DESIGN.md).
+#define K64F_PRIO 1
+#define K64F_NODMA 2
+#define K64F_DIST11 4    /* one DMA piece per barrier interval per wave (LOAD and MFMA intervals alike) instead of 1 / 3 / 3 / 1 per LOAD */
+#define K64F_DLATE 8     /* DIST11: the MFMA interval's piece goes after the 8th MFMA instead of after the 1st */
+#define K64F_CLK 16      /* experiment: workgroup 0 records shader-clock and 100-MHz-clock ticks across its run (effective clock under load) */
+#ifndef ANTMMF_EMULATE
+__device__ unsigned long long g_k64_clk[2];
+extern "C" int antmmf_debug_gemm_clock(unsigned long long* host2) {
+    return hipMemcpyFromSymbol(host2, HIP_SYMBOL(g_k64_clk), sizeof(g_k64_clk)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef ANTMMF_EMULATE
+#define K64_NT_STORE16(ptr, val) (*reinterpret_cast<u32x4_t*>(ptr) = (val))
+#else
+#define K64_NT_STORE16(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<u32x4_t*>(ptr))
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned int k64_u2_t;
+
+template <int EPI, int FLAGS>
+__global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int ntiles) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
+    constexpr int STAGE = 65536, QOFF = 32768;
+    constexpr bool PRIO = FLAGS & K64F_PRIO, NODMA = FLAGS & K64F_NODMA, DIST11 = FLAGS & K64F_DIST11, DLATE = FLAGS & K64F_DLATE;
+    // residual / generic epilogues run from registers (permuted Q rows + lane swap, 16-B accesses of 64-B row segments: the residual is read
+    // coalesced); plain / bias epilogues stage through the 32 KiB of LDS above the ring (128-B row segments)
+    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4;
+    const int lane = threadIdx.x & 63;
+#ifdef ANTMMF_EMULATE
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lds0 = 0;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#endif
+    (void)lds0;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int tiles_j = g.J / BN, tiles_i = g.I / BM;
+    const int nk = g.R >> 6;
+    // XCD x owns the contiguous tile-id range [xbase, xbase + xcount); this workgroup takes ids lx, lx + per_xcd, ... (4 x 8 patches)
+    const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int qd = ntiles >> 3, rm = ntiles & 7;
+    const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
+    auto tile_origin = [&](int local, int& i0, int& j0) {
+        const int wgid = xbase + local;
+        const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+        const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+        i0 = (band * 4 + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
+    };
+    int local = lx;
+    if (local >= xcount) return;
+#ifndef ANTMMF_EMULATE
+    unsigned long long clk0 = 0, rt0 = 0;
+    if ((FLAGS & K64F_CLK) && blockIdx.x == 0) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+
+    // fragment read bases (see gemm_nt_k64_kernel); SWAPEPI: the Q fragment row of lane l15 is l15 with bits 2 and 3 exchanged
+    const int pl15 = SWAPEPI ? ((l15 & 3) | (((l15 >> 3) & 1) << 2) | (((l15 >> 2) & 1) << 3)) : l15;
+    uint32_t pbase[4], qbase[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        pbase[x] = (uint32_t)(l15 * 128 + (((grp ^ lds_swz(l15)) ^ (2 * x)) << 4) + wi * 128 * 128);
+        qbase[x] = (uint32_t)(pl15 * 128 + (((grp ^ lds_swz(pl15)) ^ (2 * x)) << 4) + QOFF + wj * 64 * 128);
+    }
+    // DMA pieces (8 rows x 128 B); P quarter pq = rows {wi' 128 + 32 pq + [0, 32)}, wave w: wi' = w >> 2, 8-row block w & 3;
+    // Q quarter pq = rows {wj' 64 + 16 pq + [0, 16)}, wave w: wj' = w >> 1, 8-row block w & 1
+    const int pl = lane >> 3, pslot = lane & 7;
+    const int prow0 = (wave >> 2) * 128 + (wave & 3) * 8, qrow0 = (wave >> 1) * 64 + (wave & 1) * 8;
+    const long ldpb = g.ldp * 2, ldqb = g.ldq * 2;
+    uint32_t pv[2], qv[4];  // per-lane byte offsets: row pl of the piece + the source-side swizzle of the 16-B slot
+    {
+        const uint32_t ps0 = (uint32_t)((pslot ^ lds_swz(prow0 + pl)) << 4), qs0 = (uint32_t)((pslot ^ lds_swz(qrow0 + pl)) << 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) pv[b] = (uint32_t)(pl * (int)ldpb) + (ps0 ^ (uint32_t)(b << 6));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) qv[b] = (uint32_t)(pl * (int)ldqb) + (qs0 ^ (uint32_t)(b << 5));
+    }
+    const char* pgc; const char* qgc; const char* pgn = nullptr; const char* qgn = nullptr;  // wave-uniform bases: current / next tile
+    auto tile_bases = [&](int i0, int j0, const char*& pgx, const char*& qgx) {
+        pgx = reinterpret_cast<const char*>(g.P) + (long)(i0 + prow0) * ldpb;
+        qgx = reinterpret_cast<const char*>(g.Q) + (long)(j0 + qrow0) * ldqb;
+    };
+    auto dma_p = [&](const char* base, int pq, int kk, uint32_t stage_off) {
+        glds16(base + (long)pq * 32 * ldpb + (long)kk * 128 + pv[pq & 1], smem + stage_off + (prow0 + 32 * pq) * 128);
+    };
+    auto dma_q = [&](const char* base, int pq, int kk, uint32_t stage_off) {
+        glds16(base + (long)pq * 16 * ldqb + (long)kk * 128 + qv[pq], smem + stage_off + QOFF + (qrow0 + 16 * pq) * 128);
+    };
+    int i0, j0;
+    tile_origin(local, i0, j0);
+    tile_bases(i0, j0, pgc, qgc);
+    // prologue: K-tiles 0 and 1 of the first tile (16 pieces per wave), drained once
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, tt, tt * STAGE); dma_q(qgc, pq, tt, tt * STAGE); }
+    glds_wait_all();
+    wg_barrier_lds_only();
+
+    bf16x8_t qa[8], pb[4];  // qa[2 jt + ks], pb[2 f + ks]
+    const bool late = wave >= 4;
+    uint32_t so = 0;     // byte offset of the current K-tile's stage (toggles every K-tile, across output tiles)
+    bool first = true;   // the kernel's first K-tile: K-tile 1 is already complete, its first refills are skipped
+    // one DMA piece: SLOT = 2 PH (LOAD interval) or 2 PH + 1 (MFMA interval), WT as in K64P_WAIT
+    // DIST11 schedule (slot -> piece, target K-tile):  L0 P1 (t+1) | M0 P2 (t+1) | L1 P3 (t+1) | M1 Q0 (t+2) | L2 Q1 (t+2) | M2 Q2 (t+2) | L3 Q3 (t+2) | M3 P0 (t+2)
+    // every quarter is refilled at least one full barrier interval after the interval in which the LAST wave waited for its reads of it
+#define K64P_DMA11(SLOT, WT)                                                                                                        \
+    do {                                                                                                                            \
+        if (!NODMA && (WT == 0 || (WT == 1 && SLOT <= 2))) {                                                                        \
+            int kk = t + (SLOT <= 2 ? 1 : 2);                                                                                       \
+            const bool nx = kk >= nk;                                                                                               \
+            if (nx) kk -= nk;                                                                                                       \
+            const char* pbs = nx ? pgn : pgc;                                                                                       \
+            const char* qbs = nx ? qgn : qgc;                                                                                       \
+            const uint32_t st = SLOT <= 2 ? (so ^ STAGE) : so;                                                                      \
+            if (SLOT == 0) { if (!first) dma_p(pbs, 1, kk, st); }                                                                   \
+            else if (SLOT == 1) { if (!first) dma_p(pbs, 2, kk, st); }                                                              \
+            else if (SLOT == 2) { if (!first) dma_p(pbs, 3, kk, st); first = false; }                                               \
+            else if (SLOT == 3) dma_q(qbs, 0, kk, st);                                                                              \
+            else if (SLOT == 4) dma_q(qbs, 1, kk, st);                                                                              \
+            else if (SLOT == 5) dma_q(qbs, 2, kk, st);                                                                              \
+            else if (SLOT == 6) dma_q(qbs, 3, kk, st);                                                                              \
+            else dma_p(pbs, 0, kk, st);                                                                                             \
+        }                                                                                                                           \
+    } while (0)
+    // WT: wait ladder -- 0 steady, 1 = K-tile nk - 2 of the LAST output tile, 2 = K-tile nk - 1 of the last output tile
+#define K64P_WAIT(PH, WT)                                                                                                            \
+    do {                                                                                                                            \
+        if (DIST11) {                                                                                                               \
+            if (WT == 0) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<10>(); else glds_wait_le<7>(); } \
+            else if (WT == 1) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<3>(); } \
+            else { if (PH == 0) glds_wait_le<2>(); else if (PH == 1) glds_wait_le<1>(); else glds_wait_le<0>(); }                   \
+        } else {                                                                                                                    \
+            if (WT == 0) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<12>(); else if (PH == 2) glds_wait_le<14>(); else glds_wait_le<9>(); } \
+            else if (WT == 1) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<2>(); } \
+            else { if (PH == 0) glds_wait_le<4>(); else if (PH == 1) glds_wait_le<1>(); else glds_wait_le<0>(); }                   \
+        }                                                                                                                           \
+    } while (0)
+#define K64P_PHASE(PH, WT)                                                                                                          \
+    do {                                                                                                                            \
+        /* LOAD interval: fragment reads, then the refills */                                                                       \
+        if (PH == 0) {  /* qa[2 jt + ks]: ks = 0 -> x = jt, ks = 1 -> x = jt ^ 2 */                                                 \
+            K64_READ(qa[0], so + qbase[0], 0);    K64_READ(qa[1], so + qbase[2], 0);                                                \
+            K64_READ(qa[2], so + qbase[1], 2048); K64_READ(qa[3], so + qbase[3], 2048);                                             \
+            K64_READ(qa[4], so + qbase[2], 4096); K64_READ(qa[5], so + qbase[0], 4096);                                             \
+            K64_READ(qa[6], so + qbase[3], 6144); K64_READ(qa[7], so + qbase[1], 6144);                                             \
+        }                                                                                                                           \
+        K64_READ(pb[0], so + pbase[((PH & 1) * 2 + 0)], PH * 4096);                                                                 \
+        K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
+        K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
+        K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
+        if (DIST11) K64P_DMA11(2 * PH, WT);                                                                                         \
+        else if (!NODMA) {                                                                                                          \
+            int kk = t + (PH == 0 ? 1 : 2);                                                                                         \
+            const bool nx = kk >= nk;                                                                                               \
+            if (nx) kk -= nk;                                                                                                       \
+            const char* pbs = nx ? pgn : pgc;                                                                                       \
+            const char* qbs = nx ? qgn : qgc;                                                                                       \
+            const uint32_t st = PH == 0 ? (so ^ STAGE) : so;                                                                        \
+            if (WT == 0) {                                                                                                          \
+                if (PH == 0) { if (!first) dma_p(pbs, 3, kk, st); first = false; }                                                  \
+                else if (PH == 1) { dma_p(pbs, 0, kk, st); dma_q(qbs, 0, kk, st); dma_q(qbs, 1, kk, st); }                          \
+                else if (PH == 2) { dma_p(pbs, 1, kk, st); dma_q(qbs, 2, kk, st); dma_q(qbs, 3, kk, st); }                          \
+                else dma_p(pbs, 2, kk, st);                                                                                         \
+            } else if (WT == 1 && PH == 0) { if (!first) dma_p(pbs, 3, kk, st); first = false; }                                    \
+        }                                                                                                                           \
+        K64P_WAIT(PH, WT);                                                                                                          \
+        K64_BARRIER();                                                                                                              \
+        /* MFMA interval */                                                                                                         \
+        if (PH == 0) K64_FENCE8(qa);                                                                                                \
+        K64_FENCE4(pb);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+        if (PRIO) K64_SETPRIO(1);                                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                            \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
+                _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                                  \
+                    acc[2 * PH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks], acc[2 * PH + f][jt], 0, 0, 0); \
+                    if (DIST11 && (ks * 8 + f * 4 + jt) == (DLATE ? 7 : 0)) { SCHED_FENCE(); K64P_DMA11(2 * PH + 1, WT); SCHED_FENCE(); } \
+                }                                                                                                                   \
+        if (PRIO) K64_SETPRIO(0);                                                                                                   \
+        SCHED_FENCE();                                                                                                              \
+        K64_BARRIER();                                                                                                              \
+    } while (0)
+#define K64P_TILE(WT) do { K64P_PHASE(0, WT); K64P_PHASE(1, WT); K64P_PHASE(2, WT); K64P_PHASE(3, WT); so ^= STAGE; } while (0)
+
+    for (;;) {
+        const bool more = local + per_xcd < xcount;
+        int ni0 = 0, nj0 = 0;
+        if (more) { tile_origin(local + per_xcd, ni0, nj0); tile_bases(ni0, nj0, pgn, qgn); }
+        f32x4_t acc[TI][TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (late) K64_BARRIER();  // group B runs one barrier interval behind group A
+        const int tend = more ? nk : nk - 2;
+        int t = 0;
+        for (; t < tend; ++t) K64P_TILE(0);
+        if (!more) {
+            K64P_TILE(1);
+            ++t;
+            K64P_TILE(2);
+        }
+        if (!late) K64_BARRIER();  // both groups enter the epilogue together
+
+        if (!SWAPEPI) {
+            // bias in the fragment layout, then bf16 rows staged through this wave's 4 KiB above the ring (asm LDS traffic: pieces of the
+            // next tile are in flight and hipcc would drain them in front of any LDS access it can see)
+            if (EPI & 1) epilogue_apply_operands<TI, TJ, EPI & 1>(g, acc, i0, j0, wi, wj, lane);
+            epilogue_store_bf16_staged_raw<TI, TJ, 4>(g, acc, i0, j0, wi, wj, lane, smem + 2 * STAGE + wave * 4096);
+        } else {
+            // ---- epilogue straight from the accumulators.  lane (l15, grp) holds out[i = it 16 + l15][j = jt 16 + 4 PB(grp) + r],
+            // PB = {0, 2, 1, 3}; after the swap it holds 8 consecutive columns of fragment 2 p + (lane >> 5) at (grp & 1) * 8.
+            constexpr bool GENERIC = EPI == 4, BIAS = EPI & 1, RES = EPI & 2;
+            const int pbg = ((grp & 1) << 1) | (grp >> 1);
+            const int jw = j0 + wj * 64, iw = i0 + wi * 128 + l15;
+            if (BIAS && !GENERIC) {
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + jw + jt * 16 + pbg * 4);
+#pragma unroll
+                    for (int it = 0; it < TI; ++it) { acc[it][jt][0] += b.x; acc[it][jt][1] += b.y; acc[it][jt][2] += b.z; acc[it][jt][3] += b.w; }
+                }
+            }
+            const int cj = jw + (lane >> 5) * 16 + (grp & 1) * 8;  // + 32 p
+            bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // two halves of the rows: 8 residual vectors in flight at a time
+                u32x4_t rv[8];
+                if (RES || (GENERIC && g.residual)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int it = h * 4 + (q >> 1), p2 = q & 1;
+                        rv[q] = *reinterpret_cast<const u32x4_t*>(g.residual + (long)(iw + it * 16) * g.ldr + cj + 32 * p2);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int it = h * 4 + (q >> 1), p2 = q & 1, a = 2 * p2, b = 2 * p2 + 1;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const k64_u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][a][r]), __float_as_uint(acc[it][b][r]), false, false);
+                        v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const long row = iw + it * 16;
+                    const int col = cj + 32 * p2;
+                    if (GENERIC) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+                        if (g.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col), b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (g.aux) {
+                            const u32x4_t av = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                            *reinterpret_cast<u32x4_t*>(g.aux + row * g.ldaux + col) = av;
+                        }
+                        if (g.gate) {
+                            const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g.gate + row * g.ldgate + col);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[2 * e] *= act_grad(bf_lo(gv[e]), g.act); v[2 * e + 1] *= act_grad(bf_hi(gv[e]), g.act); }
+                        } else if (g.act != ANTMMF_ACT_NONE) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], g.act);
+                        }
+                    }
+                    if (RES || (GENERIC && g.residual)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rv[q][e]); v[2 * e + 1] += bf_hi(rv[q][e]); }
+                    }
+                    const u32x4_t ov = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                    K64_NT_STORE16(C + row * g.ldc + col, ov);
+                }
+            }
+        }
+        if (!more) {
+#ifndef ANTMMF_EMULATE
+            if ((FLAGS & K64F_CLK) && blockIdx.x == 0 && threadIdx.x == 0) {
+                g_k64_clk[0] = __builtin_readcyclecounter() - clk0; g_k64_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+            }
+#endif
+            return;
+        }
+        local += per_xcd;
+        i0 = ni0; j0 = nj0; pgc = pgn; qgc = qgn;
+    }
+#undef K64P_TILE
+#undef K64P_PHASE
+#undef K64P_WAIT
+#undef K64P_DMA11
+}
+
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
 // instruction writes whole 256-B row segments (fp32 atomics straight from the fragment layout measured ~90 G adds / s:
 // 0.37 ms for the 33 M adds of one fc1 wgrad, as long as its whole K loop).
@@ -1073,6 +1529,13 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
     gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, g.ksteps_per_split < nk_total);
 }
 
+// Experiment / test knob (tools/gemm_bench, tests): bit 0 = route the large all-r-contiguous GEMMs to gemm_nt_k64_kernel, bit 1 = the same
+// without s_setprio; initialised from ANTMMF_GEMM_VARIANT.
+static int g_gemm_variant = -1;
+static long g_k64_launches = 0;
+extern "C" int antmmf_debug_set_gemm_variant(int v) { g_gemm_variant = v; return ANTMMF_OK; }
+extern "C" long antmmf_debug_gemm_k64_launches() { return g_k64_launches; }
+
 // C ABI: see include/antmmf_hip.h for the contract.
 static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                      int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
@@ -1126,6 +1589,18 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         static const char* cont_env = getenv("ANTMMF_GEMM_CONT");  // A/B knob: "0" = next-tile prologue as a burst in front of the epilogue
         const bool cont = !(cont_env && cont_env[0] == '0');
         const int epi = (aux || gate || act != ANTMMF_ACT_NONE || alpha != 1.0f || c_dtype != ANTMMF_BF16) ? 4 : ((bias ? 1 : 0) | (residual ? 2 : 0));
+        if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; }
+        const bool k64p = (g_gemm_variant & 4) && c_dtype == ANTMMF_BF16 && !(ldc & 7) && !(I & 255) && !(J & 255) && R >= 128 &&
+                          (!residual || !(ldr & 7)) && (!aux || !(ldaux & 7)) && (!gate || !(ldgate & 7)) &&
+                          (force ? force[0] == 'k' : tiles256 >= 512);
+#define K64P_LAUNCH(E_, F_)                                                                                                       \
+    do {                                                                                                                          \
+        static bool oncep = false;                                                                                                \
+        if (!oncep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64p_kernel<E_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); oncep = true; } \
+        hipLaunchKernelGGL((gemm_nt_k64p_kernel<E_, F_>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);              \
+    } while (0)
+        const bool k64 = (g_gemm_variant & 3) && c_dtype == ANTMMF_BF16 && !(ldc & 7) && !(I & 255) && !(J & 255) && R >= 128 &&
+                         (force ? force[0] == 'k' : tiles256 >= 512);
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
@@ -1137,7 +1612,35 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
             once = true;                                                                                                          \
         }                                                                                                                         \
-        if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                       \
+        if (k64p) {                                                                                                               \
+            ++g_k64_launches;                                                                                                     \
+            const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);  /* the tile walk needs a multiple of 8 workgroups (XCD = id % 8) */ \
+            const unsigned gridp = (g_gemm_variant & 64) ? t8 : (pwgs < t8 ? pwgs : t8);                                          \
+            /* variant bits: 8 NODMA (timing experiment), 16 = 1 / 3 / 3 / 1 pieces per LOAD instead of one per interval, 32 = late piece, 128 no setprio */ \
+            const int fsel = ((g_gemm_variant & 128) ? 0 : 1) | ((g_gemm_variant & 16) ? 0 : 2) | ((g_gemm_variant & 32) ? 4 : 0) | ((g_gemm_variant & 8) ? 8 : 0) | ((g_gemm_variant & 256) ? 16 : 0); \
+            switch (fsel) {                                                                                                       \
+                case 1: K64P_LAUNCH(E, K64F_PRIO); break;                                                                         \
+                case 2: K64P_LAUNCH(E, K64F_DIST11); break;                                                                       \
+                case 3: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11); break;                                                           \
+                case 7: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_DLATE); break;                                              \
+                case 11: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_NODMA); break;                                             \
+                case 19: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_CLK); break;                                               \
+                case 27: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_NODMA | K64F_CLK); break;                                  \
+                default: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11); break;                                                          \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        else if (k64) {                                                                                                           \
+            ++g_k64_launches;                                                                                                     \
+            static bool once64 = false;                                                                                           \
+            if (!once64) {                                                                                                        \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64_kernel<E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64_kernel<E, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+                once64 = true;                                                                                                    \
+            }                                                                                                                     \
+            if (g_gemm_variant & 2) hipLaunchKernelGGL((gemm_nt_k64_kernel<E, false>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
+            else hipLaunchKernelGGL((gemm_nt_k64_kernel<E, true>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g);       \
+        }                                                                                                                         \
+        else if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                  \
             if (cont) hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256); \
             else hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);     \
         }                                                                                                                         \
@@ -1153,6 +1656,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             default: LAUNCH_NT(4); break;
         }
 #undef LAUNCH_NT
+#undef K64P_LAUNCH
     }
     else if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
     else if (!p_rmajor && q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, stream, g);

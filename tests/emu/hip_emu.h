@@ -155,6 +155,24 @@ static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32_bf16(a, b, c)
 
+// v_permlane32_swap_b32 (gfx950): lanes 0-31 keep `a` and receive the upper half's `a` in `b`; lanes 32-63 receive the lower half's
+// `b` in `a` and keep `b`  (vdst[32..63] <-> vsrc[0..31]).
+typedef __attribute__((ext_vector_type(2))) unsigned emu_u2;
+static inline emu_u2 emu_permlane32_swap(unsigned a, unsigned b) {
+    auto* w = emu::tls.wave;
+    const int l = emu::tls.lane;
+    float fa, fb; std::memcpy(&fa, &a, 4); std::memcpy(&fb, &b, 4);
+    w->fbuf[l] = l < 32 ? fb : fa;   // what this lane gives away
+    w->bar.arrive_and_wait();
+    float got = w->fbuf[l ^ 32];
+    w->bar.arrive_and_wait();
+    unsigned ug; std::memcpy(&ug, &got, 4);
+    emu_u2 r;
+    if (l < 32) { r[0] = a; r[1] = ug; } else { r[0] = ug; r[1] = b; }
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emu_permlane32_swap(a, b)
+
 // ds_read_b64_tr_b16 as measured on gfx950 (profiles/r1_probe_gfx950_tr16_glds.txt): within each 16-lane group, lane j
 // supplies the address of 4 contiguous 16-bit elements; result element r of lane i is element (i & 3) of the chunk
 // supplied by lane 4 r + (i >> 2)  (a 4 x 16 block, row = supplying lane >> 2, read out by columns).

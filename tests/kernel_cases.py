@@ -279,6 +279,37 @@ def case_gemm_persistent(ops, dev, I=700, J=600, R=192, quick=False):
     check("gemm.persist.generic", ops.gemm(Xd, Wd, bias=bias.to(dev), act="gelu"), oops.gelu_erf(ref + bias), 2e-2, 1e-2)
 
 
+def case_gemm_k64(ops, dev, I=512, J=512, R=192, quick=False):
+    """Forward-layout GEMM on the BK = 64 quarter-phase kernel (256-aligned I / J, R % 64 == 0): every compile-time epilogue and the
+    generic one (aux store, activation, gate, alpha, residual) through the register-level (permlane swap) store path."""
+    X = q(rnd((I, R), 246))
+    Wt = q(rnd((J, R), 247, R ** -0.5))
+    bias = rnd((J,), 248)
+    res = q(rnd((I, J), 249))
+    ref = X @ Wt.t()
+    Xd, Wd = X.to(dev, BF), Wt.to(dev, BF)
+    check("gemm.k64.plain", ops.gemm(Xd, Wd), ref, 2e-2, 1e-2)
+    check("gemm.k64.bias_res", ops.gemm(Xd, Wd, bias=bias.to(dev), residual=res.to(dev, BF)), ref + bias + res, 2e-2, 1e-2)
+    if quick:
+        return
+    check("gemm.k64.bias", ops.gemm(Xd, Wd, bias=bias.to(dev)), ref + bias, 2e-2, 1e-2)
+    check("gemm.k64.res", ops.gemm(Xd, Wd, residual=res.to(dev, BF)), ref + res, 2e-2, 1e-2)
+    aux = torch.empty(I, J, dtype=BF, device=dev)
+    y = ops.gemm(Xd, Wd, bias=bias.to(dev), act="quick_gelu", residual=res.to(dev, BF), aux=aux, alpha=0.5)
+    pre = 0.5 * ref + bias
+    check("gemm.k64.generic.aux", aux, pre, 2e-2, 1e-2)
+    check("gemm.k64.generic", y, oops.quick_gelu(pre) + res, 2e-2, 1e-2)
+    u = q(rnd((I, J), 250))
+    dx = ops.gemm(Xd, Wd, gate=u.to(dev, BF), act="gelu")
+    ur = u.clone().requires_grad_(True)
+    oops.gelu_erf(ur).backward(ref)
+    check("gemm.k64.gate", dx, ur.grad, 2e-2, 1e-2)
+    packed = torch.zeros(I, 2 * J, dtype=BF, device=dev)
+    ops.gemm(Xd, Wd, out=packed[:, J:])
+    check("gemm.k64.ldc", packed[:, J:], ref, 2e-2, 1e-2)
+    assert float(packed[:, :J].float().abs().max()) == 0.0
+
+
 def case_gemm_wgrad_ring(ops, dev, tokens=4096, n_out=256, k_in=256):
     """wgrad through the 4-stage DMA ring + transpose reads (256-aligned outputs, >= 4096 tokens), split over tokens."""
     dY = q(rnd((tokens, n_out), 55, 0.5))

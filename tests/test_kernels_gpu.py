@@ -69,6 +69,45 @@ def test_gemm_persistent_ring(ops):
     kc.case_gemm_persistent(ops, DEV, I=13412, J=2560, R=256)
 
 
+def test_gemm_k64_persistent(ops):
+    """The BK = 64 quarter-phase persistent kernel (256-aligned shapes, >= 512 tiles): 520 tiles on 256 workgroups (every workgroup walks
+    2-3 tiles, ring continuous across them), nk = 4 and nk = 2; all epilogues against the fp32 oracle GEMM."""
+    from antmmf.hip import _lib
+
+    lib = _lib.load()
+    lib.antmmf_debug_gemm_k64_launches.restype = __import__("ctypes").c_long
+    before = lib.antmmf_debug_gemm_k64_launches()
+    kc.case_gemm_k64(ops, DEV, I=13312, J=2560, R=256)
+    kc.case_gemm_k64(ops, DEV, I=33024, J=1024, R=128, quick=True)
+    assert lib.antmmf_debug_gemm_k64_launches() - before >= 9, "the dispatcher did not pick the k64 kernel"
+
+
+def test_gemm_k64_full_size_vs_fp32(ops):
+    """BASELINE sizes (ViT-L/14, 256 pairs): fc2-shaped GEMM with bias + residual (register-level epilogue) and fc1-shaped with bias
+    (staged epilogue) against an fp32 matmul of the same bf16 operands on sampled rows; bit-exact against the BK = 32 ring kernel
+    (same K order) through the variant knob."""
+    from antmmf.hip import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    I = 257 * 256
+    for (J, R, with_res) in ((1024, 4096, True), (4096, 1024, False)):
+        X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
+        W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
+        bias = torch.randn(J, generator=g, device=DEV)
+        res = torch.randn(I, J, generator=g, device=DEV).bfloat16() if with_res else None
+        y = ops.gemm(X, W, bias=bias, residual=res)
+        rows = torch.randint(0, I, (96,), device=DEV)
+        ref = X[rows].float() @ W.float().t() + bias + (res[rows].float() if with_res else 0)
+        torch.testing.assert_close(y[rows].float(), ref, rtol=2e-2, atol=2e-2)
+        lib.antmmf_debug_set_gemm_variant(0)
+        try:
+            y0 = ops.gemm(X, W, bias=bias, residual=res)
+        finally:
+            lib.antmmf_debug_set_gemm_variant(4)
+        assert torch.equal(y, y0)
+
+
 def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV)
     kc.case_gemm_wgrad_ring(ops, DEV, tokens=257 * 64, n_out=1024, k_in=512)
