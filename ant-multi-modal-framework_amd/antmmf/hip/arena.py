@@ -54,7 +54,12 @@ class ParamArena:
         self.sync_shadow()
 
     def sync_shadow(self):
+        """Rebuild the whole bf16 shadow from the fp32 masters (one cast launch).  Required after writes that torch's version counter does
+        not see (`p.data...` edits); ordinary in-place writes to a parameter are detected per parameter by functional.compute_copy."""
         ops.cast_bf16(self.master, out=self.shadow)
+        for g in self.groups:
+            for p in g["params"]:
+                p._antmmf_ver = p._version
         from .functional import bump_weight_version
 
         bump_weight_version()
@@ -121,9 +126,35 @@ class HipAdamW(torch.optim.Optimizer):
         return d
 
     def load_state_dict(self, state_dict):
+        """Accepts this optimizer's own state (flat moments under "antmmf_arena") AND a reference-format torch.optim.AdamW state_dict
+        (per-parameter exp_avg / exp_avg_sq / step, ids in param_groups order -- what a released AntMMF checkpoint holds,
+        antmmf/common/checkpoint.py:229-238): those moments are scattered into the flat buffers at the parameters' arena offsets."""
+        state_dict = dict(state_dict)  # the caller's dict is left untouched
         extra = state_dict.pop("antmmf_arena", None)
-        super().load_state_dict(state_dict)
+        per_param = state_dict.get("state", {}) or {}
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if extra is not None:
-            self._step = extra["step"]
+            self._step = int(extra["step"])
             self.exp_avg.copy_(extra["exp_avg"])
             self.exp_avg_sq.copy_(extra["exp_avg_sq"])
+            return
+        if not per_param:
+            return
+        idx, loaded, step = 0, 0, 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = per_param.get(idx, per_param.get(str(idx)))
+                idx += 1
+                off = getattr(p, "_antmmf_offset", None)
+                if st is None or off is None or getattr(p, "_antmmf_arena", None) is not self.arena:
+                    continue
+                n = p.numel()
+                if st["exp_avg"].numel() != n:
+                    raise ValueError(f"optimizer state of parameter {idx - 1} has {st['exp_avg'].numel()} elements, expected {n}")
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = max(step, int(st["step"]))
+                loaded += 1
+        if loaded == 0:
+            raise ValueError("HipAdamW.load_state_dict: the state matches none of this optimizer's parameters")
+        self._step = step

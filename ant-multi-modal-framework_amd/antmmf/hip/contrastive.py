@@ -31,10 +31,28 @@ def _world(group):
     return 1, 0
 
 
+def _assert_equal_batch(n_rows, device, group):
+    """The sharded losses and the MoCo queue assume the same number of rows on every rank (row0 = rank * B, all_gather_into_tensor /
+    reduce_scatter_tensor take equal shares; the reference instead exchanges sizes and pads on every call,
+    distributed_utils.py:131-160).  A tiny all-gather of the local count + a DEVICE-side assert (no host sync) turns a ragged
+    batch into an error instead of a hang or mis-indexed diagonals.  ANTMMF_SKIP_BATCH_CHECK=1 removes it."""
+    import os
+
+    if os.environ.get("ANTMMF_SKIP_BATCH_CHECK"):
+        return
+    w, _ = _world(group)
+    mine = torch.full((1,), int(n_rows), dtype=torch.int64, device=device)
+    every = torch.empty(w, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(every, mine, group=group)
+    torch._assert_async((every == mine).all(), "ragged per-rank batch: the row-sharded losses need the same number of pairs on every rank "
+                                               "(drop the last partial batch or pad it)")
+
+
 def _all_gather(t, group):
     w, _ = _world(group)
     if w == 1:
         return t
+    _assert_equal_batch(t.shape[0], t.device, group)
     out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     return out

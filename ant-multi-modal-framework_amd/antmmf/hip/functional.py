@@ -31,6 +31,13 @@ def compute_copy(p):
         return None
     s = getattr(p, "_antmmf_bf16", None)
     if s is not None:
+        # the shadow is rewritten by the fused optimizer / EMA launches (which bypass torch's version counter); any OTHER in-place write
+        # to the fp32 master -- load_state_dict, an initialiser, p.clamp_() -- bumps p._version and is picked up here.  (Writes through
+        # `p.data` are invisible to the counter: call arena.sync_shadow() after those.)
+        if getattr(p, "_antmmf_ver", None) != p._version:
+            ops.cast_bf16(p.detach().reshape(-1), out=s.view(-1))
+            p._antmmf_ver = p._version
+            bump_weight_version()
         return s
     if p.dtype == BF:
         return p.detach()

@@ -3,9 +3,10 @@
 Same registry name, constructor kwargs (`simi_logit_key`), collect / calculate / summarize protocol and result keys
 ("<key>_r@1", "<key>_t2v-mr", ...).  The reference moves every similarity block to numpy, argsorts the full matrix on one CPU
 core and walks the rows in Python; here blocks stay on the GPU and the rank of each row's ground truth comes from one fused
-counting kernel (`antmmf_rank_rows`: rank = number of strictly larger scores), after which recall@k / median rank are
-reductions over a [rows] vector.  Difference: exactly tied scores -- the reference's position inside a tie group depends on
-numpy's unstable sort; here a tie never counts against the ground truth."""
+counting kernel (`antmmf_rank_rows`: rank = position in a stable descending sort = strictly larger scores + equal scores at a lower
+column index), after which recall@k / median rank are reductions over a [rows] vector.  Ties are broken by column index (the
+reference's position inside a tie group depends on numpy's sort implementation); a NaN ground-truth score ranks last, so a collapsed
+or diverged model cannot report perfect retrieval."""
 from collections import defaultdict
 
 import torch

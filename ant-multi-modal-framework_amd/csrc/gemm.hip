@@ -893,19 +893,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
     }
 }
 
-// ---- BK = 64 "quarter-phase" ping-pong NT kernel ---------------------------------------------------------------------------
-// 256 x 256 output tile, K-tiles of 64 (LDS rows = whole 128-B cache lines: one LDS-DMA piece = 8 rows x 128 B instead of the
-// 16 half-lines of the BK = 32 ring), TWO 64-KiB K-tile stages.  A K-tile is consumed in FOUR phases of 16 MFMAs per wave: phase ph
-// multiplies the wave's P rows [32 ph, 32 ph + 32) (2 fragments x 2 k-halves, read in that phase) with all four Q fragments (read in
-// phase 0, kept for the tile).  Waves 0-3 / 4-7 (pairwise on the same SIMDs) run one barrier interval apart: while one group issues
-// its 16 MFMAs (s_setprio 1) the other issues 2 DMA pieces + its fragment reads, so the load side comes in bursts of 4-12 reads
-// and 2 pieces instead of 12 + 4 per 32 MFMAs.  Ring discipline (g = 4 t + ph counts phases):
-//   * the P quarter / Q quarter read in LOAD(g - 1) is refilled in LOAD(g) with the data of K-tile t + 2 (every wave has passed the
-//     lgkmcnt(0) of its reads before the barrier in front of that interval);
-//   * a piece is needed 7 phases after it was issued (Q's last quarter: 4), each LOAD issues exactly 2 pieces per wave, so the
-//     counted waits are the constants vmcnt(12) / vmcnt(6) in steady state and a fixed ladder in the last two K-tiles; every wave
-//     waits for ITS pieces of what LOAD(g + 1) reads before the barrier that closes LOAD(g).
-// Requires I % 256 == 0, J % 256 == 0, R % 64 == 0, R >= 128.
+// ---- helpers of gemm_nt_k64p_kernel (asm LDS reads: invisible to hipcc's waitcnt pass, which would otherwise drain the DMA ring) ----
 #ifdef ANTMMF_EMULATE
 #define K64_READ(dst, addr, OFF) dst = *reinterpret_cast<const bf16x8_t*>(smem + (addr) + (OFF))
 #define K64_SETPRIO(n) do {} while (0)
@@ -918,147 +906,41 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
 #define K64_FENCE8(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 #endif
 
-template <int EPI, bool PRIO>
-__global__ __launch_bounds__(512) void gemm_nt_k64_kernel(const GemmArgs g) {
-    ANTMMF_DYN_LDS(char, smem);
-    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
-    constexpr int STAGE = 65536, QOFF = 32768;
-    const int lane = threadIdx.x & 63;
-#ifdef ANTMMF_EMULATE
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lds0 = 0;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-#endif
-    (void)lds0;
-    const int wi = wave / NWJ, wj = wave % NWJ;
-    const int l15 = lane & 15, grp = lane >> 4;
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int tiles_j = g.J / BN, tiles_i = g.I / BM;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
-    const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
-    const int i0 = (band * 4 + inb % rows_here) * BM, j0 = (inb / rows_here) * BN;
-    const int nk = g.R >> 6;
-
-    f32x4_t acc[TI][TJ];
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // fragment read addresses: row r (16 rows per fragment, r0 = fragment origin), logical 16-B slot s = 4 ks + grp lives at
-    // byte r * 128 + ((s ^ lds_swz(r)) << 4); lds_swz(r0 + l15) = lds_swz(l15) ^ (((r0 >> 4) & 3) << 1), so four lane bases
-    // rb[x] (x = the XOR constant / 2) cover every fragment of both operands
-    uint32_t pbase[4], qbase[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const uint32_t lb = (uint32_t)(l15 * 128 + (((grp ^ lds_swz(l15)) ^ (2 * x)) << 4));
-        pbase[x] = lb + (uint32_t)(wi * 128 * 128);
-        qbase[x] = lb + (uint32_t)(QOFF + wj * 64 * 128);
-    }
-    // DMA pieces (1 KiB = 8 rows x 128 B): per phase this wave moves one piece of the P quarter and one of the Q quarter that were
-    // read in the previous phase.  P quarter pq = rows {wi' 128 + 32 pq + [0, 32)} (8 pieces, wave w: wi' = w >> 2, 8-row block w & 3);
-    // Q quarter pq = rows {wj' 64 + 16 pq + [0, 16)} (wave w: wj' = w >> 1, 8-row block w & 1).
-    const int pl = lane >> 3, pslot = lane & 7;
-    const int prow0 = (wave >> 2) * 128 + (wave & 3) * 8, qrow0 = (wave >> 1) * 64 + (wave & 1) * 8;  // + 32 pq / + 16 pq
-    const char* pg = reinterpret_cast<const char*>(g.P + (long)(i0 + prow0) * g.ldp);                  // wave-uniform
-    const char* qg = reinterpret_cast<const char*>(g.Q + (long)(j0 + qrow0) * g.ldq);
-    const uint32_t pvo = (uint32_t)(pl * (int)g.ldp * 2), qvo = (uint32_t)(pl * (int)g.ldq * 2);      // per-lane row offset (bytes)
-    auto dma = [&](int pq, int tt) {
-        const int pr = prow0 + 32 * pq + pl, qr = qrow0 + 16 * pq + pl;
-        const uint32_t ps = (uint32_t)((pslot ^ lds_swz(pr)) << 4), qs = (uint32_t)((pslot ^ lds_swz(qr)) << 4);
-        char* st = smem + (tt & 1) * STAGE;
-        glds16(pg + (long)pq * 32 * g.ldp * 2 + (long)tt * 128 + (pvo + ps), st + (prow0 + 32 * pq) * 128);
-        glds16(qg + (long)pq * 16 * g.ldq * 2 + (long)tt * 128 + (qvo + qs), st + QOFF + (qrow0 + 16 * pq) * 128);
-    };
-    // prologue: K-tiles 0 and 1 complete (16 pieces per wave), drained once
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int pq = 0; pq < 4; ++pq) dma(pq, tt);
-    glds_wait_all();
-    wg_barrier_lds_only();
-
-    bf16x8_t qa[8], pb[4];  // qa[2 jt + ks], pb[2 f + ks]
-    const bool late = wave >= 4;
-    uint32_t so = 0;  // byte offset of the current stage
-    // TAILPOS: 0 steady state, 1 = K-tile nk - 2, 2 = K-tile nk - 1
-#define K64_PHASE(PH, TAILPOS, FIRST)                                                                                               \
-    do {                                                                                                                            \
-        /* LOAD interval */                                                                                                         \
-        if (PH == 0) {  /* qa[2 jt + ks]: ks = 0 -> x = jt, ks = 1 -> x = jt ^ 2 (slot bit 2) */                                   \
-            K64_READ(qa[0], so + qbase[0], 0);    K64_READ(qa[1], so + qbase[2], 0);                                                \
-            K64_READ(qa[2], so + qbase[1], 2048); K64_READ(qa[3], so + qbase[3], 2048);                                             \
-            K64_READ(qa[4], so + qbase[2], 4096); K64_READ(qa[5], so + qbase[0], 4096);                                             \
-            K64_READ(qa[6], so + qbase[3], 6144); K64_READ(qa[7], so + qbase[1], 6144);                                             \
-        }                                                                                                                           \
-        K64_READ(pb[0], so + pbase[((PH & 1) * 2 + 0)], PH * 4096);                                                                 \
-        K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
-        K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
-        K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
-        if (TAILPOS == 0 ? !(FIRST) : (TAILPOS == 1 && PH == 0 && !(FIRST))) dma((PH + 3) & 3, (PH == 0 ? t - 1 : t) + 2);         \
-        if (TAILPOS == 0) { if (PH == 3) glds_wait_le<6>(); else glds_wait_le<12>(); }                                              \
-        else if (TAILPOS == 1) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<10>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<0>(); } \
-        else { if (PH == 0) glds_wait_le<4>(); else if (PH == 1) glds_wait_le<2>(); else glds_wait_le<0>(); }                       \
-        K64_BARRIER();                                                                                                              \
-        /* MFMA interval */                                                                                                         \
-        if (PH == 0) K64_FENCE8(qa);                                                                                                \
-        K64_FENCE4(pb);                                                                                                             \
-        SCHED_FENCE();                                                                                                              \
-        if (PRIO) K64_SETPRIO(1);                                                                                                   \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                            \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
-                _Pragma("unroll") for (int jt = 0; jt < 4; ++jt)                                                                    \
-                    acc[2 * PH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks], acc[2 * PH + f][jt], 0, 0, 0); \
-        if (PRIO) K64_SETPRIO(0);                                                                                                   \
-        SCHED_FENCE();                                                                                                              \
-        K64_BARRIER();                                                                                                              \
-    } while (0)
 #ifdef ANTMMF_EMULATE
 #define K64_BARRIER() __syncthreads()
 #else
 #define K64_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
-    if (late) K64_BARRIER();
-    int t = 0;
-    for (; t < nk - 2; ++t) {
-        if (t == 0) K64_PHASE(0, 0, true); else K64_PHASE(0, 0, false);
-        K64_PHASE(1, 0, false);
-        K64_PHASE(2, 0, false);
-        K64_PHASE(3, 0, false);
-        so ^= STAGE;
-    }
-    {   // K-tile nk - 2 (t == nk - 2): only its phase 0 still issues (the last quarters of K-tile nk - 1) -- unless it is also tile 0
-        if (t == 0) K64_PHASE(0, 1, true); else K64_PHASE(0, 1, false);
-        K64_PHASE(1, 1, false);
-        K64_PHASE(2, 1, false);
-        K64_PHASE(3, 1, false);
-        so ^= STAGE;
-        ++t;
-        K64_PHASE(0, 2, false);
-        K64_PHASE(1, 2, false);
-        K64_PHASE(2, 2, false);
-        K64_PHASE(3, 2, false);
-    }
-    if (!late) K64_BARRIER();
-#undef K64_PHASE
-    // every wave is past its last fragment read and nothing is in flight: the stages are free for the store staging
-    gemm_epilogue_bf16_staged<TI, TJ, EPI>(g, acc, i0, j0, wi, wj, lane, smem + wave * (TI * 16 * TJ * 32));
-}
 
-// ---- persistent form of the BK = 64 quarter-phase kernel: the two-stage ring runs CONTINUOUSLY across the output tiles a workgroup
-// walks (its refills simply move on to the next tile's K-tiles), and the epilogue needs NO LDS: the Q fragment rows are read in the
-// order {0-3, 8-11, 4-7, 12-15}, so that after one v_permlane32_swap per accumulator register a lane holds 8 CONSECUTIVE columns
-// of its output row -- bias / residual / activation / store are then 16-B accesses of 64-B row segments straight from registers
-// (no staging pass, no barrier, the DMA ring is never touched).  DMA issue per phase {P q3 | P q0 + Q q0 q1 | P q1 + Q q2 q3 | P q2}
-// = 1 / 3 / 3 / 1 pieces beside 12 / 4 / 4 / 4 fragment reads; steady waits vmcnt {12, 12, 14, 9} (see the derivation in DESIGN.md).
+// ---- gemm_nt_k64p_kernel: the large all-r-contiguous GEMMs (forward, pre-transposed dgrad) ----------------------------------------
+// 256 x 256 output tile per workgroup (8 waves, 128 x 64 each), K-tiles of 64: LDS rows are whole 128-B cache lines, one LDS-DMA
+// piece = 8 rows x 128 B (the BK = 32 ring moved 16 half-lines per piece), TWO 64-KiB K-tile stages.  A K-tile is consumed in FOUR
+// phases of 16 MFMAs per wave: phase ph multiplies the wave's P rows [32 ph, +32) (2 fragments x 2 k-halves, read in that phase) with
+// all four Q fragments (read in phase 0, kept for the K-tile): 12 / 4 / 4 / 4 fragment reads.
+//   * Ping-pong with ONE barrier per phase: every wave runs the same stream L(0) M(0) L(1) M(1) ... (L = fragment reads + refills,
+//     M = 16 MFMAs); waves 0-3 (group A) take their barrier behind every L, waves 4-7 (group B, same SIMDs pairwise) behind every M,
+//     so inside a period A runs [M(g-1) L(g)] and B [L(g) M(g)]: the two waves of a SIMD start on opposite sides (matrix / memory)
+//     and cross over, the matrix pipe is shared.  (Two barriers per phase measured 1-5 % slower; kept as variant bit 16.)
+//   * Persistent, ring continuous across output tiles: a workgroup walks its XCD's tile range (4 x 8 patches per L2) and its refills
+//     simply move on to the next tile's K-tiles -- no drain / refill bubble at a tile boundary.
+//   * Ring discipline: a quarter read in period g (B early, A late; A's lgkmcnt(0) sits behind the next barrier) is refilled in period
+//     g + 2 or later: two pieces per phase per wave, ph0 P q0 q1 (K-tile t+1) | ph1 P q2 q3 (t+1) | ph2 Q q0 q1 (t+2) | ph3 Q q2 q3 (t+2).
+//     A piece is needed >= 4 periods after its issue; each wave waits for ITS pieces of what phase g + 1 reads before the barrier
+//     that closes its period g: constant counted waits vmcnt {8, 9, 10, 7} in steady state, fixed ladders in the last two K-tiles of
+//     the last tile.  Stores of an epilogue only add to the counter (never unsafe, at worst an early drain).
+//   * Epilogues: plain / bias stage bf16 rows through 4 KiB per wave above the ring (128-B row segments).  Residual / generic
+//     epilogues run from registers: the Q fragment rows are read in the order {0-3, 8-11, 4-7, 12-15}, so after one v_permlane32_swap
+//     per accumulator register a lane holds 8 CONSECUTIVE columns of its output row -- residual / gate are read and the result stored
+//     as 16-B accesses of 64-B row segments (the fragment-layout residual fetch cost the out-projection 19 % of its time).
+// Measured on MI355X (profiles/r2_gemm_bench_*.jsonl, same box, bit-identical results): +12 ... +18 % over the BK = 32 persistent ring on
+// every forward / dgrad shape of the ViT-L/14 step.  What the ablations said: the L2 -> LDS stream alone sustains 104 GB/s per CU
+// (tools/l2_stream_probe.hip) but a wave issues at most one piece per ~160 cycles, so DMA issue has to be spread over all 8 waves
+// and every period; without DMA the same loop runs at 1.5-1.6 PF.
+// Requires I % 256 == 0, J % 256 == 0, R % 64 == 0, R >= 128, bf16 output.
 #define K64F_PRIO 1
 #define K64F_NODMA 2
-#define K64F_DIST11 4    /* one DMA piece per barrier interval per wave (LOAD and MFMA intervals alike) instead of 1 / 3 / 3 / 1 per LOAD */
-#define K64F_DLATE 8     /* DIST11: the MFMA interval's piece goes after the 8th MFMA instead of after the 1st */
+#define K64F_DIST11 4    /* the second piece of a phase is issued behind the first MFMA of the MFMA block instead of behind the fragment reads */
+#define K64F_ONEBAR 32   /* ONE barrier per 16-MFMA phase: group A runs [MFMA(g-1), LOAD(g)], group B [LOAD(g), MFMA(g)] inside each period */
 #define K64F_CLK 16      /* experiment: workgroup 0 records shader-clock and 100-MHz-clock ticks across its run (effective clock under load) */
 #ifndef ANTMMF_EMULATE
 __device__ unsigned long long g_k64_clk[2];
@@ -1078,7 +960,8 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
     ANTMMF_DYN_LDS(char, smem);
     constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
     constexpr int STAGE = 65536, QOFF = 32768;
-    constexpr bool PRIO = FLAGS & K64F_PRIO, NODMA = FLAGS & K64F_NODMA, DIST11 = FLAGS & K64F_DIST11, DLATE = FLAGS & K64F_DLATE;
+    constexpr bool PRIO = FLAGS & K64F_PRIO, NODMA = FLAGS & K64F_NODMA, DIST11 = FLAGS & K64F_DIST11,
+                   ONEBAR = FLAGS & K64F_ONEBAR;
     // residual / generic epilogues run from registers (permuted Q rows + lane swap, 16-B accesses of 64-B row segments: the residual is read
     // coalesced); plain / bias epilogues stage through the 32 KiB of LDS above the ring (128-B row segments)
     constexpr bool SWAPEPI = (EPI & 2) || EPI == 4;
@@ -1184,15 +1067,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
     // WT: wait ladder -- 0 steady, 1 = K-tile nk - 2 of the LAST output tile, 2 = K-tile nk - 1 of the last output tile
 #define K64P_WAIT(PH, WT)                                                                                                            \
     do {                                                                                                                            \
-        if (DIST11) {                                                                                                               \
-            if (WT == 0) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<10>(); else glds_wait_le<7>(); } \
-            else if (WT == 1) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<3>(); } \
-            else { if (PH == 0) glds_wait_le<2>(); else if (PH == 1) glds_wait_le<1>(); else glds_wait_le<0>(); }                   \
-        } else {                                                                                                                    \
-            if (WT == 0) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<12>(); else if (PH == 2) glds_wait_le<14>(); else glds_wait_le<9>(); } \
-            else if (WT == 1) { if (PH == 0) glds_wait_le<12>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<2>(); } \
-            else { if (PH == 0) glds_wait_le<4>(); else if (PH == 1) glds_wait_le<1>(); else glds_wait_le<0>(); }                   \
-        }                                                                                                                           \
+        if (WT == 0) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<10>(); else glds_wait_le<7>(); } \
+        else if (WT == 1) { if (PH == 0) glds_wait_le<8>(); else if (PH == 1) glds_wait_le<9>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<3>(); } \
+        else { if (PH == 0) glds_wait_le<2>(); else if (PH == 1) glds_wait_le<1>(); else glds_wait_le<0>(); }                       \
     } while (0)
 #define K64P_PHASE(PH, WT)                                                                                                          \
     do {                                                                                                                            \
@@ -1207,21 +1084,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
         K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
         K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
         K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
-        if (DIST11) K64P_DMA11(2 * PH, WT);                                                                                         \
-        else if (!NODMA) {                                                                                                          \
-            int kk = t + (PH == 0 ? 1 : 2);                                                                                         \
-            const bool nx = kk >= nk;                                                                                               \
-            if (nx) kk -= nk;                                                                                                       \
-            const char* pbs = nx ? pgn : pgc;                                                                                       \
-            const char* qbs = nx ? qgn : qgc;                                                                                       \
-            const uint32_t st = PH == 0 ? (so ^ STAGE) : so;                                                                        \
-            if (WT == 0) {                                                                                                          \
-                if (PH == 0) { if (!first) dma_p(pbs, 3, kk, st); first = false; }                                                  \
-                else if (PH == 1) { dma_p(pbs, 0, kk, st); dma_q(qbs, 0, kk, st); dma_q(qbs, 1, kk, st); }                          \
-                else if (PH == 2) { dma_p(pbs, 1, kk, st); dma_q(qbs, 2, kk, st); dma_q(qbs, 3, kk, st); }                          \
-                else dma_p(pbs, 2, kk, st);                                                                                         \
-            } else if (WT == 1 && PH == 0) { if (!first) dma_p(pbs, 3, kk, st); first = false; }                                    \
-        }                                                                                                                           \
+        K64P_DMA11(2 * PH, WT);                                                                                                     \
         K64P_WAIT(PH, WT);                                                                                                          \
         K64_BARRIER();                                                                                                              \
         /* MFMA interval */                                                                                                         \
@@ -1233,7 +1096,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
                 _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                                  \
                     acc[2 * PH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks], acc[2 * PH + f][jt], 0, 0, 0); \
-                    if (DIST11 && (ks * 8 + f * 4 + jt) == (DLATE ? 7 : 0)) { SCHED_FENCE(); K64P_DMA11(2 * PH + 1, WT); SCHED_FENCE(); } \
+                    if ((ks * 8 + f * 4 + jt) == 0) { SCHED_FENCE(); K64P_DMA11(2 * PH + 1, WT); SCHED_FENCE(); } \
                 }                                                                                                                   \
         if (PRIO) K64_SETPRIO(0);                                                                                                   \
         SCHED_FENCE();                                                                                                              \
@@ -1250,9 +1113,89 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
         for (int a = 0; a < TI; ++a)
 #pragma unroll
             for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (late) K64_BARRIER();  // group B runs one barrier interval behind group A
         const int tend = more ? nk : nk - 2;
         int t = 0;
+        if (ONEBAR) {
+            // One barrier per phase.  Period g = 4 t + ph:  group A (waves 0-3): MFMA(g - 1) then LOAD(g);  group B: LOAD(g) then MFMA(g).  The two
+            // waves of a SIMD start a period on opposite sides (matrix / memory) and cross over in the middle, the matrix pipe is shared.
+            // Refills (two pieces per period per wave, A then B):  ph0 P q0 q1 (t+1) | ph1 P q2 q3 (t+1) | ph2 Q q0 q1 (t+2) | ph3 Q q2 q3 (t+2):
+            // a quarter read in period g (group B early, group A late; group A's lgkmcnt(0) sits behind the NEXT barrier) is refilled in period
+            // g + 2 or later.  Waits at the end of a period cover what phase g + 1 reads: the same ladders as the DIST11 schedule.
+#define K64Q_PIECE(IDX, WT)                                                                                                         \
+    do {                                                                                                                            \
+        if (!NODMA && (WT == 0 || (WT == 1 && IDX < 4))) {                                                                          \
+            int kk = t + (IDX < 4 ? 1 : 2);                                                                                         \
+            const bool nx = kk >= nk;                                                                                               \
+            if (nx) kk -= nk;                                                                                                       \
+            const char* pbs = nx ? pgn : pgc;                                                                                       \
+            const char* qbs = nx ? qgn : qgc;                                                                                       \
+            const uint32_t st = IDX < 4 ? (so ^ STAGE) : so;                                                                        \
+            if (IDX < 4) { if (!first) dma_p(pbs, IDX, kk, st); if (IDX == 3) first = false; }                                      \
+            else dma_q(qbs, IDX - 4, kk, st);                                                                                       \
+        }                                                                                                                           \
+    } while (0)
+#define K64Q_READS(PH)                                                                                                              \
+    do {                                                                                                                            \
+        if (PH == 0) {                                                                                                              \
+            K64_READ(qa[0], so + qbase[0], 0);    K64_READ(qa[1], so + qbase[2], 0);                                                \
+            K64_READ(qa[2], so + qbase[1], 2048); K64_READ(qa[3], so + qbase[3], 2048);                                             \
+            K64_READ(qa[4], so + qbase[2], 4096); K64_READ(qa[5], so + qbase[0], 4096);                                             \
+            K64_READ(qa[6], so + qbase[3], 6144); K64_READ(qa[7], so + qbase[1], 6144);                                             \
+        }                                                                                                                           \
+        K64_READ(pb[0], so + pbase[((PH & 1) * 2 + 0)], PH * 4096);                                                                 \
+        K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
+        K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
+        K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
+    } while (0)
+    /* MPH: the phase whose MFMAs run; PIDX >= 0: the DMA piece issued behind the first MFMA (DIST11) */
+#define K64Q_MFMA(MPH, PIDX, WT)                                                                                                    \
+    do {                                                                                                                            \
+        if (MPH == 0) K64_FENCE8(qa);                                                                                               \
+        K64_FENCE4(pb);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+        if (PRIO) K64_SETPRIO(1);                                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                            \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
+                _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                                  \
+                    acc[2 * MPH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks], acc[2 * MPH + f][jt], 0, 0, 0); \
+                    if (PIDX >= 0 && (ks * 8 + f * 4 + jt) == 0) { SCHED_FENCE(); K64Q_PIECE((PIDX < 0 ? 0 : PIDX), WT); SCHED_FENCE(); } \
+                }                                                                                                                   \
+        if (PRIO) K64_SETPRIO(0);                                                                                                   \
+        SCHED_FENCE();                                                                                                              \
+    } while (0)
+    /* ONE instruction stream  L(0) M(0) L(1) M(1) ...  for both groups; group A's barrier sits behind every LOAD, group B's behind every MFMA block,
+       so A's periods are [M(g-1) L(g)] and B's [L(g) M(g)].  A waits (vmcnt) before the piece issued inside M(g): its ladder is B's minus that piece. */
+#define K64Q_WAIT_A(PH, WT)                                                                                                         \
+    do {                                                                                                                            \
+        if (!DIST11) K64P_WAIT(PH, WT);                                                                                             \
+        else if (WT == 0) { if (PH == 0) glds_wait_le<7>(); else if (PH == 1) glds_wait_le<8>(); else if (PH == 2) glds_wait_le<9>(); else glds_wait_le<6>(); } \
+        else if (WT == 1) { if (PH == 0) glds_wait_le<7>(); else if (PH == 1) glds_wait_le<8>(); else if (PH == 2) glds_wait_le<8>(); else glds_wait_le<3>(); } \
+        else K64P_WAIT(PH, WT);                                                                                                     \
+    } while (0)
+#define K64Q_PHASE(PH, WT)                                                                                                          \
+    do {                                                                                                                            \
+        K64Q_READS(PH);                                                                                                             \
+        K64Q_PIECE(2 * PH, WT);                                                                                                     \
+        if (!DIST11) K64Q_PIECE(2 * PH + 1, WT);                                                                                    \
+        if (!late) { K64Q_WAIT_A(PH, WT); K64_BARRIER(); }                                                                          \
+        if (DIST11) K64Q_MFMA(PH, 2 * PH + 1, WT); else K64Q_MFMA(PH, -1, WT);                                                      \
+        if (late) { K64P_WAIT(PH, WT); K64_BARRIER(); }                                                                             \
+    } while (0)
+#define K64Q_TILE(WT) do { K64Q_PHASE(0, WT); K64Q_PHASE(1, WT); K64Q_PHASE(2, WT); K64Q_PHASE(3, WT); so ^= STAGE; } while (0)
+            for (; t < tend; ++t) K64Q_TILE(0);
+            if (!more) {
+                K64Q_TILE(1);
+                ++t;
+                K64Q_TILE(2);
+            }
+#undef K64Q_TILE
+#undef K64Q_PHASE
+#undef K64Q_WAIT_A
+#undef K64Q_MFMA
+#undef K64Q_READS
+#undef K64Q_PIECE
+        } else {
+        if (late) K64_BARRIER();  // group B runs one barrier interval behind group A
         for (; t < tend; ++t) K64P_TILE(0);
         if (!more) {
             K64P_TILE(1);
@@ -1260,6 +1203,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             K64P_TILE(2);
         }
         if (!late) K64_BARRIER();  // both groups enter the epilogue together
+        }
 
         if (!SWAPEPI) {
             // bias in the fragment layout, then bf16 rows staged through this wave's 4 KiB above the ring (asm LDS traffic: pieces of the
@@ -1529,8 +1473,139 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
     gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, g.ksteps_per_split < nk_total);
 }
 
-// Experiment / test knob (tools/gemm_bench, tests): bit 0 = route the large all-r-contiguous GEMMs to gemm_nt_k64_kernel, bit 1 = the same
-// without s_setprio; initialised from ANTMMF_GEMM_VARIANT.
+// ---- gemm_tn_k64_kernel: wgrad dW += dY^T X with the schedule of gemm_nt_k64p_kernel ---------------------------------------------------
+// K-tiles of 64 tokens, two 64-KiB stages ([64 tokens][256 cols] per operand, natural token-major image, 512-B rows, the 32-B chunk swizzle
+// ftr of the ring kernel), fragments by ds_read_b64_tr_b16.  Four phases of 16 MFMAs per K-tile: phase (ks, ih) = 32-token half ks x
+// output rows [64 ih, +64) of the wave (4 P fragments, read in that phase) x all four Q fragments of that half (read in (ks, 0)):
+// 16 / 8 / 16 / 8 transposing reads.  One barrier per phase, same L M stream as the NT kernel (group A barrier behind L, group B behind M).
+// Ring units are the 32-token halves (16 P + 16 Q pieces of 2 rows x 512 B, 4 per wave): half 0 of a stage is read in ph0, ph1 and
+// refilled in ph3 (P pieces) and ph0' (Q pieces) with the data two K-tiles ahead; half 1 is read in ph2, ph3 and refilled in ph1', ph2'
+// (>= 2 periods after the last read period, needed >= 4 periods later).  Waits: only before the phases that open a new half (ph1 -> ph2,
+// ph3 -> ph0'): vmcnt(6) in steady state.  The token range is split over gridDim (fp32 partial tiles to the workspace, as before).
+template <int FLAGS>
+__global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4, ROWB = 512, STAGE = 65536, QOFF = 32768;
+    constexpr bool PRIO = FLAGS & K64F_PRIO;
+    const int lane = threadIdx.x & 63;
+#ifdef ANTMMF_EMULATE
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tiles_j = g.J / BN, tiles = (g.I / BM) * tiles_j;
+    const int split = wgid / tiles, tile = wgid - split * tiles;
+    const int i0 = (tile / tiles_j) * BM, j0 = (tile % tiles_j) * BN;
+    const int nk_total = g.R >> 6;                  // 64-token K-tiles
+    const int kbeg = split * g.ksteps_per_split;    // ksteps_per_split counts 64-token K-tiles here
+    int kend = kbeg + g.ksteps_per_split;
+    if (kend > nk_total) kend = nk_total;
+    if (kbeg >= kend) return;
+    const int nk = kend - kbeg;                     // >= 2 (host)
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // DMA: piece = 2 token rows x 512 B; half h of a stage = rows [32 h, +32) = pieces 16 h .. 16 h + 15 of each operand, wave w moves
+    // pieces 16 h + 2 w, + 1.  Per-lane source offsets (bytes) inside a piece pair are loop-invariant.
+    const char* pgb = reinterpret_cast<const char*>(g.P + i0) + (long)kbeg * 64 * g.ldp * 2;   // token row kbeg * 64 of this split
+    const char* qgb = reinterpret_cast<const char*>(g.Q + j0) + (long)kbeg * 64 * g.ldq * 2;
+    uint32_t pvo[2], qvo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int lin = (wave * 2 + q) * 64 + lane;  // 16-B slot index within the half's [32][512 B] image
+        const int row = lin >> 5, sidx = lin & 31;
+        const int col = (((sidx >> 1) ^ ftr(row)) << 4) + ((sidx & 1) << 3);   // ftr(row + 32 h) == ftr(row): bits 0, 1, 3 only
+        pvo[q] = (uint32_t)(row * (int)(g.ldp * 2) + col * 2);
+        qvo[q] = (uint32_t)(row * (int)(g.ldq * 2) + col * 2);
+    }
+    auto dma_p = [&](int h, int kk, uint32_t st) {
+        const char* b = pgb + ((long)kk * 64 + 32 * h) * g.ldp * 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(b + pvo[q], smem + st + (16 * h + wave * 2 + q) * 1024);
+    };
+    auto dma_q = [&](int h, int kk, uint32_t st) {
+        const char* b = qgb + ((long)kk * 64 + 32 * h) * g.ldq * 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(b + qvo[q], smem + st + QOFF + (16 * h + wave * 2 + q) * 1024);
+    };
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { dma_p(h, tt, tt * STAGE); dma_q(h, tt, tt * STAGE); }
+    glds_wait_all();
+    wg_barrier_lds_only();
+
+    bf16x8_t qa[4], pb[4];
+    const bool late = wave >= 4;
+    uint32_t so = 0;
+    bool first = true;   // first K-tile: K-tile 1 is complete, the refills that target it are skipped
+    // WT: 0 steady, 1 = K-tile nk - 2, 2 = K-tile nk - 1
+#define TK_PIECES(PH, WT)                                                                                                           \
+    do {                                                                                                                            \
+        if (WT == 0 || (WT == 1 && PH < 3)) {                                                                                       \
+            const int kk = t + (PH < 3 ? 1 : 2);                                                                                    \
+            const uint32_t st = PH < 3 ? (so ^ STAGE) : so;                                                                         \
+            if (PH == 0) { if (!first) dma_q(0, kk, st); }                                                                          \
+            else if (PH == 1) { if (!first) dma_p(1, kk, st); }                                                                     \
+            else if (PH == 2) { if (!first) dma_q(1, kk, st); first = false; }                                                      \
+            else dma_p(0, kk, st);                                                                                                  \
+        }                                                                                                                           \
+    } while (0)
+#define TK_WAIT(PH, WT)                                                                                                             \
+    do {                                                                                                                            \
+        if (PH == 1) { if (WT == 2) glds_wait_le<0>(); else glds_wait_le<6>(); }                                                    \
+        else if (PH == 3) { if (WT == 0) glds_wait_le<6>(); else if (WT == 1) glds_wait_le<4>(); else glds_wait_le<0>(); }          \
+    } while (0)
+#define TK_PHASE(PH, WT)                                                                                                            \
+    do {                                                                                                                            \
+        const char* ps = smem + so;                                                                                                 \
+        const char* qs = ps + QOFF;                                                                                                 \
+        if ((PH & 1) == 0) {                                                                                                        \
+            _Pragma("unroll") for (int jt = 0; jt < TJ; ++jt) qa[jt] = frag_tr_raw<ROWB>(qs, 32 * (PH >> 1) + 8 * grp, wj * TJ + jt, l15); \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) pb[f] = frag_tr_raw<ROWB>(ps, 32 * (PH >> 1) + 8 * grp, wi * TI + 4 * (PH & 1) + f, l15); \
+        TK_PIECES(PH, WT);                                                                                                          \
+        if (!late) { TK_WAIT(PH, WT); K64_BARRIER(); }                                                                              \
+        if ((PH & 1) == 0) K64_FENCE4(qa);                                                                                          \
+        K64_FENCE4(pb);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+        if (PRIO) K64_SETPRIO(1);                                                                                                   \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                                               \
+            _Pragma("unroll") for (int jt = 0; jt < TJ; ++jt)                                                                       \
+                acc[4 * (PH & 1) + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[f], acc[4 * (PH & 1) + f][jt], 0, 0, 0); \
+        if (PRIO) K64_SETPRIO(0);                                                                                                   \
+        SCHED_FENCE();                                                                                                              \
+        if (late) { TK_WAIT(PH, WT); K64_BARRIER(); }                                                                               \
+    } while (0)
+#define TK_TILE(WT) do { TK_PHASE(0, WT); TK_PHASE(1, WT); TK_PHASE(2, WT); TK_PHASE(3, WT); so ^= STAGE; } while (0)
+    int t = 0;
+    for (; t < nk - 2; ++t) TK_TILE(0);
+    TK_TILE(1);
+    ++t;
+    TK_TILE(2);
+#undef TK_TILE
+#undef TK_PHASE
+#undef TK_WAIT
+#undef TK_PIECES
+    wg_barrier_lds_only();  // every wave is past its last MFMA block and nothing is in flight: the stages are free
+    if (g.ws) {
+        store_partial_f32_staged<TI, TJ>(g.ws + (long)split * g.I * g.J + (long)i0 * g.J + j0, g.J, acc, wi, wj, lane, smem + wave * 16384);
+        return;
+    }
+    gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, nk < nk_total);
+}
+
+// Experiment / test knob (tools/gemm_bench, tests), initialised from ANTMMF_GEMM_VARIANT: 0 = the BK = 32 ring kernels of round 1; bit 2 (default) routes
+// the large 256-aligned all-r-contiguous GEMMs to gemm_nt_k64p_kernel; further bits select its A/B forms (see the launch site).
 static int g_gemm_variant = -1;
 static long g_k64_launches = 0;
 extern "C" int antmmf_debug_set_gemm_variant(int v) { g_gemm_variant = v; return ANTMMF_OK; }
@@ -1599,8 +1674,6 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         if (!oncep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64p_kernel<E_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); oncep = true; } \
         hipLaunchKernelGGL((gemm_nt_k64p_kernel<E_, F_>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);              \
     } while (0)
-        const bool k64 = (g_gemm_variant & 3) && c_dtype == ANTMMF_BF16 && !(ldc & 7) && !(I & 255) && !(J & 255) && R >= 128 &&
-                         (force ? force[0] == 'k' : tiles256 >= 512);
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
@@ -1616,29 +1689,12 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             ++g_k64_launches;                                                                                                     \
             const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);  /* the tile walk needs a multiple of 8 workgroups (XCD = id % 8) */ \
             const unsigned gridp = (g_gemm_variant & 64) ? t8 : (pwgs < t8 ? pwgs : t8);                                          \
-            /* variant bits: 8 NODMA (timing experiment), 16 = 1 / 3 / 3 / 1 pieces per LOAD instead of one per interval, 32 = late piece, 128 no setprio */ \
-            const int fsel = ((g_gemm_variant & 128) ? 0 : 1) | ((g_gemm_variant & 16) ? 0 : 2) | ((g_gemm_variant & 32) ? 4 : 0) | ((g_gemm_variant & 8) ? 8 : 0) | ((g_gemm_variant & 256) ? 16 : 0); \
-            switch (fsel) {                                                                                                       \
-                case 1: K64P_LAUNCH(E, K64F_PRIO); break;                                                                         \
-                case 2: K64P_LAUNCH(E, K64F_DIST11); break;                                                                       \
-                case 3: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11); break;                                                           \
-                case 7: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_DLATE); break;                                              \
-                case 11: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_NODMA); break;                                             \
-                case 19: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_CLK); break;                                               \
-                case 27: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11 | K64F_NODMA | K64F_CLK); break;                                  \
-                default: K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11); break;                                                          \
-            }                                                                                                                     \
-        }                                                                                                                         \
-        else if (k64) {                                                                                                           \
-            ++g_k64_launches;                                                                                                     \
-            static bool once64 = false;                                                                                           \
-            if (!once64) {                                                                                                        \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64_kernel<E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64_kernel<E, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-                once64 = true;                                                                                                    \
-            }                                                                                                                     \
-            if (g_gemm_variant & 2) hipLaunchKernelGGL((gemm_nt_k64_kernel<E, false>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
-            else hipLaunchKernelGGL((gemm_nt_k64_kernel<E, true>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g);       \
+            /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
+            constexpr int PROD = K64F_ONEBAR | ((E & 2) && E != 4 ? K64F_DIST11 : 0);                                             \
+            if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);                                                     \
+            else if (g_gemm_variant & 128) K64P_LAUNCH(E, PROD);                                                                  \
+            else if (g_gemm_variant & 256) K64P_LAUNCH(E, PROD | K64F_PRIO | K64F_CLK);                                           \
+            else K64P_LAUNCH(E, PROD | K64F_PRIO);                                                                                \
         }                                                                                                                         \
         else if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                  \
             if (cont) hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256); \
@@ -1679,6 +1735,32 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             once = true;
+        }
+        if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; }
+        // BK = 64 schedule (default; variant bit 10 = the BK = 32 ring for A/B): K-tiles of 64 tokens, every split needs >= 2 of them
+        int k64_steps = 0, k64_zs = 0;
+        if ((g_gemm_variant & 4) && !(g_gemm_variant & 1024) && (R & 63) == 0 && R >= 128) {
+            const int nk64 = R / 64;
+            int spl = sp < nk64 / 2 ? sp : nk64 / 2;
+            if (spl < 1) spl = 1;
+            k64_steps = (nk64 + spl - 1) / spl;
+            while ((nk64 % k64_steps) == 1) ++k64_steps;   // a trailing split of a single K-tile would have no steady state
+            k64_zs = (nk64 + k64_steps - 1) / k64_steps;
+        }
+        if (k64_steps >= 2) {
+            g.ksteps_per_split = k64_steps;
+            const bool ws64 = k64_zs > 1 && workspace && workspace_bytes >= (long)k64_zs * I * J * 4;
+            g.ws = ws64 ? workspace : nullptr;
+            static bool once64 = false;
+            if (!once64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_k64_kernel<K64F_PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once64 = true; }
+            ++g_k64_launches;
+            hipLaunchKernelGGL(gemm_tn_k64_kernel<K64F_PRIO>, dim3((unsigned)(tiles * k64_zs)), dim3(512), 131072, stream, g);
+            if (ws64) {
+                const long nvec = (long)I * J / 4;
+                const int rg = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, workspace, reinterpret_cast<float*>(C), k64_zs, I, J, ldc, 1);
+            }
+            return antmmf_check_launch();
         }
         if (g.raster & 16) hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
         else hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);

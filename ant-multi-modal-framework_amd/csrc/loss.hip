@@ -332,10 +332,15 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float* __restrict_
     const float* r = S + (long)i * ld;
     int best = cols;
     for (int g = gt_off[i]; g < gt_off[i + 1]; ++g) {
-        const float thr = r[gt_idx[g]];
+        // position of the ground truth in a STABLE descending sort (the reference argsorts -S): strictly larger scores, plus equal scores at a
+        // lower column index -- a collapsed model (all scores equal) gets index-order ranks, not rank 0; NaN scores of other columns sort last
+        // (never counted), a NaN ground-truth score is the worst rank
+        const int gj = gt_idx[g];
+        const float thr = r[gj];
         float c = 0.f;
-        for (int j = threadIdx.x; j < cols; j += 256) c += r[j] > thr ? 1.f : 0.f;
-        const int cnt = (int)block_sum(c, shf);
+        for (int j = threadIdx.x; j < cols; j += 256) { const float v = r[j]; c += (v > thr || (v == thr && j < gj)) ? 1.f : 0.f; }
+        int cnt = (int)block_sum(c, shf);
+        if (!(thr == thr)) cnt = cols - 1;
         best = cnt < best ? cnt : best;
     }
     if (threadIdx.x == 0) rank[i] = best;

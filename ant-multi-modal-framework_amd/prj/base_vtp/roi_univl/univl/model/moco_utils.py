@@ -7,8 +7,8 @@ moco_loss, dequeue_and_enqueue) and hyper-parameters (K, M, T from the config). 
     parameter arena (plus a bf16 compute shadow), so the momentum update is a single fused launch over the whole arena
     (`antmmf_ema_update`: k = m k + (1 - m) q, shadow = bf16(k)) instead of a Python loop over ~190 M parameters;
   * the loss reads the [R, K] negatives once in a fused row kernel (`antmmf_moco_fwd/bwd`);
-  * enqueue gathers keys with one all_gather_into_tensor, guards NaNs on device (no `.item()` host sync) and keeps the
-    write pointer on the host."""
+  * enqueue gathers keys with one all_gather_into_tensor; write pointer (the checkpointed `*_queue_ptr` buffer) and NaN guard
+    live on the device: a non-finite batch leaves queue AND pointer untouched, as in the reference, without a host sync."""
 import copy
 
 import torch
@@ -41,7 +41,6 @@ class MocoUtils(nn.Module):
             q = torch.nn.functional.normalize(torch.randn(self.dim, self.txt_K), dim=0)
             self.register_buffer("txt_queue", q)
             self.register_buffer("txt_queue_ptr", torch.zeros(1, dtype=torch.long))
-        self._ptr = {"img": 0, "txt": 0}
         self._flat = None  # (k_master, k_shadow, q_arena) once the key towers mirror the optimizer arena
 
     def _key_copy(self, enc_q):
@@ -92,19 +91,20 @@ class MocoUtils(nn.Module):
     # ------------------------------------------------------------------ queue
     @torch.no_grad()
     def dequeue_and_enqueue(self, vis_keys, txt_keys):
-        def push(keys, which, queue, queue_ptr, K):
+        def push(keys, queue, queue_ptr, K):
             keys = contrastive._all_gather(keys.detach().float().contiguous(), None)
             n = keys.shape[0]
-            ptr = self._ptr[which]
-            end_ptr = min(ptr + n, K)
-            start_ptr = end_ptr - n
-            ok = torch.isfinite(keys).all()  # the reference skips the whole update when a NaN appears (host sync); here on device
-            new = torch.where(ok, keys.t().to(queue.dtype), queue[:, start_ptr:end_ptr])
-            queue[:, start_ptr:end_ptr] = new
-            self._ptr[which] = end_ptr % K
-            queue_ptr[0] = self._ptr[which]
+            # the write pointer IS the checkpointed `*_queue_ptr` buffer and stays on the device: the slot indices are computed from it
+            # there (end = min(ptr + n, K), start = end - n, as moco_utils.py:98-103), so neither the pointer nor the NaN guard ever
+            # syncs with the host.  A non-finite batch leaves queue AND pointer untouched, as in the reference (:92-96).
+            start = torch.clamp(queue_ptr + n, max=K) - n
+            cols = start + torch.arange(n, device=queue.device)
+            ok = torch.isfinite(keys).all()
+            new = torch.where(ok, keys.t().to(queue.dtype), queue.index_select(1, cols))
+            queue.index_copy_(1, cols, new)
+            queue_ptr.copy_(torch.where(ok, (start + n) % K, queue_ptr))
 
         if self.img_encoder_q is not None:
-            push(vis_keys, "img", self.img_queue, self.img_queue_ptr, self.img_K)
+            push(vis_keys, self.img_queue, self.img_queue_ptr, self.img_K)
         if self.txt_encoder_q is not None:
-            push(txt_keys, "txt", self.txt_queue, self.txt_queue_ptr, self.txt_K)
+            push(txt_keys, self.txt_queue, self.txt_queue_ptr, self.txt_K)

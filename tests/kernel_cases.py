@@ -495,6 +495,15 @@ def case_retrieval_metrics(dev, golden):
     m.collect(None, {"l1_simi": g["rect.sim"][9:].to(dev)}, 1, 0, t2v=t2v[9:])
     summ = m.summarize()
     assert abs(float(summ["l1_simi_t2v-mr"]) - float(g["rect.t2v-mr"])) < 1e-6 and abs(float(summ["l1_simi_v2t-r@5"]) - float(g["rect.v2t-r@5"])) < 1e-6
+    # degenerate score matrices must not look like perfect retrieval: all-equal scores rank by column index (stable argsort of the
+    # reference), a NaN ground-truth score ranks last
+    flat = grr._cal_recall(torch.zeros(16, 16, device=dev))
+    assert abs(flat["r@1"] - 1 / 16) < 1e-6 and abs(flat["r@5"] - 5 / 16) < 1e-6 and abs(flat["mr"] - 8.5) < 1e-6, flat
+    nan = grr._cal_recall(torch.full((16, 16), float("nan"), device=dev))
+    assert nan["r@1"] == 0.0 and nan["r@10"] == 0.0 and nan["mr"] == 16.0, nan
+    ref_sorted = (-g["sq.sim"]).argsort(dim=1, stable=True)
+    ref_rank = (ref_sorted == torch.arange(g["sq.sim"].shape[0])[:, None]).float().argmax(dim=1)
+    assert torch.equal(grr.gt_ranks(g["sq.sim"].to(dev)).cpu().long(), ref_rank)
 
 
 # ------------------------------------------------------------------------------ dropout (counter-based masks)

@@ -12,6 +12,18 @@
 typedef int (*gemm_fn)(const void*, const void*, void*, int, int, int, long, long, long, int, int, int, float, const float*, int, const void*, long,
                        void*, long, const void*, long, int, int, hipStream_t);
 typedef int (*setv_fn)(int);
+typedef int (*wgrad_fn)(const void*, const void*, float*, long, int, int, long, long, long, int, float*, long, hipStream_t);
+__global__ void maxdiff_f32(const float* a, const float* b, long n, unsigned* out, unsigned* outmag) {
+    unsigned m = 0, mm = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        const unsigned u = (d == d) ? __float_as_uint(d) : 0x7f800000u;
+        m = u > m ? u : m;
+        const unsigned v = __float_as_uint(fabsf(a[i]));
+        mm = v > mm ? v : mm;
+    }
+    atomicMax(out, m); atomicMax(outmag, mm);
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void fill_bf16(uint16_t* p, long n, uint32_t seed, float scale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -99,6 +111,42 @@ int main(int argc, char** argv) {
             printf("{\"shape\": \"%s\", \"clock_mhz\": %.0f, \"I\": %ld, \"J\": %d, \"R\": %d, \"epi\": %d, \"variant\": %d, \"pad\": %d, \"ms_med\": %.4f, \"tf_med\": %.1f, \"tf_best\": %.1f, \"maxdiff_vs_v0\": %g}\n",
                    s.tag, mhz, tokens, s.J, s.R, s.bias | (s.res << 1), variants[vi], pad, med, fl / med * 1e-9, fl / best * 1e-9, diff[vi]);
             fflush(stdout);
+        }
+    }
+    // ---- wgrad (TN): dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in]
+    wgrad_fn wgrad = (wgrad_fn)dlsym(h, "antmmf_gemm_wgrad_bf16");
+    if (wgrad && !getenv("GEMM_BENCH_NO_TN")) {
+        struct WS { const char* tag; int n_out, k_in; };
+        const WS wss[] = {{"wgrad_fc1", 4096, 1024}, {"wgrad_fc2", 1024, 4096}, {"wgrad_out", 1024, 1024}, {"wgrad_qkv", 3072, 1024}};
+        float *dW0, *dW1, *wsb; unsigned* dm2;
+        const long wsbytes = 32L * 4096 * 1024 * 4;
+        CK(hipMalloc(&dW0, 4096L * 4096 * 4)); CK(hipMalloc(&dW1, 4096L * 4096 * 4)); CK(hipMalloc(&wsb, wsbytes)); CK(hipMalloc(&dm2, 8));
+        std::vector<int> tv = {1028, 4};
+        for (const WS& w : wss) {
+            auto runw = [&](int v, float* out) { setv(v); return wgrad(Rz, A, out, tokens, w.n_out, w.k_in, w.n_out, w.k_in, w.k_in, 1, wsb, wsbytes, 0); };
+            CK(hipMemset(dW0, 0, (long)w.n_out * w.k_in * 4)); CK(hipMemset(dW1, 0, (long)w.n_out * w.k_in * 4));
+            runw(tv[0], dW0); runw(tv[1], dW1);
+            CK(hipMemset(dm2, 0, 8));
+            maxdiff_f32<<<1024, 256>>>(dW0, dW1, (long)w.n_out * w.k_in, dm2, dm2 + 1);
+            unsigned u2[2]; CK(hipMemcpy(u2, dm2, 8, hipMemcpyDeviceToHost));
+            std::vector<std::vector<double>> ms(tv.size());
+            for (int r = 0; r < rounds; ++r)
+                for (size_t vi = 0; vi < tv.size(); ++vi) {
+                    const int iters = 8;
+                    runw(tv[vi], dW1);
+                    CK(hipEventRecord(e0, 0));
+                    for (int it = 0; it < iters; ++it) runw(tv[vi], dW1);
+                    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    float t; CK(hipEventElapsedTime(&t, e0, e1));
+                    ms[vi].push_back(t / iters);
+                }
+            for (size_t vi = 0; vi < tv.size(); ++vi) {
+                std::sort(ms[vi].begin(), ms[vi].end());
+                const double med = ms[vi][ms[vi].size() / 2], fl = 2.0 * tokens * w.n_out * w.k_in;
+                printf("{\"shape\": \"%s\", \"tokens\": %ld, \"n_out\": %d, \"k_in\": %d, \"variant\": %d, \"ms_med\": %.4f, \"tf_med\": %.1f, \"maxdiff_new_vs_old\": %g, \"max_abs\": %g}\n",
+                       w.tag, tokens, w.n_out, w.k_in, tv[vi], med, fl / med * 1e-9, *reinterpret_cast<float*>(&u2[0]), *reinterpret_cast<float*>(&u2[1]));
+                fflush(stdout);
+            }
         }
     }
     return 0;
