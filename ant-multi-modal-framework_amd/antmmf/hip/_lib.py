@@ -37,6 +37,7 @@ _SIGNATURES = {
     "antmmf_embed_gather": [P, P, P, P, P, P, P, L, I, I, I, P],
     "antmmf_embed_scatter_add": [P, P, P, P, L, I, I, I, P],
     "antmmf_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, F, P],
+    "antmmf_adamw_step_scaled": [P, P, P, P, P, L, F, F, F, F, F, I, F, P, P],
     "antmmf_sumsq": [P, P, L, P],
     "antmmf_gemm_bf16": [P, P, P, I, I, I, L, L, L, I, I, I, F, P, I, P, L, P, L, P, L, I, I, P],
     "antmmf_gemm_wgrad_bf16": [P, P, P, L, I, I, L, L, L, I, P, L, P],

@@ -214,9 +214,17 @@ def embed_scatter_add_(dtable, dx, idx=None, skip_rows=None, seq=1, offset=0):
 
 
 def adamw_step_(p, g, m, v, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """grad_scale: a Python number, or a 1-element fp32 DEVICE tensor (e.g. 1/world x clip coefficient) that is read by the kernel."""
     _dev_ok(p, g, m, v, shadow)
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _c(t, n); _f32(t, n)
+    if torch.is_tensor(grad_scale):
+        gs = grad_scale.detach().reshape(-1)[:1].float().contiguous()
+        _dev_ok(p, gs)
+        _rc(_lib.load().antmmf_adamw_step_scaled(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
+                                                 float(beta2), float(eps), float(weight_decay), int(step), 1.0, _p(gs),
+                                                 _stream()), "antmmf_adamw_step_scaled")
+        return
     _rc(_lib.load().antmmf_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
                                       float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
                                       _stream()), "antmmf_adamw_step")

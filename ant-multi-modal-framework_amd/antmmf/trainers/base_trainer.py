@@ -10,7 +10,16 @@ keys the loop reads, `_forward_pass / _extract_loss / _backward / _update_meter`
   * bf16 compute with fp32 masters instead of fp16 autocast + GradScaler (no scaler, no unscale pass);
   * `current_iteration` advances ONCE per batch (the reference increments it twice, base_trainer.py:551,589, so its
     max_iterations / lr steps count half-steps; documented deviation, see DESIGN.md);
-  * the per-iteration reduce_dict of losses is skipped when the model already returns globally reduced losses.
+  * the per-iteration reduce_dict of losses is skipped when the model already returns globally reduced losses;
+  * meters stay ON THE DEVICE: losses and the gradient norm are accumulated as tensors and read (one sync) only at `log_interval`,
+    evaluation and the end of training -- the reference's `float(v)` per loss per iteration and the `.item()` in clip_gradients
+    are host syncs that stall kernel launch-ahead; the clip coefficient is computed on the device and handed to the fused AdamW as a tensor.
+Also kept: the LR schedule (`lr_scheduler: true` -> LambdaLR over `lr_lambda_update`: warm-up, `lr_steps` / `lr_epochs`, `lr_ratio`;
+a model's `get_custom_scheduler(trainer)` wins; reference base_trainer.py:445-464, 604-607, utils/general.py:27-44), gradient accumulation under
+the reference key `gradient_accumulation_steps` (base.yml:174; `update_frequency` kept as an alias), evaluation every `evaluation_interval`
+iterations with early stopping on `monitored_metric` (`should_early_stop`, `patience`, `metric_minimize`; base_trainer.py:473-530 `_logistics`),
+the scheduled hard-mining ratio `incre_num` of the CN-VID configs (base_trainer.py:552-571) and the fp32 escape list
+`amp_attributes.amp_escapes` (antmmf/utils/register_fp32.py:42-69).
 Checkpointing (antmmf.common.checkpoint.Checkpoint, same files and keys as the reference's) is active when
 `training_parameters.save_dir` / `resume_file` / `resume` is set: `load()` restores, `train()` snapshots every
 `snapshot_interval` iterations and writes `<model>_final.pth` at the end (reference: base_trainer.py:184-218,373-397,555-607).
@@ -20,6 +29,8 @@ iterable of SampleLists (tests / bench feed synthetic ones).
 import math
 import os
 import time
+import warnings
+from bisect import bisect
 
 import torch
 import torch.distributed as dist
@@ -40,6 +51,8 @@ class BaseTrainer:
         self.current_iteration = 0
         self.current_epoch = 0
         self.meters = {}
+        self._dev_meters = {}
+        self.val_batches = None
         self.checkpoint = None
 
     # ------------------------------------------------------------------ load
@@ -50,10 +63,22 @@ class BaseTrainer:
         tp = self.config.training_parameters
         self.max_iterations = tp.get("max_iterations", math.inf)
         self.log_interval = tp.get("log_interval", 100)
-        self.gradient_accumulation_steps = max(1, int(tp.get("update_frequency", 1)))
+        gas = tp.get("gradient_accumulation_steps", None)
+        if gas is None:
+            gas = tp.get("update_frequency", 1)      # this build's earlier name, kept as an alias
+        self.gradient_accumulation_steps = int(gas)
+        assert self.gradient_accumulation_steps >= 1
         self.should_clip_gradients = bool(tp.get("clip_gradients", False))
         self.max_grad_l2_norm = tp.get("max_grad_l2_norm", None)
         self.snapshot_interval = tp.get("snapshot_interval", None)
+        self.evaluation_interval = tp.get("evaluation_interval", None)
+        self.should_early_stop = bool(tp.get("should_early_stop", False))
+        self.patience = tp.get("patience", 30000)
+        self.monitored_metric = tp.get("monitored_metric", "total_loss")
+        self.metric_minimize = bool(tp.get("metric_minimize", True))
+        self.best_monitored, self.best_iteration = None, 0
+        self.epoch_iterations = len(self.train_batches) if hasattr(self.train_batches, "__len__") else 0
+        self.setup_lr_scheduler()
         self.load_extras()
 
     def load_extras(self):
@@ -95,6 +120,11 @@ class BaseTrainer:
             from antmmf.utils.optim_utils import replace_speedup_op
 
             replace_speedup_op(self.model)
+        escapes = self.config.get("amp_attributes", {}).get("amp_escapes", None) if hasattr(self.config, "get") else None
+        if escapes:
+            from antmmf.utils.register_fp32 import set_escapes_class_fp32
+
+            set_escapes_class_fp32(self.model, escapes)
         if get_world_size() > 1:  # identical replicas: broadcast rank 0's initial weights
             for p in self.model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -104,35 +134,115 @@ class BaseTrainer:
         self.arena = getattr(self.optimizer, "arena", None)
         self.lr_scheduler = None
 
-    def load_task(self, batches):
+    def load_task(self, batches, val_batches=None):
         self.train_batches = batches
+        self.val_batches = val_batches
+        self.epoch_iterations = len(batches) if hasattr(batches, "__len__") else 0
+
+    # ------------------------------------------------------------------ LR schedule
+    def lr_lambda_update(self, i_iter):
+        """Multiplier of every group's base lr at scheduler step i_iter (reference: antmmf/utils/general.py:27-44)."""
+        tp = self.config.training_parameters
+        if tp.get("use_warmup", False) and i_iter <= tp.get("warmup_iterations", 1000):
+            alpha = float(i_iter) / float(tp.get("warmup_iterations", 1000))
+            return tp.get("warmup_factor", 0.2) * (1.0 - alpha) + alpha
+        steps = list(tp.get("lr_steps", []) or [])
+        epochs = list(tp.get("lr_epochs", []) or [])
+        if epochs:  # lr_epochs win over lr_steps
+            steps = [self.epoch_iterations * e for e in epochs]
+        return pow(tp.get("lr_ratio", 0.1), bisect(steps, i_iter))
+
+    def setup_lr_scheduler(self):
+        self.lr_scheduler = None
+        target = self.model.module if hasattr(self.model, "module") and hasattr(self.model.module, "get_custom_scheduler") else self.model
+        if hasattr(target, "get_custom_scheduler"):
+            self.lr_scheduler = target.get_custom_scheduler(self)
+        if self.lr_scheduler is None and self.config.training_parameters.get("lr_scheduler", False) is True:
+            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda=self.lr_lambda_update)
+
+    def _run_scheduler(self):
+        if self.lr_scheduler is not None and self.current_iteration % self.gradient_accumulation_steps == 0:
+            self.lr_scheduler.step()
 
     # ------------------------------------------------------------------ loop
     def train(self):
         self.model.train()
         self.optimizer.zero_grad()
         t0 = time.perf_counter()
+        mcfg = self.config.model_attributes[list(self.config.model_attributes.keys())[0]]
+        mining = bool(mcfg.get("hard_example_mining", False)) and mcfg.get("change_iter", None) is not None
         for batch in self.train_batches:
             if self.current_iteration >= self.max_iterations:
                 break
             self.current_iteration += 1
+            registry.register("current_iteration", self.current_iteration)
+            if mining and batch:  # scheduled hard-negative ratio of the CN-VID configs (reference base_trainer.py:552-571)
+                batch["incre_num"] = min(int(self.current_iteration / mcfg.change_iter) * mcfg.change_rate, 1.0)
             report, model_output, _ = self._forward_pass(batch)
             if report is None:
                 continue
             self._update_meter(report)
             loss = self._extract_loss(report)
             self._backward(loss)
-            if self.current_iteration % self.log_interval == 0 and is_main_process():
-                dt = time.perf_counter() - t0
-                print(f"iter {self.current_iteration}: " + ", ".join(f"{k}={v:.5f}" for k, v in self.meters.items()) + f" ({dt:.1f}s)", flush=True)
+            self._run_scheduler()
+            if self.current_iteration % self.log_interval == 0:
+                meters = self.read_meters()  # the one host sync of the interval
+                if is_main_process():
+                    dt = time.perf_counter() - t0
+                    lr = self.optimizer.param_groups[0]["lr"]
+                    print(f"iter {self.current_iteration}: " + ", ".join(f"{k}={v:.5f}" for k, v in meters.items()) + f", lr={lr:.3e} ({dt:.1f}s)", flush=True)
             if (self.checkpoint is not None and self.snapshot_interval and self.checkpoint.save_dir_enabled
                     and self.current_iteration % self.snapshot_interval == 0
                     and self.current_iteration % self.gradient_accumulation_steps == 0):
                 self.checkpoint.save(self.current_iteration)
+            if self._logistics():
+                break
         synchronize()
         if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
             self.checkpoint.finalize()
-        return self.meters
+        return self.read_meters()
+
+    # ------------------------------------------------------------------ evaluation / early stopping
+    def evaluate(self, batches):
+        """Mean losses of `batches` in eval mode (no gradients, no optimizer); overridden by RetrievalTrainer for retrieval metrics."""
+        was_training = self.model.training
+        self.model.eval()
+        sums, n = {}, 0
+        with torch.no_grad():
+            for batch in batches:
+                report, _, _ = self._forward_pass(batch)
+                if report is None:
+                    continue
+                n += 1
+                for k, v in report["losses"].items():
+                    sums[k] = sums.get(k, 0) + v.detach().float().mean()
+        if was_training:
+            self.model.train()
+        out = {k: float(v) / max(n, 1) for k, v in sums.items()}
+        out["total_loss"] = sum(out.values())
+        return out
+
+    def _logistics(self):
+        """Evaluation every `evaluation_interval` iterations + early stopping on `monitored_metric` (reference `_logistics` /
+        EarlyStopping, base_trainer.py:473-530).  Returns True when training should stop."""
+        if not self.evaluation_interval or getattr(self, "val_batches", None) is None:
+            return False
+        if self.current_iteration % self.evaluation_interval != 0:
+            return False
+        result = self.evaluate(self.val_batches)
+        self.last_evaluation = result
+        if is_main_process():
+            print(f"iter {self.current_iteration} val: " + ", ".join(f"{k}={v:.5f}" for k, v in result.items() if isinstance(v, float)), flush=True)
+        key = self.monitored_metric if self.monitored_metric in result else next((k for k in result if k.endswith(self.monitored_metric)), None)
+        if key is None:
+            return False
+        value = result[key]
+        better = self.best_monitored is None or (value < self.best_monitored if self.metric_minimize else value > self.best_monitored)
+        if better:
+            self.best_monitored, self.best_iteration = value, self.current_iteration
+            if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
+                self.checkpoint.save(self.current_iteration, update_best=True)
+        return self.should_early_stop and (self.current_iteration - self.best_iteration) > self.patience
 
     def _forward_pass(self, batch, enable_amp=False):
         if not batch:
@@ -154,10 +264,10 @@ class BaseTrainer:
             world = self.arena.allreduce_grads()
             scale = 1.0 / world
             if self.should_clip_gradients and self.max_grad_l2_norm:
-                norm = float(self.arena.grad_norm()) * scale
-                if norm > self.max_grad_l2_norm:
-                    scale *= self.max_grad_l2_norm / (norm + 1e-6)
-                registry.register("grad_norm", norm)
+                # clip coefficient min(1, max_norm / (norm + 1e-6)) stays on the device: it reaches the fused AdamW as a 1-element tensor
+                norm = self.arena.grad_norm() * scale
+                self._dev_meters["grad_norm"] = norm.detach().reshape(())
+                scale = scale * torch.clamp(self.max_grad_l2_norm / (norm + 1e-6), max=1.0)
             self.optimizer.grad_scale = scale
         else:
             if get_world_size() > 1:
@@ -171,13 +281,29 @@ class BaseTrainer:
         self.optimizer.zero_grad()
 
     def _update_meter(self, report, meter=None, sync=True):
+        """Meters are device tensors (latest value per key); nothing is copied to the host here."""
+        if not hasattr(self, "_dev_meters"):
+            self._dev_meters = {}
         with torch.no_grad():
-            losses = {k: v.detach().mean() for k, v in report["losses"].items()}
+            losses = {k: v.detach().float().mean() for k, v in report["losses"].items()}
             if sync and get_world_size() > 1 and not self.config.training_parameters.get("losses_are_global", True):
                 losses = reduce_dict(losses)
-            total = 0.0
+            total = None
             for k, v in losses.items():
-                self.meters[k] = float(v)
-                total += float(v)
-            self.meters[f"{report['dataset_type']}/total_loss"] = total
-            registry.register(f"{report['dataset_type']}/total_loss", total)
+                self._dev_meters[k] = v
+                total = v if total is None else total + v
+            if total is not None:
+                self._dev_meters[f"{report['dataset_type']}/total_loss"] = total
+
+    def read_meters(self):
+        """ONE host sync: every meter of the last iteration as a Python float (also published to the registry, where the
+        reference keeps `<dataset_type>/total_loss` and `grad_norm`)."""
+        dm = getattr(self, "_dev_meters", {})
+        if dm:
+            keys = list(dm.keys())
+            vals = torch.stack([dm[k].reshape(()).float() for k in keys]).tolist()
+            for k, v in zip(keys, vals):
+                self.meters[k] = v
+                if k.endswith("/total_loss") or k == "grad_norm":
+                    registry.register(k, v)
+        return self.meters

@@ -327,7 +327,8 @@ extern "C" int antmmf_embed_scatter_add(const void* dx, const long* idx, const u
 // p, m, v fp32 master state; g fp32 gradient (scaled by grad_scale first, e.g. 1/world or a clip coefficient); writes the bf16 compute shadow.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ shadow, long n, float lr, float beta1, float beta2, float eps, float wd,
-                                                    float bc1, float bc2, float grad_scale) {
+                                                    float bc1, float bc2, float grad_scale, const float* __restrict__ dev_scale) {
+    if (dev_scale) grad_scale *= *dev_scale;  // e.g. the gradient-clipping coefficient computed on the device (no host sync in the step)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * grad_scale;
         float pi = p[i];
@@ -344,7 +345,18 @@ extern "C" int antmmf_adamw_step(float* p, const float* g, float* m, float* v, v
     if (!p || !g || !m || !v || n < 0 || step < 1) return ANTMMF_EINVAL;
     if (!n) return ANTMMF_OK;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                       (const float*)nullptr);
+    return antmmf_check_launch();
+}
+// the same step with an additional gradient scale read from device memory (one fp32; nullable)
+extern "C" int antmmf_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1, float beta2, float eps,
+                                        float weight_decay, int step, float grad_scale, const float* dev_scale, hipStream_t s) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return ANTMMF_EINVAL;
+    if (!n) return ANTMMF_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                       dev_scale);
     return antmmf_check_launch();
 }
 

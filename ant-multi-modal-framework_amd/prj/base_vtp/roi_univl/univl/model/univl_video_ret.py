@@ -202,7 +202,11 @@ class UnivlForVideoTextRetrieval(nn.Module):
         return output_dict
 
     def forward(self, img_input, caption_input, ocr_input=None, region_input=None, caption_output=None, sample_list=None):
-        cap_input, vis_input, _, _ = self.module.get_l2_input(img_input, caption_input)
+        if sample_list is not None and "text_stage1_output" in sample_list and "visual_stage1_output" in sample_list:
+            # retrieval evaluation: the towers ran once per batch, the block is scored from the cached stage-1 outputs (reference :466-472)
+            cap_input, vis_input = tuple(sample_list["text_stage1_output"]), tuple(sample_list["visual_stage1_output"])
+        else:
+            cap_input, vis_input, _, _ = self.module.get_l2_input(img_input, caption_input)
         return self.forward_stage(cap_input + (caption_input,), vis_input + (img_input,), True)
 
     def get_optimizer_parameters(self, config):

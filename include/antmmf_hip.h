@@ -108,6 +108,11 @@ int antmmf_embed_scatter_add(const void* dx, const int64_t* idx, const unsigned 
 int antmmf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, float grad_scale,
                       antmmf_stream_t stream);
+/* The same step with one more gradient factor read from DEVICE memory (`dev_scale`, one fp32, nullable): the clipping coefficient
+ * min(1, max_norm / (norm + 1e-6)) of antmmf/utils/general.py:47-75 is computed on the device and never visits the host. */
+int antmmf_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             const float* dev_scale, antmmf_stream_t stream);
 /* ---- *out += sum x[i]^2  (gradient-norm clipping, antmmf/utils/general.py:47-56). */
 int antmmf_sumsq(const float* x, float* out, int64_t n, antmmf_stream_t stream);
 

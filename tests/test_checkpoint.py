@@ -161,3 +161,60 @@ def test_reference_parameter_names_exist_in_this_build(golden):
     ref = {k.split("gnorm.", 1)[1] for k in g if k.startswith("gnorm.")}
     own = set(mc.build_tiny_m2(dev).state_dict())
     assert len(ref) > 50 and ref <= own, sorted(ref - own)[:5]
+
+
+def test_shadow_follows_in_place_weight_writes(tmp_path):
+    """the bf16 compute shadow used by the forward pass must follow writes to the fp32 masters that do not come from the
+    fused optimizer -- model.load_state_dict, an initialiser, an in-place clamp (detected through torch's version counter) -- and
+    `sync_shadow()` covers `.data` edits."""
+    from antmmf.hip import functional as F
+
+    tr = _toy()(_cfg(tmp_path, save_dir=None, snapshot_interval=None))
+    tr.load()
+    p = tr.model.enc_a.weight
+    torch.testing.assert_close(F.compute_copy(p).float(), p.detach().bfloat16().float())
+    sd = {k: v.clone() + 1.0 for k, v in tr.model.state_dict().items()}
+    tr.model.load_state_dict(sd)
+    torch.testing.assert_close(p.detach(), sd["enc_a.weight"])
+    torch.testing.assert_close(F.compute_copy(p).float(), sd["enc_a.weight"].bfloat16().float())
+    v0 = F._T_CACHE_VERSION[0]
+    with torch.no_grad():
+        p.clamp_(-0.25, 0.25)
+    assert float(F.compute_copy(p).float().abs().max()) <= 0.25 and F._T_CACHE_VERSION[0] > v0
+    p.data.mul_(2.0)                       # invisible to the version counter ...
+    tr.arena.sync_shadow()                 # ... documented remedy
+    torch.testing.assert_close(F.compute_copy(p).float(), p.detach().bfloat16().float())
+
+
+def test_hip_adamw_loads_reference_torch_adamw_state(tmp_path):
+    """resuming from a reference-format optimizer state (torch.optim.AdamW: per-parameter exp_avg / exp_avg_sq / step) restores
+    the flat moments and the step count; the next fused step then equals torch's next step."""
+    Trainer = _toy()
+    tr = Trainer(_cfg(tmp_path, save_dir=None, snapshot_interval=None))
+    tr.load()
+    batches = _batches()
+    ref_model = type(tr.model)(tr.model.config)
+    ref_model.build()
+    ref_model.load_state_dict({k: v.clone() for k, v in tr.model.state_dict().items()})
+    ref_opt = torch.optim.AdamW(ref_model.parameters(), lr=0.05, weight_decay=0.01)
+    for b in batches[:2]:
+        ref_opt.zero_grad()
+        ref_model(b)["losses"]["toy_loss"].backward()
+        ref_opt.step()
+    state = ref_opt.state_dict()
+    snapshot = {k: (v if not isinstance(v, dict) else dict(v)) for k, v in state.items()}
+    tr.model.load_state_dict({k: v.clone() for k, v in ref_model.state_dict().items()})
+    tr.optimizer.load_state_dict(state)
+    assert set(state.keys()) == set(snapshot.keys()) and "state" in state and len(state["state"]) == len(snapshot["state"])  # caller's dict untouched
+    assert tr.optimizer._step == 2 and float(tr.optimizer.exp_avg.abs().sum()) > 0
+    ref_opt.zero_grad()
+    ref_model(batches[2])["losses"]["toy_loss"].backward()
+    ref_opt.step()
+    tr.optimizer.zero_grad()
+    tr.model(batches[2])["losses"]["toy_loss"].backward()
+    tr.optimizer.step()
+    for (n, a), (_, b) in zip(tr.model.named_parameters(), ref_model.named_parameters()):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-3, atol=2e-4, msg=n)
+    with pytest.raises(ValueError):
+        tr.optimizer.load_state_dict({"state": {0: dict(step=torch.tensor(1.0), exp_avg=torch.zeros(3), exp_avg_sq=torch.zeros(3))},
+                                      "param_groups": tr.optimizer.state_dict()["param_groups"]})
