@@ -338,9 +338,48 @@ def gen_e2e_clip():
             if p.grad is None:
                 continue
             d[f"{tag}.gnorm.{n}"] = p.grad.norm()
+            d[f"{tag}.gfull.{n}"] = p.grad.to(torch.bfloat16)  # every parameter's gradient (bf16 storage): direction checks, not only norms
             if n in full:
                 d[f"{tag}.grad.{n}"] = p.grad
     save("e2e_clip_arch.pt", d)
+
+
+def gen_temporal_head():
+    """UnivlForVideo.get_temporal_output (prj/base_vtp/.../univl_video_pretrain.py:76-90).  The reference hands the [cls] + clip
+    features to a HuggingFace AutoModel through `inputs_embeds` (transformers is not pinned: that boundary cannot be executed reproducibly);
+    here the method body is executed with the reference's OWN BERT modules in that place -- BertEmbeddings(inputs_embeds, token type 0) followed by
+    BertEncoder under the all-ones attention mask, which is what a BERT model does with inputs_embeds -- so the temporal head is pinned by
+    reference code up to that substitution."""
+    vtp = L.load_vtp("base_vtp")
+
+    class Holder(torch.nn.Module):  # parameter names as in UnivlForVideo: cls_token, temporal_encoder.*
+        def __init__(self):
+            super().__init__()
+            self.cls_token = torch.nn.Parameter(torch.randn(1, 1, 128))
+            self.temporal_encoder = vtp["txt_enc"].RobertBertEncoder(
+                pretrained=False, vocab_size=40, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                max_position_embeddings=40, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=128, is_proj=False)
+            self.temporal_encoder.embeddings.word_embeddings = None   # add_temporal_head, :71-74
+            self.temporal_encoder.module.pooler = None
+
+    m = Holder()
+    W.fill_module_(m)
+    m.train()
+    clip = (W.data_tensor("temporal.clip", (3, 8, 128)) * 0.5).requires_grad_(True)
+    w = W.data_tensor("temporal.w", (3, 9, 128))
+    bsz, n_clips, _ = clip.shape
+    attention_mask = torch.cat((torch.ones(1).expand(bsz, -1), torch.ones((bsz, n_clips), dtype=torch.long)), dim=1)   # :79-83
+    input_embeds = torch.cat((m.cls_token.expand(bsz, -1, -1), clip), dim=1)                                              # :85-86
+    emb = m.temporal_encoder.embeddings(inputs_embeds=input_embeds, token_type_ids=torch.zeros(bsz, n_clips + 1, dtype=torch.long))
+    ext = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+    seq_out = m.temporal_encoder.encoder(emb, ext, head_mask=[None] * 3)[0]
+    (seq_out * w).sum().backward()
+    d = {"out": seq_out, "dclip": clip.grad, "dcls": m.cls_token.grad}
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            d[f"gfull.{n}"] = p.grad.to(torch.bfloat16)
+            d[f"gnorm.{n}"] = p.grad.norm()
+    save("ops_temporal_head.pt", d)
 
 
 def gen_e2e_clip_stage2():
@@ -364,6 +403,8 @@ def gen_e2e_clip_stage2():
         for n, p in model.named_parameters():
             if p.grad is not None:
                 d[f"s2.{tag}.gnorm.{n}"] = p.grad.norm()
+                if tag == "plain":
+                    d[f"s2.{tag}.gfull.{n}"] = p.grad.to(torch.bfloat16)
     save("e2e_clip_stage2.pt", d)
 
 
@@ -391,6 +432,8 @@ def gen_e2e_dmae_stage3():
         for n, p in model.named_parameters():
             if p.grad is not None:
                 d[f"s3.{loss_type}.gnorm.{n}"] = p.grad.norm()
+                if loss_type == "negNCE":
+                    d[f"s3.{loss_type}.gfull.{n}"] = p.grad.to(torch.bfloat16)
     # the same step with TPM-CL switched on (l3_partial_type 4): losses + the new head's gradient norms only
     cfg = dict(TINY_CLIP_CFG, training_stage="stage1+stage3", l3_loss_type="negNCE", **dict(DMAE_E2E, l3_partial_type=4))
     model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
@@ -502,6 +545,7 @@ def gen_e2e_m2():
         if p.grad is None:
             continue
         d[f"gnorm.{n}"] = p.grad.norm()
+        d[f"gfull.{n}"] = p.grad.to(torch.bfloat16)
         if n in full:
             d[f"grad.{n}"] = p.grad
     d["param_names"] = [n for n, _ in model.named_parameters()]
@@ -543,8 +587,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -26,6 +26,38 @@ TINY_CLIP_CFG = dict(
 )
 
 
+
+def grad_direction_report(named_params, g, prefix, zero_rel=1e-4):
+    """Per-parameter gradient parity against the reference's FULL gradients (`<prefix>gfull.<name>`, bf16 storage): cosine of the
+    flattened gradients and relative difference of their norms.  Parameters whose TRUE gradient vanishes (reference norm below
+    `zero_rel` x the largest, e.g. the key-projection bias by softmax shift invariance) must stay small instead.
+    Returns rows [cos, norm_rel, name] sorted worst-cosine first."""
+    rows, refs = [], {}
+    for n, p in named_params:
+        k = f"{prefix}gfull.{n}"
+        if k in g and p.grad is not None:
+            refs[n] = (p.grad.detach().float().flatten().cpu(), g[k].float().flatten())
+    top = max(float(r.norm()) for _, r in refs.values())
+    for n, (got, ref) in refs.items():
+        rn, gn = float(ref.norm()), float(got.norm())
+        if rn < zero_rel * top:
+            assert gn < 10 * zero_rel * top, f"{n}: gradient should vanish, got norm {gn}"
+            continue
+        rows.append([float(torch.dot(got, ref)) / max(gn * rn, 1e-30), abs(gn - rn) / rn, n])
+    rows.sort()
+    return rows
+
+
+def assert_grad_directions(named_params, g, prefix, min_cos=0.995, max_norm_rel=0.05, min_checked=20):
+    """north_star: "logits, loss and grads match the reference": every parameter's gradient points the reference's way (cosine) and
+    has its length (norm), not only the length (a norm check cannot see a permuted head or a wrong sign)."""
+    rows = grad_direction_report(named_params, g, prefix)
+    assert len(rows) >= min_checked, len(rows)
+    assert rows[0][0] >= min_cos, f"gradient direction off: {rows[:5]}"
+    worst_norm = max(rows, key=lambda r: r[1])
+    assert worst_norm[1] <= max_norm_rel, f"gradient norm off: {worst_norm}"
+    return dict(min_cos=rows[0][:1] + rows[0][2:], worst_norm=worst_norm[1:], n=len(rows))
+
 def build_tiny_univl(dev):
     import roi_univl  # noqa: F401  (registers encoders + model)
     from antmmf.common.configuration import Configuration
@@ -38,7 +70,8 @@ def build_tiny_univl(dev):
 
 def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     """Product UnivlForVideoTextRetrieval (bf16 HIP path) vs the reference's outputs on the same weights / batch.
-    Tolerance: bf16 activations through 2+2 layers; loss is compared at 2e-3 relative."""
+    Tolerance: bf16 activations through 2+2 layers; loss within 1e-3 relative (the contract of BASELINE.json's north_star); every
+    parameter's gradient: cosine >= 0.995 against the reference's full gradient and norm within 5 %."""
     g = golden("e2e_clip_arch.pt")
     model = build_tiny_univl(dev)
     img = g[f"{tag}.image_data"].to(dev)
@@ -50,7 +83,7 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     out = model(img_input, cap_input)
     loss = out["losses"]["level1_similarity_loss"]
     ref_loss = float(g[f"{tag}.loss"])
-    assert abs(float(loss) - ref_loss) <= 2e-3 * abs(ref_loss), (float(loss), ref_loss)
+    assert abs(float(loss) - ref_loss) <= 1e-3 * abs(ref_loss), (float(loss), ref_loss)   # north_star: loss within 1e-3 rel
     check(f"{tag}.l1_simi", out["l1_simi"], g[f"{tag}.l1_simi"], rtol, 5e-2)
     cap, vis, _, _ = model.module.get_l2_input(img_input, cap_input)
     check(f"{tag}.text_embed", cap[2], g[f"{tag}.text_embed"], rtol, 3e-2)
@@ -82,8 +115,9 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
         kept.append(w)
     worst = sorted(kept, reverse=True)
     assert n_checked > 50
-    assert worst[0][0] < 0.15, f"gradient norms off: {worst[:5]}"
-    return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3])
+    assert worst[0][0] < 0.05, f"gradient norms off: {worst[:5]}"
+    dirs = assert_grad_directions(model.named_parameters(), g, f"{tag}.", min_checked=50)
+    return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3], directions=dirs)
 
 
 def case_bert_layer_dropout(dev):
@@ -137,9 +171,10 @@ def case_bert_layer_dropout(dev):
     return dict(checked=n)
 
 
-def case_temporal_head(dev):
+def case_temporal_head(dev, golden=None):
     """UnivlForVideo.get_temporal_output ([cls] + clip features through a 3-layer BERT, inputs_embeds path) vs the CPU oracle's
-    BERT restatement on the same weights, forward and input / parameter gradients."""
+    BERT restatement on the same weights, forward and input / parameter gradients -- and, with `golden`, vs the run of the reference's own
+    BERT modules over the same method body (tests/golden/ops_temporal_head.pt: output, input gradients, every parameter's full gradient)."""
     import roi_univl  # noqa: F401
     from antmmf.common.configuration import Configuration
     from oracle import towers as otowers
@@ -179,7 +214,16 @@ def case_temporal_head(dev):
             assert abs(float(named[k].grad.float().norm()) - rn) <= 0.15 * rn, (k, float(named[k].grad.float().norm()), rn)
             n += 1
     assert n > 30
-    return dict(checked=n)
+    res = dict(checked=n)
+    if golden is not None:
+        g = golden("ops_temporal_head.pt")
+        check("temporal.out.ref", out, g["out"], 5e-2, 3e-2)
+        check("temporal.dclip.ref", x.grad, g["dclip"], 1e-1, 5e-2)
+        check("temporal.dcls.ref", model.cls_token.grad, g["dcls"], 1e-1, 5e-2)
+        torch.testing.assert_close(ref.detach(), g["out"], rtol=2e-5, atol=2e-5)   # the oracle itself is pinned by the same fixture
+        temporal = [(k, v) for k, v in model.named_parameters() if k.startswith(("temporal_encoder.", "cls_token"))]
+        res["directions"] = assert_grad_directions(temporal, g, "", min_checked=30)
+    return res
 
 
 def case_univl_stage2(dev, golden, mining=False):
@@ -207,8 +251,8 @@ def case_univl_stage2(dev, golden, mining=False):
     (l1 + l2).backward()
     if not mining:
         ref1, ref2 = float(g["s2.plain.loss1"]), float(g["s2.plain.loss2"])
-        assert abs(float(l1) - ref1) <= 2e-3 * abs(ref1), (float(l1), ref1)
-        assert abs(float(l2) - ref2) <= 5e-3 * abs(ref2), (float(l2), ref2)
+        assert abs(float(l1) - ref1) <= 1e-3 * abs(ref1), (float(l1), ref1)
+        assert abs(float(l2) - ref2) <= 2e-3 * abs(ref2), (float(l2), ref2)   # cross-encoder scores through 2 more bf16 layers + an MLP
         check("s2.l2_simi", out["l2_simi"], g["s2.plain.l2_simi"], 5e-2, 3e-2)
         worst = []
         for n, p in model.named_parameters():
@@ -218,7 +262,11 @@ def case_univl_stage2(dev, golden, mining=False):
         top = max(w[1] for w in worst)
         rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-4 * top), reverse=True)
         assert len(rel) > 50 and rel[0][0] < 0.2, rel[:5]
-        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3])
+        # the level-2 loss is a softmax over pair scores that are nearly the same function of the shared text-tower weights at random init: its
+        # parameter gradient is a sum of almost-cancelling per-pair terms, so bf16 rounding of the activations shows up in the DIRECTION
+        # (measured: cosine 0.91-0.97 on the text tower, >= 0.995 everywhere in stage 1 / stage 3 / M2); a sign or permutation error would be << 0.9
+        dirs = assert_grad_directions(model.named_parameters(), g, "s2.plain.", min_cos=0.9, max_norm_rel=0.2, min_checked=50)
+        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs)
     from oracle import step as ostep
 
     P = tiny_models.clip_arch_params(stage2=True)
@@ -409,6 +457,7 @@ import roi_univl
 from antmmf.common.configuration import Configuration
 from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
 from kernel_cases import check
+DMAE_MIN_COS = 0.995
 dev = torch.device(%r)
 loss_type = %r
 g = torch.load(os.path.join(ROOT, "tests", "golden", "e2e_dmae_stage3.pt"))
@@ -425,9 +474,9 @@ out = model(img_input, cap_input)
 l1, l3 = out["losses"]["level1_similarity_loss"], out["losses"]["level3_similarity_loss"]
 (l1 + l3).backward()
 r1, r3 = float(g[f"s3.{loss_type}.loss1"]), float(g[f"s3.{loss_type}.loss3"])
-assert abs(float(l1) - r1) <= 2e-3 * abs(r1), (float(l1), r1)
-# logit scale 100 on cosines computed from bf16 embedding-layer features: 2 %% on the loss
-assert abs(float(l3) - r3) <= 2e-2 * abs(r3), (float(l3), r3)
+assert abs(float(l1) - r1) <= 1e-3 * abs(r1), (float(l1), r1)
+# logit scale 100 on cosines computed from bf16 token features (measured 4e-3): 8e-3 on the loss
+assert abs(float(l3) - r3) <= 8e-3 * abs(r3), (float(l3), r3)
 check("s3.l3_simi", out["l3_simi"], g[f"s3.{loss_type}.l3_simi"], 5e-2, 5e-2)
 worst = []
 for n, p in model.named_parameters():
@@ -436,8 +485,14 @@ for n, p in model.named_parameters():
         worst.append((abs(float(p.grad.float().norm()) - float(g[key])), float(g[key]), n))
 top = max(w[1] for w in worst)
 rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-3 * top), reverse=True)
-assert len(rel) > 40 and rel[0][0] < 0.25, rel[:5]
-print("okdmae", float(l1), r1, float(l3), r3, rel[:2])
+assert len(rel) > 40 and rel[0][0] < 0.05, rel[:5]
+dirs = None
+if loss_type == "negNCE":
+    from model_cases import grad_direction_report
+    rows = grad_direction_report(model.named_parameters(), g, "s3.negNCE.")
+    dirs = (rows[0], max(rows, key=lambda r: r[1]), len(rows))
+    assert len(rows) > 40 and rows[0][0] >= DMAE_MIN_COS, rows[:5]
+print("okdmae", float(l1), r1, float(l3), r3, rel[:2], dirs)
 """
     return code
 
@@ -559,8 +614,9 @@ def case_m2_towers(dev, golden, rtol=5e-2):
         w[0] /= w[3]
         kept.append(w)
     kept.sort(reverse=True)
-    assert len(kept) > 50 and kept[0][0] < 0.15, f"gradient norms off: {kept[:5]}"
-    return dict(pin=float(pin), ref_pin=float(g["pin"]), worst_gnorm=kept[:3])
+    assert len(kept) > 50 and kept[0][0] < 0.05, f"gradient norms off: {kept[:5]}"
+    dirs = assert_grad_directions(model.named_parameters(), g, "", min_checked=50)
+    return dict(pin=float(pin), ref_pin=float(g["pin"]), worst_gnorm=kept[:3], directions=dirs)
 
 
 def case_m2_itc_vs_oracle(dev):
@@ -577,11 +633,12 @@ def case_m2_itc_vs_oracle(dev):
     loss = out["losses"]["itc_loss"] + out["losses"]["itc_vl_loss"]
     P = tiny_models.m2_params(requires_grad=True)
     ref = ostep.m2_itc(P, img, ids, mask, heads=2, patch=8)
-    assert abs(float(loss) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])), (float(loss), float(ref["loss"]))
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"])), (float(loss), float(ref["loss"]))
     loss.backward()
     ref["loss"].backward()
     named = dict(model.named_parameters())
     rels = []
+    gold = {f"gfull.{n}": p.grad for n, p in P.items() if p.grad is not None and n in named}
     for n, p in P.items():
         if p.grad is None or n not in named or named[n].grad is None:
             continue
@@ -590,5 +647,88 @@ def case_m2_itc_vs_oracle(dev):
             continue
         rels.append((abs(float(named[n].grad.float().norm()) - rn) / rn, n))
     rels.sort(reverse=True)
-    assert len(rels) > 50 and rels[0][0] < 0.2, rels[:5]
-    return dict(loss=float(loss), ref=float(ref["loss"]), worst=rels[:3])
+    assert len(rels) > 50 and rels[0][0] < 0.05, rels[:5]
+    dirs = assert_grad_directions(named.items(), gold, "", min_checked=50)
+    return dict(loss=float(loss), ref=float(ref["loss"]), worst=rels[:3], directions=dirs)
+
+
+# ------------------------------------------------------------------------------ one transformer layer at REAL width
+def case_layer_real_width(dev, kind="m2", d=1024, heads=16, N=257, B=2, pad_tail=0):
+    """`transformer_layer` forward + backward at the widths of BASELINE.json's configs (M2 ViT-L/14: d = 1024, 16 heads, 257 tokens; CLIP-arch
+    ViT-B/16: d = 768, 12 heads, 197 tokens) against the fp32 oracle layer on the same bf16-rounded weights and input: output element-wise,
+    input gradient and EVERY parameter gradient by cosine (>= 0.999) and norm (2 %).  The tiny-dim fixtures cannot see an indexing error that only
+    shows up at 16 heads x 64 or past the first 128 / 256-wide tile; this can."""
+    from antmmf.hip import functional as HF
+    from kernel_cases import q, rnd
+    from oracle import towers as otowers
+
+    g = torch.Generator().manual_seed(1234 + d + N)
+
+    def w(shape, scale):
+        return q(torch.randn(shape, generator=g) * scale)
+
+    P = {}
+    if kind == "m2":
+        spec = HF.LayerSpec(kind="m2", heads=heads, eps=1e-5, act="gelu", packed_qkv=False)
+        names = dict(ln1="self_attn_layer_norm.A", inner="self_attn.inner_attn_ln.A", ln2="final_layer_norm.A", ffn="ffn.A.ffn_layernorm")
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            P[f"self_attn.{nm}.A.weight"], P[f"self_attn.{nm}.A.bias"] = w((d, d), d ** -0.5), w((d,), 0.1)
+        P["ffn.A.fc1.weight"], P["ffn.A.fc1.bias"] = w((4 * d, d), d ** -0.5), w((4 * d,), 0.1)
+        P["ffn.A.fc2.weight"], P["ffn.A.fc2.bias"] = w((d, 4 * d), (4 * d) ** -0.5), w((d,), 0.1)
+        for key, width in ((names["ln1"], d), (names["inner"], d), (names["ln2"], d), (names["ffn"], 4 * d)):
+            P[key + ".weight"], P[key + ".bias"] = q(1.0 + 0.1 * torch.randn(width, generator=g)), w((width,), 0.1)
+        slots = dict(ln1_w=names["ln1"] + ".weight", ln1_b=names["ln1"] + ".bias", wq="self_attn.q_proj.A.weight", bq="self_attn.q_proj.A.bias",
+                     wk="self_attn.k_proj.A.weight", bk="self_attn.k_proj.A.bias", wv="self_attn.v_proj.A.weight", bv="self_attn.v_proj.A.bias",
+                     inner_w=names["inner"] + ".weight", inner_b=names["inner"] + ".bias", wo="self_attn.out_proj.A.weight", bo="self_attn.out_proj.A.bias",
+                     ln2_w=names["ln2"] + ".weight", ln2_b=names["ln2"] + ".bias", w1="ffn.A.fc1.weight", b1="ffn.A.fc1.bias",
+                     ffn_w=names["ffn"] + ".weight", ffn_b=names["ffn"] + ".bias", w2="ffn.A.fc2.weight", b2="ffn.A.fc2.bias")
+    else:
+        spec = HF.LayerSpec(kind="clip", heads=heads, eps=1e-5, act="quick_gelu", packed_qkv=True)
+        P["attn.in_proj_weight"], P["attn.in_proj_bias"] = w((3 * d, d), d ** -0.5), w((3 * d,), 0.1)
+        P["attn.out_proj.weight"], P["attn.out_proj.bias"] = w((d, d), d ** -0.5), w((d,), 0.1)
+        P["mlp.c_fc.weight"], P["mlp.c_fc.bias"] = w((4 * d, d), d ** -0.5), w((4 * d,), 0.1)
+        P["mlp.c_proj.weight"], P["mlp.c_proj.bias"] = w((d, 4 * d), (4 * d) ** -0.5), w((d,), 0.1)
+        for ln in ("ln_1", "ln_2"):
+            P[ln + ".weight"], P[ln + ".bias"] = q(1.0 + 0.1 * torch.randn(d, generator=g)), w((d,), 0.1)
+        slots = dict(ln1_w="ln_1.weight", ln1_b="ln_1.bias", wqkv="attn.in_proj_weight", bqkv="attn.in_proj_bias", wo="attn.out_proj.weight",
+                     bo="attn.out_proj.bias", ln2_w="ln_2.weight", ln2_b="ln_2.bias", w1="mlp.c_fc.weight", b1="mlp.c_fc.bias",
+                     w2="mlp.c_proj.weight", b2="mlp.c_proj.bias")
+    x = w((B, N, d), 1.0)
+    G = w((B, N, d), 1.0)
+    pad = None
+    if pad_tail and kind == "m2":
+        pad = torch.zeros(B, N, dtype=torch.bool)
+        pad[1, N - pad_tail:] = True
+    # oracle (fp32, CPU)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = otowers.m2_layer(Pr, xr, "A", heads, pad=pad) if kind == "m2" else otowers.clip_block(Pr, xr, heads)
+    keep = torch.ones(B, N, 1) if pad is None else (~pad).float()[..., None]
+    (yr * G * keep).sum().backward()
+    # product
+    Pd = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in P.items()}
+    xd = x.to(dev, torch.bfloat16).requires_grad_(True)
+    key_bias = None if pad is None else torch.zeros(B, N, dtype=torch.float32, device=dev).masked_fill_(pad.to(dev), float("-inf"))
+    yd = HF.transformer_layer(xd, spec, {s: Pd[k] for s, k in slots.items()}, key_bias)
+    (yd.float() * (G * keep).to(dev)).sum().backward()
+    sel = keep.bool().expand_as(yr)
+    check(f"layer.{kind}.{d}.y", torch.where(sel.to(dev), yd.float(), torch.zeros_like(yd.float())), torch.where(sel, yr, torch.zeros_like(yr)), 2e-2, 1e-2)
+    rows = []
+
+    def cmp(name, got, ref):
+        got, ref = got.detach().float().flatten().cpu(), ref.detach().float().flatten()
+        gn, rn = float(got.norm()), float(ref.norm())
+        rows.append((float(torch.dot(got, ref)) / max(gn * rn, 1e-30), abs(gn - rn) / max(rn, 1e-30), name))
+
+    cmp("dx", xd.grad, xr.grad)
+    top = max(float(Pr[k].grad.norm()) for k in P)
+    for k in P:
+        if float(Pr[k].grad.norm()) < 1e-5 * top:   # the key-projection bias: zero by softmax shift invariance (fp32 rounding noise in the oracle)
+            assert float(Pd[k].grad.float().norm()) < 1e-2 * top, (k, float(Pd[k].grad.float().norm()), top)
+            continue
+        cmp(k, Pd[k].grad, Pr[k].grad)
+    rows.sort()
+    assert rows[0][0] >= 0.999, f"gradient direction off: {rows[:4]}"
+    worst = max(rows, key=lambda r: r[1])
+    assert worst[1] <= 0.02, f"gradient norm off: {worst}"
+    return dict(min_cos=rows[0], worst_norm=worst, n=len(rows))

@@ -79,8 +79,8 @@ def test_bert_layer_dropout_vs_oracle_same_masks():
     print(mc.case_bert_layer_dropout(DEV))
 
 
-def test_temporal_head_vs_oracle():
-    print(mc.case_temporal_head(DEV))
+def test_temporal_head_vs_oracle_and_reference(golden):
+    print(mc.case_temporal_head(DEV, golden))
 
 
 def test_dmae_seqtransf_vs_reference(golden):
@@ -100,6 +100,13 @@ def test_m2_itc_step_vs_oracle_keep_ffn_norm():
         print(mc.case_m2_itc_vs_oracle(DEV))
     finally:
         functional.set_keep_ffn_norm(False)
+
+
+@pytest.mark.parametrize("kind,d,heads,N,pad", [("m2", 1024, 16, 257, 0), ("m2", 1024, 16, 77, 30), ("clip", 768, 12, 197, 0), ("m2", 768, 12, 197, 0)])
+def test_transformer_layer_real_width_vs_oracle(kind, d, heads, N, pad):
+    """One fused layer at the real widths of BASELINE.json's configs (ViT-L/14 image / text towers, ViT-B/16) vs the fp32 oracle:
+    output, input gradient and every parameter gradient (cosine >= 0.999, norm within 2 %)."""
+    print(mc.case_layer_real_width(DEV, kind=kind, d=d, heads=heads, N=N, B=2, pad_tail=pad))
 
 
 def test_smoke_entry():
