@@ -77,7 +77,7 @@ def dgrad(dy2d, weight, weight_layout="oi", **epi):
         return ops.gemm(dy2d, compute_copy(weight), **epi)          # Q = W [in][out]: already r-contiguous
     if torch.is_tensor(weight) and isinstance(weight, torch.nn.Parameter):
         return ops.gemm(dy2d, compute_copy_t(weight), **epi)        # Q = W^T [in][out]
-    return ops.gemm(dy2d, weight, q_rmajor=True, **epi)             # ad-hoc bf16 tensor (e.g. concatenated qkv)
+    return ops.gemm(dy2d, weight if weight.dtype == BF else compute_copy(weight), q_rmajor=True, **epi)  # ad-hoc tensor (e.g. concatenated qkv)
 
 
 class GradSink:

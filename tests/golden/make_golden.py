@@ -382,6 +382,34 @@ def gen_temporal_head():
     save("ops_temporal_head.pt", d)
 
 
+def gen_vilbert_biattention():
+    """antmmf/models/vilbert.py BertBiAttention (:285-416), executed unmodified (only the class body is taken from the file: the
+    module's top-level imports pull the whole antmmf package).  128-wide co-attention with 2 heads of 64, vision width 96, text width 128,
+    ragged key masks on both streams, eval-mode (dropout off) outputs and every gradient."""
+    import math as _math
+    src = open(f"{L.REF}/antmmf/models/vilbert.py").read()
+    body = src[src.index("class BertBiAttention(nn.Module):"):src.index("class BertBiOutput(nn.Module):")]
+    ns = {"nn": torch.nn, "torch": torch, "math": _math}
+    exec(body, ns)
+    cfg = L.AttrDict(dict(bi_hidden_size=128, bi_num_attention_heads=2, v_hidden_size=96, hidden_size=128, v_attention_probs_dropout_prob=0.1,
+                          attention_probs_dropout_prob=0.1, visualization=False))
+    m = ns["BertBiAttention"](cfg)
+    W.fill_module_(m)
+    m.eval()
+    B, Nv, Nt = 3, 9, 14
+    x1 = (W.data_tensor("bi.x1", (B, Nv, 96)) * 0.7).requires_grad_(True)
+    x2 = (W.data_tensor("bi.x2", (B, Nt, 128)) * 0.7).requires_grad_(True)
+    len1, len2 = torch.tensor([9, 4, 7]), torch.tensor([14, 14, 5])
+    m1 = ((torch.arange(Nv)[None] >= len1[:, None]).float() * -10000.0)[:, None, None, :]
+    m2 = ((torch.arange(Nt)[None] >= len2[:, None]).float() * -10000.0)[:, None, None, :]
+    c1, c2, _ = m(x1, m1, x2, m2)
+    g1, g2 = W.data_tensor("bi.g1", (B, Nt, 128)), W.data_tensor("bi.g2", (B, Nv, 128))
+    ((c1 * g1).sum() + (c2 * g2).sum()).backward()
+    d = {"x1": x1.detach(), "x2": x2.detach(), "mask1": m1, "mask2": m2, "ctx1": c1, "ctx2": c2, "g1": g1, "g2": g2, "dx1": x1.grad, "dx2": x2.grad}
+    d.update(grads_of(m))
+    save("ops_vilbert_biattention.pt", d)
+
+
 def gen_e2e_clip_stage2():
     vtp = L.load_vtp("base_vtp")
     d = {}
@@ -587,8 +615,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "vilbert_biattention", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(vilbert_biattention=gen_vilbert_biattention, temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

@@ -732,3 +732,69 @@ def case_layer_real_width(dev, kind="m2", d=1024, heads=16, N=257, B=2, pad_tail
     worst = max(rows, key=lambda r: r[1])
     assert worst[1] <= 0.02, f"gradient norm off: {worst}"
     return dict(min_cos=rows[0], worst_norm=worst, n=len(rows))
+
+
+# ------------------------------------------------------------------------------ ViLBERT co-attention operator (T12)
+def case_vilbert_biattention(dev, golden):
+    """BertBiAttention (antmmf/models/vilbert.py:285-416) on the HIP path vs the reference run (ops_vilbert_biattention.pt: both contexts, input
+    gradients, every parameter gradient; ragged key masks on both streams), and -- training mode, dropout on -- vs the oracle co-attention with
+    the same counter-based masks rebuilt on the host."""
+    import numpy as np
+    from antmmf.common.configuration import Configuration
+    from antmmf.models.vilbert import BertBiAttention
+    from kernel_cases import dropout_keep_np
+    from oracle import ops as oops
+
+    g = golden("ops_vilbert_biattention.pt")
+    cfg = Configuration(dict(bi_hidden_size=128, bi_num_attention_heads=2, v_hidden_size=96, hidden_size=128, v_attention_probs_dropout_prob=0.1,
+                             attention_probs_dropout_prob=0.1, visualization=False))
+    m = BertBiAttention(cfg)
+    W.fill_module_(m)
+    m = m.to(dev).eval()
+    x1 = g["x1"].to(dev).requires_grad_(True)
+    x2 = g["x2"].to(dev).requires_grad_(True)
+    c1, c2, vis = m(x1, g["mask1"].to(dev), x2, g["mask2"].to(dev))
+    assert vis is None and c1.shape == g["ctx1"].shape and c2.shape == g["ctx2"].shape
+    check("bi.ctx1", c1, g["ctx1"], 3e-2, 2e-2)
+    check("bi.ctx2", c2, g["ctx2"], 3e-2, 2e-2)
+    ((c1.float() * g["g1"].to(dev)).sum() + (c2.float() * g["g2"].to(dev)).sum()).backward()
+    check("bi.dx1", x1.grad, g["dx1"], 5e-2, 3e-2)
+    check("bi.dx2", x2.grad, g["dx2"], 5e-2, 3e-2)
+    rows = []
+    for n, p in m.named_parameters():
+        ref = g["grad." + n].float().flatten()
+        got = p.grad.detach().float().flatten().cpu()
+        if float(ref.norm()) < 1e-5:      # key biases: zero by shift invariance
+            continue
+        rows.append((float(torch.dot(got, ref)) / float(got.norm() * ref.norm()), abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()), n))
+    rows.sort()
+    assert len(rows) >= 10 and rows[0][0] >= 0.995 and max(r[1] for r in rows) <= 0.05, rows[:4]
+    # training mode: attention-probability dropout inside the kernels, masks = keep(seed, ((b h + head) Nq + q) Nk + k)
+    m.train()
+    seeds = [(5 << 32) | 1234, (9 << 32) | 77]
+    with torch.no_grad():
+        d1, d2, _ = m(g["x1"].to(dev), g["mask1"].to(dev), g["x2"].to(dev), g["mask2"].to(dev), dropout_seeds=seeds)
+    P = {n: p.detach().float().cpu() for n, p in m.named_parameters()}
+    xa, xb = g["x1"].to(torch.bfloat16).float(), g["x2"].to(torch.bfloat16).float()
+
+    def proj(x, s):
+        return [oops.split_heads((x @ P[f"{k}{s}.weight"].to(torch.bfloat16).float().t() + P[f"{k}{s}.bias"]).to(torch.bfloat16).float(), 2)
+                for k in ("query", "key", "value")]
+
+    (q1, k1, v1), (q2, k2, v2) = proj(xa, 1), proj(xb, 2)
+    B, Nv, Nt = xa.shape[0], xa.shape[1], xb.shape[1]
+    for tag, got, qq, kk, vv, bias, seed, nq, nk in (("ctx1", d1, q2, k1, v1, g["mask1"].reshape(B, -1), seeds[0], Nt, Nv),
+                                                    ("ctx2", d2, q1, k2, v2, g["mask2"].reshape(B, -1), seeds[1], Nv, Nt)):
+        keep = dropout_keep_np(np.arange(B * 2 * nq * nk).reshape(B, 2, nq, nk), seed, 0.1).float() / 0.9
+        s = torch.matmul(qq, kk.transpose(-1, -2)) / 8.0 + bias[:, None, None, :]
+        want = oops.merge_heads(torch.matmul(torch.softmax(s, -1) * keep, vv))
+        check("bi.drop." + tag, got, want, 3e-2, 2e-2)
+    with pytest_raises(NotImplementedError):
+        BertBiAttention(Configuration(dict(cfg.to_dict() if hasattr(cfg, "to_dict") else dict(cfg), bi_hidden_size=256)))
+    return dict(min_cos=rows[0], n=len(rows))
+
+
+def pytest_raises(exc):
+    import pytest
+
+    return pytest.raises(exc)

@@ -103,6 +103,10 @@ def test_bert_layer_dropout_vs_oracle_same_masks():
     print(mc.case_bert_layer_dropout(torch.device("cpu")))
 
 
+def test_vilbert_biattention_vs_reference(golden):
+    print(mc.case_vilbert_biattention(torch.device("cpu"), golden))
+
+
 def test_temporal_head_vs_oracle_and_reference(golden):
     print(mc.case_temporal_head(torch.device("cpu"), golden))
 

@@ -79,6 +79,10 @@ def test_bert_layer_dropout_vs_oracle_same_masks():
     print(mc.case_bert_layer_dropout(DEV))
 
 
+def test_vilbert_biattention_vs_reference(golden):
+    print(mc.case_vilbert_biattention(DEV, golden))
+
+
 def test_temporal_head_vs_oracle_and_reference(golden):
     print(mc.case_temporal_head(DEV, golden))
 
