@@ -72,18 +72,107 @@ class ParamArena:
         ops.sumsq_(s, self.grad)
         return s.sqrt()
 
-    def allreduce_grads(self, group=None, bucket_bytes=512 << 20):
-        """SUM all-reduce of the gradient arena in large contiguous buckets (the 1/world average is folded
-        into the optimizer's grad_scale).  Returns the world size."""
+    # ------------------------------------------------------------------ data-parallel gradient reduction
+    def _build_buckets(self, bucket_bytes):
+        """Contiguous ranges of whole parameters, >= bucket_bytes each (xGMI ring all-reduce is per-link-bound: few large messages)."""
+        want = max(1, bucket_bytes // 4)
+        buckets, start, params = [], 0, []
+        for g in self.groups:
+            off = g["start"]
+            for p in g["params"]:
+                n = (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+                params.append(p)
+                off += n
+                if off - start >= want:
+                    buckets.append(dict(start=start, end=off, params=params))
+                    start, params = off, []
+        if params or start < self.grad.numel():
+            buckets.append(dict(start=start, end=self.grad.numel(), params=params))
+        for i, b in enumerate(buckets):
+            for p in b["params"]:
+                p._antmmf_bucket = i
+        return buckets
+
+    def arm_overlap(self, group=None, bucket_bytes=256 << 20, reduce_dtype=None):
+        """Call BEFORE the forward pass of an optimizer-step iteration: the fused layers then report (functional._TransformerLayer)
+        when a parameter's gradient is final, and every bucket whose parameters are all final is all-reduced right away on RCCL's
+        stream, under the rest of the backward pass.  `allreduce_grads()` launches what is left and waits.
+        reduce_dtype=torch.bfloat16 sends buckets as bf16 (half the xGMI bytes; the sum of W bf16 values carries ~3 significant digits)."""
+        self._ov = None
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return False
+        key = (bucket_bytes,)
+        if getattr(self, "_bucket_key", None) != key:
+            self._buckets, self._bucket_key = self._build_buckets(bucket_bytes), key
+        for g in self.groups:
+            for p in g["params"]:
+                p._antmmf_uses = 0
+        self._ov = dict(group=group, dtype=reduce_dtype, handles=[], launched=set(), frozen=False, left=None)
+        return True
+
+    def note_forward(self, params):
+        ov = getattr(self, "_ov", None)
+        if ov is None or ov["frozen"]:
+            return
+        for p in params:
+            if p is not None and getattr(p, "_antmmf_arena", None) is self:
+                p._antmmf_uses += 1
+
+    def note_backward(self, params):
+        """The calling autograd node has accumulated its share of these parameters' gradients."""
+        ov = getattr(self, "_ov", None)
+        if ov is None:
+            return
+        if not ov["frozen"]:  # first backward node of the step: per bucket, how many tracked parameters are still open
+            ov["frozen"] = True
+            ov["left"] = []
+            for b in self._buckets:
+                tracked = sum(1 for p in b["params"] if p._antmmf_uses > 0)
+                untracked = sum(1 for p in b["params"] if p._antmmf_uses == 0)
+                ov["left"].append(tracked if untracked == 0 else -1)  # -1: holds parameters outside the fused layers -> reduced at the end
+        for p in params:
+            if p is None or getattr(p, "_antmmf_arena", None) is not self or p._antmmf_uses <= 0:
+                continue
+            p._antmmf_uses -= 1
+            if p._antmmf_uses == 0:
+                i = p._antmmf_bucket
+                if ov["left"][i] > 0:
+                    ov["left"][i] -= 1
+                    if ov["left"][i] == 0:
+                        self._launch_bucket(i)
+
+    def _launch_bucket(self, i):
+        ov, b = self._ov, self._buckets[i]
+        if i in ov["launched"]:
+            return
+        ov["launched"].add(i)
+        seg = self.grad[b["start"]:b["end"]]
+        if ov["dtype"] is not None and ov["dtype"] != torch.float32:
+            tmp = seg.to(ov["dtype"])
+            ov["handles"].append((dist.all_reduce(tmp, group=ov["group"], async_op=True), tmp, seg))
+        else:
+            ov["handles"].append((dist.all_reduce(seg, group=ov["group"], async_op=True), None, None))
+
+    def allreduce_grads(self, group=None, bucket_bytes=512 << 20, reduce_dtype=None):
+        """SUM all-reduce of the gradient arena in large contiguous buckets (the 1/world average is folded into the optimizer's
+        grad_scale).  After arm_overlap(): launches the buckets the backward pass has not sent yet and waits for all of them.
+        Returns the world size."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         world = dist.get_world_size(group)
         if world == 1:
             return 1
-        step = bucket_bytes // 4
-        handles = [dist.all_reduce(self.grad[i:i + step], group=group, async_op=True) for i in range(0, self.grad.numel(), step)]
-        for h in handles:
+        if getattr(self, "_ov", None) is None:
+            self.arm_overlap(group, bucket_bytes, reduce_dtype)
+            self._ov["frozen"], self._ov["left"] = True, [-1] * len(self._buckets)
+        for i in range(len(self._buckets)):
+            self._launch_bucket(i)
+        for h, tmp, seg in self._ov["handles"]:
             h.wait()
+            if tmp is not None:
+                seg.copy_(tmp)
+        self.overlapped_buckets = len(self._ov["launched"]) - sum(1 for x in self._ov["left"] if x != 0)   # diagnostics / tests
+        self._ov = None
         return world
 
 

@@ -63,13 +63,42 @@ def _reduce_scatter_sum(full, group):
     if w == 1:
         return full
     out = torch.empty((full.shape[0] // w,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
-    if dist.get_backend(group) == "gloo":  # gloo lacks reduce_scatter: CPU unit tests only
-        g = full.clone()
-        dist.all_reduce(g, group=group)
-        r = dist.get_rank(group)
-        return g[r * out.shape[0]:(r + 1) * out.shape[0]].contiguous()
     dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=group)
     return out
+
+
+def _all_gather_packed(tensors, group):
+    """ONE all-gather for several per-rank tensors that share their leading (pair) dimension: they are packed side by side into a
+    [B, sum of widths] buffer, gathered, and split again (xGMI collectives are latency- and per-link-bound: one message instead of
+    one per embedding set -- image + text + the two VL heads of the M2 step, text + clips of the video step)."""
+    w, _ = _world(group)
+    if w == 1:
+        return list(tensors)
+    B = tensors[0].shape[0]
+    flat = [t.reshape(B, -1) for t in tensors]
+    widths = [f.shape[1] for f in flat]
+    every = _all_gather(torch.cat(flat, dim=1), group)
+    outs, off = [], 0
+    for t, wd in zip(tensors, widths):
+        outs.append(every[:, off:off + wd].reshape((every.shape[0],) + tuple(t.shape[1:])).contiguous())
+        off += wd
+    return outs
+
+
+def _reduce_scatter_packed(fulls, group):
+    """ONE reduce-scatter(sum) for several [B_g, ...] gradients (the inverse of _all_gather_packed)."""
+    w, _ = _world(group)
+    if w == 1:
+        return list(fulls)
+    Bg = fulls[0].shape[0]
+    flat = [f.reshape(Bg, -1) for f in fulls]
+    widths = [f.shape[1] for f in flat]
+    mine = _reduce_scatter_sum(torch.cat(flat, dim=1), group)
+    outs, off = [], 0
+    for f, wd in zip(fulls, widths):
+        outs.append(mine[:, off:off + wd].reshape((mine.shape[0],) + tuple(f.shape[1:])).contiguous())
+        off += wd
+    return outs
 
 
 def _split(x):
@@ -109,7 +138,8 @@ class _MilNceSharded(torch.autograd.Function):
         world, rank = _world(group)
         B, D = text.shape
         text, clips = text.float().contiguous(), clips.float().contiguous()
-        T_all, V_all = _all_gather(text, group), _all_gather(clips, group)
+        T_all, V_all = _all_gather_packed([text, clips.view(B, n_clips * D)], group)   # one message: [B, (1 + n) D]
+        V_all = V_all.view(-1, D)
         Bg = T_all.shape[0]
         centre = clips.view(B, n_clips, D)[:, n_clips // 2].contiguous()
         Rm = matmul_f32(text, V_all).contiguous()      # [B, Bg*n]   <text_i, clip_c>
@@ -136,7 +166,8 @@ class _MilNceSharded(torch.autograd.Function):
         dT_all[row0:row0 + B] += matmul_f32(dR, V_all, b_rmajor=True)   # dR V_all
         dVc = matmul_f32(dC, T_all, b_rmajor=True)                      # dC T_all -> centre clips of the local videos
         dV_all.view(-1, n, D)[row0:row0 + B, n // 2] += dVc
-        return _reduce_scatter_sum(dT_all, group), _reduce_scatter_sum(dV_all, group), None, None, None
+        dT, dV = _reduce_scatter_packed([dT_all, dV_all.view(-1, n * D)], group)
+        return dT, dV.view(-1, D), None, None, None
 
 
 def mil_nce_sharded(text_embed, clip_embed, n_clips=1, weight=None, group=None):
@@ -151,7 +182,7 @@ class _ClipItcSharded(torch.autograd.Function):
         world, rank = _world(group)
         B, D = img.shape
         img, txt = img.float().contiguous(), txt.float().contiguous()
-        I_all, T_all = _all_gather(img, group), _all_gather(txt, group)
+        I_all, T_all = _all_gather_packed([img, txt], group)
         Bg = I_all.shape[0]
         row0 = rank * B
         ls = log_scale.detach().float().reshape(1).contiguous()
@@ -179,13 +210,69 @@ class _ClipItcSharded(torch.autograd.Function):
         dI_all[row0:row0 + B] += matmul_f32(dxi, T_all, b_rmajor=True)
         dT_all[row0:row0 + B] += matmul_f32(dxt, I_all, b_rmajor=True)
         dls = (dscale * ls.exp()).reshape(())  # d/d log_scale = d/d s * s
-        return _reduce_scatter_sum(dI_all, group), _reduce_scatter_sum(dT_all, group), dls, None
+        dI, dT = _reduce_scatter_packed([dI_all, dT_all], group)
+        return dI, dT, dls, None
 
 
 def clip_itc_sharded(img_embed, txt_embed, log_scale, group=None):
     """Symmetric InfoNCE over logits = exp(log_scale) * img @ txt^T (prj/M2_Encoder/m2_encoder.py:92-95;
     antmmf/modules/vision/backbone/clip/model.py:442-444), rows sharded over ranks."""
     return _ClipItcSharded.apply(img_embed, txt_embed, log_scale, group)
+
+
+class _ClipItcPairSharded(torch.autograd.Function):
+    """The M2 step's TWO symmetric InfoNCE terms (cls heads with logit_scale, VL-FFN heads with logit_vl_scale) with ONE
+    exchange each way: the four [B, D] embedding sets travel in a single all-gather ([B, 4 D]), the two loss values in one all-reduce,
+    the four embedding gradients in a single reduce-scatter.  Arithmetic per term is _ClipItcSharded's."""
+
+    @staticmethod
+    def forward(ctx, img1, txt1, ls1, img2, txt2, ls2, group):
+        world, rank = _world(group)
+        B = img1.shape[0]
+        locs = [t.float().contiguous() for t in (img1, txt1, img2, txt2)]
+        alls = _all_gather_packed(locs, group)
+        Bg, row0 = alls[0].shape[0], rank * B
+        saved, losses = [], []
+        for (im, tx, I_all, T_all, lsp) in ((locs[0], locs[1], alls[0], alls[1], ls1), (locs[2], locs[3], alls[2], alls[3], ls2)):
+            ls = lsp.detach().float().reshape(1).contiguous()
+            xi = matmul_f32(im, T_all).contiguous()
+            xt = matmul_f32(tx, I_all).contiguous()
+            li, lse_i = ops.softmax_ce_fwd(xi, row0, ls)
+            lt, lse_t = ops.softmax_ce_fwd(xt, row0, ls)
+            losses.append((li.sum() + lt.sum()) * (0.5 / Bg))
+            saved += [im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls]
+        loss = torch.stack(losses)
+        if world > 1:
+            dist.all_reduce(loss, group=group)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (row0, world, group, B, Bg)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        row0, world, group, B, Bg = ctx.meta
+        sv = ctx.saved_tensors
+        grads, dlss = [], []
+        for k, gout in enumerate((g1, g2)):
+            im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls = sv[9 * k:9 * k + 9]
+            coef = (gout * world * 0.5 / Bg).reshape(1).expand(B).contiguous().float()
+            dscale = torch.zeros(1, dtype=torch.float32, device=im.device)
+            dxi = ops.softmax_ce_bwd(xi, lse_i, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
+            dxt = ops.softmax_ce_bwd(xt, lse_t, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
+            dI_all = matmul_f32(dxt, tx, a_rmajor=True, b_rmajor=True)
+            dT_all = matmul_f32(dxi, im, a_rmajor=True, b_rmajor=True)
+            dI_all[row0:row0 + B] += matmul_f32(dxi, T_all, b_rmajor=True)
+            dT_all[row0:row0 + B] += matmul_f32(dxt, I_all, b_rmajor=True)
+            grads += [dI_all, dT_all]
+            dlss.append((dscale * ls.exp()).reshape(()))
+        dI1, dT1, dI2, dT2 = _reduce_scatter_packed(grads, group)
+        return dI1, dT1, dlss[0], dI2, dT2, dlss[1], None
+
+
+def clip_itc_pair_sharded(img1, txt1, log_scale1, img2, txt2, log_scale2, group=None):
+    """(loss of pair 1, loss of pair 2) -- two clip_itc_sharded terms with packed collectives (one all-gather, one loss all-reduce,
+    one reduce-scatter for both)."""
+    return _ClipItcPairSharded.apply(img1, txt1, log_scale1, img2, txt2, log_scale2, group)
 
 
 # ------------------------------------------------------------------------------ MoCo (queue negatives)

@@ -483,6 +483,9 @@ class _TransformerLayer(torch.autograd.Function):
                 dx = ops.gemm(dqkv2, wqkv_t, residual=dmid)
             dx = dx.view(B, N, d)
         grads = [sink.result(p, p is not None and ctx.needs_input_grad[4 + i]) for i, p in enumerate(params)]
+        arena = next((getattr(p, "_antmmf_arena", None) for p in params if p is not None), None)
+        if arena is not None:
+            arena.note_backward(params)   # these parameters' gradients may now be final: their bucket's all-reduce can start
         return (dx, None, None, None, *grads)
 
 
@@ -491,7 +494,11 @@ def transformer_layer(x, spec, params, key_bias=None, seed=None):
     (BERT layers with dropout > 0 only); None draws one from torch's CPU generator (host side: no device sync)."""
     if seed is None and spec.kind == "bert" and (spec.attn_dropout > 0 or spec.hidden_dropout > 0):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _TransformerLayer.apply(x, key_bias, spec, seed, *[params.get(s) for s in SLOTS])
+    plist = [params.get(s) for s in SLOTS]
+    arena = next((getattr(p, "_antmmf_arena", None) for p in plist if p is not None), None)
+    if arena is not None and torch.is_grad_enabled():
+        arena.note_forward(plist)   # gradient all-reduce under the backward pass (arena.arm_overlap): counts this use of the parameters
+    return _TransformerLayer.apply(x, key_bias, spec, seed, *plist)
 
 
 # ------------------------------------------------------------------------------ embeddings

@@ -5,8 +5,9 @@ What is kept: the registry name ("base_trainer"), `Trainer(config)`, `.load()`, 
 keys the loop reads, `_forward_pass / _extract_loss / _backward / _update_meter`, and the one-process-per-GPU contract
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher).  What is re-designed for MI355X:
   * data parallelism is NOT torch DDP: parameters live in a flat arena (antmmf.hip.arena) and the gradient reduction is a
-    few large RCCL all-reduces over it after backward, the 1/world mean and the clip coefficient folded into the fused
-    AdamW launch -- no per-bucket copies, no find_unused_parameters graph walk;
+    few large RCCL all-reduces over contiguous ranges of it, started from inside the backward pass as soon as the fused layers report
+    a bucket's gradients final (`overlap_grad_allreduce`, default on; `grad_allreduce_dtype: bf16` halves the xGMI bytes), the 1/world
+    mean and the clip coefficient folded into the fused AdamW launch -- no per-bucket copies, no find_unused_parameters graph walk;
   * bf16 compute with fp32 masters instead of fp16 autocast + GradScaler (no scaler, no unscale pass);
   * `current_iteration` advances ONCE per batch (the reference increments it twice, base_trainer.py:551,589, so its
     max_iterations / lr steps count half-steps; documented deviation, see DESIGN.md);
@@ -247,6 +248,11 @@ class BaseTrainer:
     def _forward_pass(self, batch, enable_amp=False):
         if not batch:
             return None, None, None
+        if (self.arena is not None and self.model.training and torch.is_grad_enabled() and get_world_size() > 1
+                and self.current_iteration % self.gradient_accumulation_steps == 0
+                and self.config.training_parameters.get("overlap_grad_allreduce", True)):
+            rd = self.config.training_parameters.get("grad_allreduce_dtype", "fp32")
+            self.arena.arm_overlap(reduce_dtype=torch.bfloat16 if str(rd) in ("bf16", "bfloat16") else None)
         prepared = batch.to(self.device) if isinstance(batch, SampleList) else SampleList(batch).to(self.device)
         model_output = self.model(prepared)
         return dict(losses=model_output["losses"], metrics=model_output.get("metrics", {}),

@@ -4,7 +4,7 @@ Same public names and meaning as the reference's antmmf/utils/distributed_utils.
 get_world_size, is_main_process, synchronize, gather_tensor, all_gather, reduce_dict, broadcast_scalar),
 re-designed for xGMI: tensor collectives are single `all_gather_into_tensor` / `reduce_scatter_tensor` calls on
 contiguous buffers (the reference issues W+1 list-of-tensor collectives, a host sync for the size exchange and W
-serial `reduce`s in backward).  Works with "gloo" on CPU for the multi-process unit tests.
+serial `reduce`s in backward).  (The multi-process CPU unit tests run it on "gloo" with a reduce_scatter shim installed by the tests.)
 """
 import pickle
 
@@ -73,12 +73,7 @@ class GradientAllGather(torch.autograd.Function):
         world = dist.get_world_size()
         grad = grad.contiguous()
         out = torch.empty((grad.shape[0] // world,) + tuple(grad.shape[1:]), dtype=grad.dtype, device=grad.device)
-        if dist.get_backend() == "gloo":  # gloo has no reduce_scatter: all_reduce + slice (CPU unit tests only)
-            g = grad.clone()
-            dist.all_reduce(g)
-            out.copy_(g[dist.get_rank() * out.shape[0]:(dist.get_rank() + 1) * out.shape[0]])
-        else:
-            dist.reduce_scatter_tensor(out, grad, op=dist.ReduceOp.SUM)
+        dist.reduce_scatter_tensor(out, grad, op=dist.ReduceOp.SUM)
         return out
 
 

@@ -167,8 +167,8 @@ class VLMo(nn.Module):
     # ------------------------------------------------------------------ training step (this build's; see module docstring)
     def compute_itc(self, batch):
         oi, ot = self.infer_image(batch), self.infer_text(batch)
-        l1 = contrastive.clip_itc_sharded(oi["cls_feats"], ot["cls_feats"], self.logit_scale)
-        l2 = contrastive.clip_itc_sharded(oi["cls_vlffn_feats"], ot["cls_vlffn_feats"], self.logit_vl_scale)
+        l1, l2 = contrastive.clip_itc_pair_sharded(oi["cls_feats"], ot["cls_feats"], self.logit_scale,
+                                                   oi["cls_vlffn_feats"], ot["cls_vlffn_feats"], self.logit_vl_scale)
         return {"losses": {"itc_loss": 0.5 * l1, "itc_vl_loss": 0.5 * l2}, "image": oi, "text": ot}
 
     def forward(self, batch):

@@ -110,12 +110,33 @@ def test_hip_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
 
 
 # ------------------------------------------------------------------------------ multi-process (gloo, world 2)
+def _install_gloo_reduce_scatter():
+    """TEST SHIM: gloo has no reduce_scatter_tensor; the product code calls it unconditionally (RCCL has it), so the CPU multi-process tests
+    provide it as all_reduce + slice."""
+    if getattr(dist, "_antmmf_rs_shim", False):
+        return
+    real = dist.reduce_scatter_tensor
+
+    def shim(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if dist.get_backend(group) != "gloo":
+            return real(output, input, op=op, group=group, async_op=async_op)
+        full = input.clone()
+        dist.all_reduce(full, op=op, group=group)
+        r, n = dist.get_rank(group), output.shape[0]
+        output.copy_(full[r * n:(r + 1) * n])
+        return None
+
+    dist.reduce_scatter_tensor = shim
+    dist._antmmf_rs_shim = True
+
+
 def _worker(rank, world, port, fn, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     for p in (ROOT, PKG, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_gloo_reduce_scatter()
     try:
         ret[rank] = fn(rank, world)
     finally:
@@ -348,3 +369,64 @@ def test_m2_checkpoint_converters_match_reference(golden):
     torch.testing.assert_close(out["backbone.encoder.embed_positions.A.weight"], g["ds.pos"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(out["visual_tokenizer.encoder.pos_embed"], g["ds.vt"], rtol=1e-6, atol=1e-7)
     assert sorted(len(k) for k in out) == g["ds.keys"].tolist()
+
+
+def _m2_step_case(rank, world):
+    """One tiny-M2 ITC training step through the product stack on `world` gloo ranks (emulated kernels): VLMo towers, packed sharded ITC
+    pair loss, gradient all-reduce over the flat arena (started from inside backward), fused AdamW with grad_scale = 1 / world."""
+    os.environ["ANTMMF_HIP_LIB"] = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+    sys.path.insert(0, os.path.join(PKG, "prj", "M2_Encoder"))
+    import model_cases as mc
+    import weightgen as W
+    from antmmf.hip import _lib
+    from antmmf.hip.arena import HipAdamW
+
+    _lib.reset_for_tests()
+    dev = torch.device("cpu")
+    model = mc.build_tiny_m2(dev)
+    opt = HipAdamW([{"params": list(model.parameters())}], lr=1e-2, weight_decay=0.01)
+    img = (W.data_tensor("m2dp.image", (4, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1)
+    ids = W.data_ints("m2dp.ids", (4, 12), 1, 300)
+    lengths = torch.tensor([12, 5, 8, 3])
+    mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
+    ids = ids * mask
+    per = 4 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    mode = os.environ.get("ANTMMF_TEST_DP_MODE", "overlap")
+    if world > 1 and mode != "plain":
+        assert opt.arena.arm_overlap(bucket_bytes=64 << 10, reduce_dtype=torch.bfloat16 if mode == "bf16" else None)
+    out = model({"image": [img[sl]], "text_ids": ids[sl], "text_masks": mask[sl]})
+    loss = out["losses"]["itc_loss"] + out["losses"]["itc_vl_loss"]
+    loss.backward()
+    w = opt.arena.allreduce_grads()
+    overlapped = getattr(opt.arena, "overlapped_buckets", 0)
+    opt.grad_scale = 1.0 / w
+    gsum = opt.arena.grad.clone() / w
+    opt.step()
+    return dict(loss=float(loss), grad=gsum, master=opt.arena.master.clone(), world=w, overlapped=overlapped,
+                nbuckets=len(getattr(opt.arena, "_buckets", [])))
+
+
+_SLOW = pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="set ANTMMF_SLOW_TESTS=1 (three emulated M2 steps, ~3 min each variant)")
+
+
+@pytest.mark.parametrize("mode", ["overlap", pytest.param("plain", marks=_SLOW), pytest.param("bf16", marks=_SLOW)])
+def test_m2_step_two_ranks_equals_single_rank(mode):
+    """the WHOLE M2 step on 2 ranks (2 pairs each) == the 1-rank step on the 4-pair batch: same global loss on both
+    ranks, the averaged arena gradient equals the single-rank gradient, replicas hold identical weights after the fused AdamW.
+    overlap: buckets all-reduced from inside the backward pass (some must really have gone early); plain: after backward; bf16: bf16 buckets."""
+    os.environ["ANTMMF_TEST_DP_MODE"] = mode
+    try:
+        two = _spawn(_m2_step_case, 29671 + ["overlap", "plain", "bf16"].index(mode))
+        one = _spawn(_m2_step_case, 29675 + ["overlap", "plain", "bf16"].index(mode), world=1)[0]
+    finally:
+        os.environ.pop("ANTMMF_TEST_DP_MODE", None)
+    assert two[0]["world"] == 2 and one["world"] == 1
+    assert abs(two[0]["loss"] - two[1]["loss"]) < 1e-6 and abs(two[0]["loss"] - one["loss"]) <= 2e-5 * abs(one["loss"])
+    torch.testing.assert_close(two[0]["master"], two[1]["master"], rtol=0, atol=0)      # replicas bit-identical
+    tol = dict(rtol=2e-2, atol=2e-3 * float(one["grad"].abs().max())) if mode == "bf16" else dict(rtol=1e-3, atol=1e-5 * float(one["grad"].abs().max()))
+    torch.testing.assert_close(two[0]["grad"], one["grad"], **tol)
+    if mode == "overlap":
+        assert two[0]["nbuckets"] >= 4 and two[0]["overlapped"] >= 1, (two[0]["nbuckets"], two[0]["overlapped"])
+    if mode != "bf16":
+        torch.testing.assert_close(two[0]["master"], one["master"], rtol=1e-4, atol=1e-5)
