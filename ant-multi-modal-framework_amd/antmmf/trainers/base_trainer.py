@@ -179,13 +179,8 @@ class BaseTrainer:
             registry.register("current_iteration", self.current_iteration)
             if mining and batch:  # scheduled hard-negative ratio of the CN-VID configs (reference base_trainer.py:552-571)
                 batch["incre_num"] = min(int(self.current_iteration / mcfg.change_iter) * mcfg.change_rate, 1.0)
-            report, model_output, _ = self._forward_pass(batch)
-            if report is None:
+            if self.train_step(batch) is None:
                 continue
-            self._update_meter(report)
-            loss = self._extract_loss(report)
-            self._backward(loss)
-            self._run_scheduler()
             if self.current_iteration % self.log_interval == 0:
                 meters = self.read_meters()  # the one host sync of the interval
                 if is_main_process():
@@ -202,6 +197,18 @@ class BaseTrainer:
         if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
             self.checkpoint.finalize()
         return self.read_meters()
+
+    def train_step(self, batch):
+        """ONE iteration of the loop body: forward, meters, loss, backward (+ gradient all-reduce, clip, fused optimizer when the
+        accumulation window closes), LR schedule.  bench.py times exactly this.  Returns the loss tensor (None for an empty batch)."""
+        report, _, _ = self._forward_pass(batch)
+        if report is None:
+            return None
+        self._update_meter(report)
+        loss = self._extract_loss(report)
+        self._backward(loss)
+        self._run_scheduler()
+        return loss
 
     # ------------------------------------------------------------------ evaluation / early stopping
     def evaluate(self, batches):

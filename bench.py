@@ -1,20 +1,29 @@
 #!/usr/bin/env python
-"""bench.py -- image-text pairs/s of the M2-Encoder ViT-L/14 ITC training step on MI355X (BASELINE.json metric).
+"""bench.py -- pairs/s of the contrastive image/video-text training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload l14|b16|vtp8|dmae12]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = forward + backward + optimizer over one synthetic batch already resident in HBM: B = 1024 pairs per GPU
-(224x224x3 frames, 77-token captions), M2 `large` towers with patch 14 (257 visual tokens, 21+3 layers, d = 1024; SURVEY.md
-"Facts" 3), random-init weights, bf16 MFMA compute with fp32 masters, global negatives all-gathered over RCCL, row-sharded
-symmetric InfoNCE on both ITC levels, bucketed RCCL all-reduce of the flat gradient arena, fused AdamW.  Weak scaling: the
-per-GPU batch is fixed, so the global batch is 1024 x N (8192 at N = 8, the configuration the metric is quoted on).
+Default workload `l14` (the BASELINE metric): one step = forward + backward + optimizer over one synthetic batch already resident in
+HBM: B = 1024 pairs per GPU (224x224x3 frames, 77-token captions, ragged true lengths), M2 `large` towers with patch 14 (257 visual
+tokens, 21+3 layers, d = 1024; SURVEY.md "Facts" 3), random-init weights, bf16 MFMA compute with fp32 masters, global negatives
+all-gathered over RCCL (one packed message), row-sharded symmetric InfoNCE on both ITC levels, gradient all-reduce of the flat arena started
+from inside the backward pass, fused AdamW.  Weak scaling: the per-GPU batch is fixed, so the global batch is 1024 x N (8192 at N = 8).
+The step is BaseTrainer.train_step -- the trainer's own loop body (forward, device-side meters, backward, reduction, optimizer, LR
+schedule), not a hand-rolled loop.
+
+Other workloads (BASELINE.json configs 1, 3, 4; their own metric strings, never the BASELINE line):
+  b16     M2 `base` (ViT-B/16 dims) ITC, 1024 pairs per GPU
+  vtp8    prj/base_vtp `univl` (clip arch: ViT-B/16 + BERT-base, vocab 21128), 8 clips per video, stage1 (MIL-NCE over the 8 x B_g clips)
+          + stage2 (cross-modal merged attention over [text ; clips ; SEP] through the text tower's layers for every text x video pair)
+  dmae12  prj/dmae_vtp `univl`, 12 frames, 30-word captions, stage1 + stage3 (seqTransf temporal transformer, WTI similarity, NegNCE, TPM-CL type 4)
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      the dominant kernel (the bf16 MFMA GEMM): algorithmic flops per launch / average launch duration, measured live
+  roofline      the dominant kernel family (the bf16 MFMA GEMMs): algorithmic flops per launch / average launch duration, measured live
                 with HIP events on the launch stream over the timed steps; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle (oracle/, plain torch fp32 restatement of the reference; kind "port") timed on this host's cores
-                on a bounded sample of the same workload (rank 0, N = 1 only).
+  cpu_baseline  the CPU oracle (oracle/, plain torch fp32 restatement of the reference; kind "port") timed on this host's cores on a bounded
+                sample of the same workload: 1 warm-up + 3 timed passes of forward + backward (NO optimizer step: stated), same ragged
+                masks; for `l14` also the SURVEY 8(d) config-0 leg (clip-arch ViT-B/16 + BERT-base, B = 8).  Rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -26,13 +35,13 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd"))
-sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder"))
+PKG = os.path.join(ROOT, "ant-multi-modal-framework_amd")
+sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(PKG, "prj", "M2_Encoder"))
 
-TRAIN_GFLOP_PER_PAIR = {"l14": 627.3, "b16": 145.3}  # BASELINE.md section 4 (algorithmic, train = 3 x forward, recompute not counted)
 PEAK_TFLOPS = 2500.0
 
-WORKLOADS = {
+M2_WORKLOADS = {
     # M2 `large`, patch 14: 21 + 3 layers, d = 1024, 16 heads, 257 image tokens, 77 text tokens, vocab 115244, D = 1024
     "l14": dict(beit_version="large", encoder_embed_dim=1024, out_embed_dim=1024, encoder_layers=21, beit3_vl_layers=3,
                 image_size=224, patch_size=14, vocab_size=115244, max_text_len=77),
@@ -40,6 +49,41 @@ WORKLOADS = {
     "b16": dict(beit_version="base", encoder_embed_dim=768, out_embed_dim=768, encoder_layers=9, beit3_vl_layers=3,
                 image_size=224, patch_size=16, vocab_size=64010, max_text_len=77),
 }
+M2_TRAIN_GFLOP_PER_PAIR = {"l14": 627.3, "b16": 145.3}  # BASELINE.md section 4 (algorithmic, train = 3 x forward, recompute not counted)
+
+CLIP_B16 = dict(image_encoder=dict(type="VitImageEncoder", params=dict(model_name="ViT-B-16", input_resolution=224, patch_size=16, width=768,
+                                                                       layers=12, out_dim=768, pretrained=False)),
+                text_encoder=dict(type="RobertBertEncoder", params=dict(pretrained=False, vocab_size=21128, hidden_size=768, intermediate_size=3072,
+                                                                        num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=512,
+                                                                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=768, is_proj=True)))
+VTP_WORKLOADS = {
+    "vtp8": dict(prj="base_vtp", n_clips=8, seq=77, default_batch=32,
+                 model=dict(training_head_type="video_text_retrieval", arch_type="clip", training_stage="stage1+stage2", with_moco=False,
+                            with_cross_encoder=True, hidden_size=768, **CLIP_B16)),
+    "dmae12": dict(prj="dmae_vtp", n_clips=12, seq=30, default_batch=64,
+                   model=dict(training_head_type="video_text_retrieval", arch_type="clip", training_stage="stage1+stage3", with_moco=False,
+                              with_cross_encoder=False, hidden_size=768, l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="seqTransf",
+                              l3_sim_header_hidden_layer=4, l3_partial_type=4, l3_max_frames=12, l3_max_words=30, l3_loss_type="negNCE", **CLIP_B16)),
+}
+
+
+def tower_gflop(L, N, d, extra=0.0):
+    """forward GFLOP of a transformer tower over one sequence: L N (24 d^2 + 4 N d)."""
+    return (L * N * (24.0 * d * d + 4.0 * N * d) + extra) / 1e9
+
+
+def vtp_train_gflop_per_pair(name, batch_global, batch_local):
+    """Algorithmic training GFLOP (3 x forward) per video-text pair of the video workloads."""
+    w = VTP_WORKLOADS[name]
+    n, seq, d = w["n_clips"], w["seq"], 768
+    vit = tower_gflop(12, 197, d, extra=2.0 * 196 * 3 * 256 * d + 2.0 * d * d)   # per frame
+    bert = tower_gflop(12, seq, d, extra=2.0 * d * d)                             # per caption
+    fwd = n * vit + bert
+    if name == "vtp8":   # stage 2: every local caption against every (gathered) video: B_g sequences of (seq + n + 1) tokens per caption
+        fwd += batch_global * tower_gflop(12, seq + n + 1, d, extra=2.0 * d * 2 * d)
+    else:                # stage 3: 4-layer temporal transformer over n + 1 tokens per video + the token-wise similarity against the global batch
+        fwd += tower_gflop(4, n + 1, d) + 2.0 * batch_global * seq * (n + 1) * d / 1e9
+    return 3.0 * fwd
 
 
 def parse():
@@ -47,75 +91,202 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="l14", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU")
+    ap.add_argument("--workload", default="l14", choices=sorted(list(M2_WORKLOADS) + list(VTP_WORKLOADS)))
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for the M2 workloads, 32 / 64 videos for vtp8 / dmae12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recompute-ffn-norm", action="store_true", help="do not keep ffn_layernorm(gelu(u)) for backward (saves ~65 GiB at 1024 pairs/GPU, costs ~3 %%)")
     ap.add_argument("--gemm-table", default=None, help="write per-shape GEMM timing (from the live HIP-event trace) to this file")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="pairs in the CPU-oracle sample (8 pairs ~ 10 s on 32 host threads)")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="pairs per pass of the CPU-oracle sample")
     return ap.parse_args()
 
 
-def synthetic_batch(cfg, batch, device, rank):
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
-    img = torch.rand(batch, 3, cfg["image_size"], cfg["image_size"], generator=g, device=device)
-    seq = cfg["max_text_len"]
-    ids = torch.randint(1, cfg["vocab_size"], (batch, seq), generator=g, device=device)
-    lengths = torch.randint(8, seq + 1, (batch,), generator=g, device=device)
+def ragged_captions(batch, seq, vocab, g, device, cls_id=None):
+    ids = torch.randint(1, vocab, (batch, seq), generator=g, device=device)
+    lengths = torch.randint(min(8, seq), seq + 1, (batch,), generator=g, device=device)
     mask = (torch.arange(seq, device=device)[None, :] < lengths[:, None]).long()
     ids = ids * mask
+    if cls_id is not None:
+        ids[:, 0] = cls_id
+    return ids, mask
+
+
+def synthetic_m2_batch(cfg, batch, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    img = torch.rand(batch, 3, cfg["image_size"], cfg["image_size"], generator=g, device=device)
+    ids, mask = ragged_captions(batch, cfg["max_text_len"], cfg["vocab_size"], g, device)
     return {"image": [img], "text_ids": ids, "text_masks": mask}
 
 
-def _cpu_baseline_worker(cfg, pairs, q):
-    """The CPU oracle's M2 ITC step (fwd + bwd, fp32) on `pairs` pairs of the same shapes; puts pairs/s on `q`."""
+def synthetic_vtp_batch(name, batch, device, seed):
+    from antmmf.structures.sample import SampleList
+
+    w = VTP_WORKLOADS[name]
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = w["n_clips"]
+    frames = torch.randn(batch, n, 3, 224, 224, generator=g, device=device)   # already-normalised frames
+    ids, mask = ragged_captions(batch, w["seq"], 21128, g, device, cls_id=101)
+    if name == "dmae12":
+        mask = torch.ones_like(mask)   # DMAE's token predictors are built for exactly l3_max_words tokens (tpmcl_utils.py:21-24)
+        ids = torch.where(ids == 0, torch.ones_like(ids), ids)
+    return SampleList(image_data=frames, image_pad_mask=torch.zeros(batch, n, 224, 224, dtype=torch.bool, device=device), image_n_clips=[n] * batch,
+                      image_num_frames=[1] * batch, caption_input_ids=ids, caption_raw_input_ids=ids, caption_input_mask=mask, dataset_type="train")
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (oracle; separate process)
+def _time_passes(fn, warm=1, timed=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def _cpu_baseline_worker(workload, pairs, q):
+    """The CPU oracle's training step (forward + backward, fp32, no optimizer) on `pairs` pairs of the same shapes and the same kind of
+    ragged masks; 1 warm-up + 3 timed passes; puts a dict on `q`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from oracle import step as ostep
-    from oracle.shapes import m2_shapes
 
     ncpu = os.cpu_count() or 1
-    # torch's CPU kernels stop scaling (and on a 256-core host collapse) well before one thread per core for this
-    # workload's GEMM shapes ([2*257, 1024] x [1024, 4096]); 32 threads is used, or every core on a smaller host
-    cores = min(ncpu, 32)
+    cores = min(ncpu, 32)  # torch's CPU GEMMs stop scaling well before one thread per core on these shapes; 32 threads, or every core of a smaller host
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(7)
-    shapes = m2_shapes(d=cfg["encoder_embed_dim"], layers=cfg["encoder_layers"], vl_layers=cfg["beit3_vl_layers"],
-                       patch=cfg["patch_size"], res=cfg["image_size"], vocab=cfg["vocab_size"], out=cfg["out_embed_dim"])
-    P = {}
-    for k, s in shapes.items():
-        if len(s) == 0:
-            t = torch.tensor(2.659)
-        elif len(s) == 1:
-            t = torch.ones(s) if ("layer_norm" in k or "layernorm" in k or "_ln" in k) and k.endswith("weight") else torch.zeros(s)
-        else:
-            t = torch.empty(s).uniform_(-0.03, 0.03, generator=g)
-        P[k] = t.requires_grad_(True)
-    heads = cfg["encoder_embed_dim"] // 64
-    img = torch.rand(pairs, 3, cfg["image_size"], cfg["image_size"], generator=g)
-    ids = torch.randint(1, cfg["vocab_size"], (pairs, cfg["max_text_len"]), generator=g)
-    mask = torch.ones(pairs, cfg["max_text_len"], dtype=torch.long)
-    t0 = time.perf_counter()
-    out = ostep.m2_itc(P, img, ids, mask, heads=heads, patch=cfg["patch_size"])
-    out["loss"].backward()
-    dt = time.perf_counter() - t0
-    q.put(dict(value=round(pairs / dt, 4), unit="pairs/s", cores=cores, kind="port",
-               sample=f"oracle.step.m2_itc fwd+bwd (no optimizer), fp32, {pairs} pairs of the same shapes, one pass of {dt:.1f} s, {cores} threads"))
+    dev = torch.device("cpu")
+
+    def rand_params(shapes):
+        P = {}
+        for k, s in shapes.items():
+            if len(s) == 0:
+                t = torch.tensor(2.659)
+            elif len(s) == 1:
+                t = torch.ones(s) if ("layer_norm" in k or "layernorm" in k or "_ln" in k or "LayerNorm" in k or "ln_" in k) and k.endswith("weight") else torch.zeros(s)
+            else:
+                t = torch.empty(s).uniform_(-0.03, 0.03, generator=g)
+            P[k] = t.requires_grad_(True)
+        return P
+
+    def clip_leg(n_pairs, n_clips, seq, stage):
+        import tiny_models
+
+        c = dict(width=768, layers=12, heads=12, patch=16, res=224, out_dim=768, vocab=21128, hidden=768, inter=3072, bert_layers=12, bert_heads=12, max_pos=512)
+        shapes = tiny_models.clip_arch_shapes(c)
+        if stage == "stage2":
+            shapes.update({"similarity_dense.0.weight": (1536, 768), "similarity_dense.0.bias": (1536,), "similarity_dense.2.weight": (1, 1536), "similarity_dense.2.bias": (1,)})
+        P = rand_params(shapes)
+        frames = torch.randn(n_pairs, n_clips, 3, 224, 224, generator=g)
+        ids, mask = ragged_captions(n_pairs, seq, 21128, g, dev, cls_id=101)
+
+        def one():
+            for p in P.values():
+                p.grad = None
+            if stage == "stage2":
+                out = ostep.univl_stage2(P, frames, ids, mask, n_clips, 12, 16, 12)
+                loss = out["loss1"] + out["loss2"] if "loss1" in out else out["loss"]
+            else:
+                loss = ostep.univl_stage1(P, frames, ids, mask, n_clips, 12, 16, 12)["loss"]
+            loss.backward()
+
+        return one
+
+    if workload in M2_WORKLOADS:
+        from oracle.shapes import m2_shapes
+
+        cfg = M2_WORKLOADS[workload]
+        P = rand_params(m2_shapes(d=cfg["encoder_embed_dim"], layers=cfg["encoder_layers"], vl_layers=cfg["beit3_vl_layers"], patch=cfg["patch_size"],
+                                  res=cfg["image_size"], vocab=cfg["vocab_size"], out=cfg["out_embed_dim"]))
+        heads = cfg["encoder_embed_dim"] // 64
+        img = torch.rand(pairs, 3, cfg["image_size"], cfg["image_size"], generator=g)
+        ids, mask = ragged_captions(pairs, cfg["max_text_len"], cfg["vocab_size"], g, dev)
+
+        def one():
+            for p in P.values():
+                p.grad = None
+            ostep.m2_itc(P, img, ids, mask, heads=heads, patch=cfg["patch_size"])["loss"].backward()
+
+        ts = _time_passes(one)
+        res = dict(value=round(pairs / (sum(ts) / len(ts)), 4), unit="pairs/s", cores=cores, kind="port",
+                   sample=f"oracle.step.m2_itc forward + backward (no optimizer step), fp32, {pairs} pairs of the same shapes with ragged caption masks, "
+                          f"1 warm-up + {len(ts)} timed passes ({', '.join(f'{t:.1f}' for t in ts)} s), {cores} threads")
+        if workload == "l14":   # SURVEY 8(d) config 0: clip-arch ViT-B/16 + BERT-base, stage 1, B = 8
+            t0 = _time_passes(clip_leg(8, 1, 77, "stage1"))
+            res["config0"] = dict(value=round(8 / (sum(t0) / len(t0)), 4), unit="pairs/s", cores=cores, kind="port",
+                                  sample=f"oracle.step.univl_stage1 (clip arch ViT-B/16 + BERT-base, B = 8, 77 tokens) forward + backward, fp32, 1 warm-up + {len(t0)} timed passes "
+                                         f"({', '.join(f'{t:.1f}' for t in t0)} s), {cores} threads")
+        q.put(res)
+        return
+    w = VTP_WORKLOADS[workload]
+    if workload == "vtp8":
+        one = clip_leg(pairs, w["n_clips"], w["seq"], "stage2")
+        what = "oracle.step.univl_stage2 (stage1 + stage2 cross-encoder)"
+    else:   # the oracle restates stage 3 without TPM-CL (l3_partial_type -1): the towers dominate the CPU time either way
+        one = clip_leg(pairs, w["n_clips"], w["seq"], "stage1")
+        what = "oracle.step.univl_stage1 on 12 frames x 30 words (towers + MIL-NCE; the stage-3 head is < 1 % of the CPU time)"
+    ts = _time_passes(one, warm=1, timed=2)
+    q.put(dict(value=round(pairs / (sum(ts) / len(ts)), 4), unit="pairs/s", cores=cores, kind="port",
+               sample=f"{what} forward + backward (no optimizer step), fp32, {pairs} video-text pairs, 1 warm-up + {len(ts)} timed passes "
+                      f"({', '.join(f'{t:.1f}' for t in ts)} s), {cores} threads"))
 
 
-def cpu_baseline(cfg, pairs, limit_s=300):
+def cpu_baseline(workload, pairs, limit_s=300):
     """Runs the CPU sample in a child process with a hard wall-clock limit so the bench line is always printed."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_cpu_baseline_worker, args=(cfg, pairs, q))
+    p = ctx.Process(target=_cpu_baseline_worker, args=(workload, pairs, q))
     p.start()
     p.join(limit_s)
     if p.is_alive():
         p.terminate()
         p.join()
         return dict(value=None, unit="pairs/s", cores=os.cpu_count() or 1, kind="port",
-                    sample=f"oracle.step.m2_itc on {pairs} pairs did not finish within the {limit_s} s bound on this host")
+                    sample=f"the oracle sample of {pairs} pairs did not finish within the {limit_s} s bound on this host")
     return q.get() if not q.empty() else None
+
+
+# ------------------------------------------------------------------------------------------------ trainer around the bench model
+def make_trainer(a, device, world):
+    """BaseTrainer with the bench's model / optimizer: its train_step is the timed unit."""
+    from antmmf.common.configuration import Configuration
+    from antmmf.hip.arena import HipAdamW
+    from antmmf.trainers.base_trainer import BaseTrainer
+
+    tp = {"trainer": "base_trainer", "device": "cuda", "log_interval": 10 ** 9, "max_iterations": 10 ** 9, "seed": 1234, "lr_scheduler": True,
+          "use_warmup": True, "warmup_iterations": 1000, "warmup_factor": 0.2, "clip_gradients": False}
+    if a.workload in M2_WORKLOADS:
+        from vlmo.config import default_config
+        from vlmo.modules.vlmo_module import VLMo
+
+        mcfg = default_config()
+        mcfg.update(M2_WORKLOADS[a.workload])
+
+        class BenchTrainer(BaseTrainer):
+            def load_model(self):
+                torch.manual_seed(1234)  # identical replicas on every rank
+                self.model = VLMo(mcfg).to(self.device).train()
+
+            def load_optimizer(self):
+                self.optimizer = HipAdamW([{"params": [p for p in self.model.parameters() if p.requires_grad]}], lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
+                self.arena = self.optimizer.arena
+
+        cfg = Configuration({"training_parameters": tp, "optimizer_attributes": {"type": "AdamW", "params": {"lr": 1e-4, "weight_decay": 0.05}},
+                             "model_attributes": {"m2_encoder": {}}})
+        return BenchTrainer(cfg)
+    w = VTP_WORKLOADS[a.workload]
+    sys.path.insert(0, os.path.join(PKG, "prj", w["prj"]))
+    import roi_univl  # noqa: F401  (registers `univl` + the encoders of the chosen project)
+
+    class VtpTrainer(BaseTrainer):
+        def load_model(self):
+            torch.manual_seed(1234)
+            super().load_model()   # build_model("univl") from the config: the registry path of prj/*_vtp
+
+    cfg = Configuration({"training_parameters": tp, "optimizer_attributes": {"type": "AdamW", "params": {"lr": 1e-4, "weight_decay": 0.05, "betas": [0.9, 0.98], "eps": 1e-6}},
+                         "model_attributes": {"univl": dict(w["model"])}})
+    return VtpTrainer(cfg)
 
 
 def main():
@@ -133,30 +304,27 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from antmmf.hip import _lib, functional, ops
-    from antmmf.hip.arena import HipAdamW
-    from vlmo.config import default_config
-    from vlmo.modules.vlmo_module import VLMo
 
     assert _lib.backend() == 1, "bench.py must run on the gfx950 library"
+    is_m2 = a.workload in M2_WORKLOADS
+    batch_size = a.batch if a.batch is not None else (1024 if is_m2 else VTP_WORKLOADS[a.workload]["default_batch"])
     # activation-memory policy: keep the 4d-wide normalised FFN activation when the device has the HBM for it
-    keep_ffn = (not a.recompute_ffn_norm) and torch.cuda.get_device_properties(device).total_memory >= 250 * 2 ** 30 and a.batch <= 1024
+    keep_ffn = is_m2 and (not a.recompute_ffn_norm) and torch.cuda.get_device_properties(device).total_memory >= 250 * 2 ** 30 and batch_size <= 1024
     functional.set_keep_ffn_norm(keep_ffn)
-    cfg = default_config()
-    cfg.update(WORKLOADS[a.workload])
-    torch.manual_seed(1234)  # identical replicas on every rank
-    model = VLMo(cfg).to(device).train()
-    opt = HipAdamW([{"params": [p for p in model.parameters() if p.requires_grad]}], lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
-    batch = synthetic_batch(cfg, a.batch, device, rank)
+    trainer = make_trainer(a, device, world)
+    trainer.load()
+    trainer.model.train()
+    batch = synthetic_m2_batch(M2_WORKLOADS[a.workload], batch_size, device, 1234 + rank) if is_m2 else synthetic_vtp_batch(a.workload, batch_size, device, 1234 + rank)
+    # every rank is really there: an RCCL all-reduce of ones
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
 
     def step():
-        out = model(batch)
-        loss = out["losses"]["itc_loss"] + out["losses"]["itc_vl_loss"]
-        loss.backward()
-        w = opt.arena.allreduce_grads()
-        opt.grad_scale = 1.0 / w
-        opt.step()
-        opt.zero_grad()
-        return loss
+        trainer.current_iteration += 1
+        return trainer.train_step(batch)
 
     loss0 = None
     for _ in range(a.warmup):
@@ -181,10 +349,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
+    meters = trainer.read_meters()
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
-        pairs_per_s = a.batch * world * a.steps / elapsed
+        pairs_per_s = batch_size * world * a.steps / elapsed
         gemm_ms = sum(t[0].elapsed_time(t[1]) for t in trace)
         gemm_flops = sum(t[2] for t in trace)
         # algorithmic bytes of a launch: both operands once + the output once (bf16; fp32 for the wgrad accumulators)
@@ -207,32 +376,40 @@ def main():
         # HBM-side traffic per GEMM launch: measured in separate rocprofv3 --pmc passes over this same command
         # (tools/gpu_traffic.sh) and committed under profiles/; null when no measurement matches the configuration
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{a.workload}_b{a.batch}.json")
+        tpath = os.path.join(ROOT, "profiles", f"gemm_traffic_{a.workload}_b{batch_size}.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = int(json.load(fh)["traffic_bytes_per_launch"])  # bytes per launch, like `achieved`
-        step_tflops = pairs_per_s / world * TRAIN_GFLOP_PER_PAIR[a.workload] / 1e3
+        gflop_pair = M2_TRAIN_GFLOP_PER_PAIR[a.workload] if is_m2 else vtp_train_gflop_per_pair(a.workload, batch_size * world, batch_size)
+        step_tflops = pairs_per_s / world * gflop_pair / 1e3
+        metric = {"l14": "image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192",
+                  "b16": "image-text pairs/sec/node, M2_Encoder ViT-B/16 ITC (BASELINE config 1; not the BASELINE metric)",
+                  "vtp8": "video-text pairs/sec/node, base_vtp univl clip-arch ViT-B/16 + BERT-base, 8 clips, stage1 + stage2 cross-encoder (BASELINE config 3; not the BASELINE metric)",
+                  "dmae12": "video-text pairs/sec/node, dmae_vtp univl, 12 frames x 30 words, stage1 + stage3 NegNCE + TPM-CL (BASELINE config 4; not the BASELINE metric)"}[a.workload]
+        workload = {"l14": "M2_Encoder ViT-L/14 (beit large, patch 14, 21+3 layers) ITC train step, 224x224x3 + 77 tokens",
+                    "b16": "M2_Encoder ViT-B/16 (beit base, 9+3 layers) ITC train step, 224x224x3 + 77 tokens",
+                    "vtp8": "univl (clip arch) video-text train step: 8 clips x 224x224x3 per video + 77 tokens, MIL-NCE over all clips + cross-encoder scores of every text x video pair",
+                    "dmae12": "univl (DMAE) video-text train step: 12 frames x 224x224x3 per video + 30 words, MIL-NCE + seqTransf / WTI / NegNCE / TPM-CL"}[a.workload]
         out = {
-            "metric": ("image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192" if a.workload == "l14"
-                       else "image-text pairs/sec/node, M2_Encoder ViT-B/16 ITC (secondary workload, not the BASELINE metric)"),
-            "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": metric, "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"M2_Encoder {'ViT-L/14 (beit large, patch 14, 21+3 layers)' if a.workload == 'l14' else 'ViT-B/16 (beit base, 9+3 layers)'} ITC train step, 224x224x3 + 77 tokens",
-                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "loss": round(final_loss, 5), "step_tflops_per_gpu": round(step_tflops, 1),
+            "config": {"workload": workload, "per_gpu_batch": batch_size, "global_batch": batch_size * world, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
+                       "step": "BaseTrainer.train_step (forward, device-side meters, backward, arena all-reduce, fused AdamW, LR schedule)",
+                       "loss": round(final_loss, 5), "meters": {k: round(v, 5) for k, v in meters.items()},
+                       "train_gflop_per_pair": round(gflop_pair, 1), "step_tflops_per_gpu": round(step_tflops, 1),
                        "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4),
                        "loss_step0": None if loss0 is None else round(loss0, 5), "keep_ffn_norm": keep_ffn,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM, all layouts)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_k64p_kernel / gemm_tn_k64_kernel (bf16 MFMA GEMM family, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gemm_traffic_*.json); algorithmic bytes per launch = 2(I R + J R + I J)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),
                          "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "avg_launch_algorithmic_bytes": int(gemm_bytes / n), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
                          "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0}},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_sample)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -410,6 +410,43 @@ def gen_vilbert_biattention():
     save("ops_vilbert_biattention.pt", d)
 
 
+def gen_m2_eval_recall():
+    """prj/M2_Encoder/eval_retrieval.py calu_recall + get_data (:16-127), executed from the reference file (its module-level nn4k imports are
+    cut off): random L2-normalised features with 3 captions per image, the printed recalls, and the ground-truth matrices of a small jsonl."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    from collections import defaultdict
+    import numpy as np
+
+    src = open(f"{L.REF}/prj/M2_Encoder/eval_retrieval.py").read()
+    body = src[src.index("def _preprocess_text"):src.index('if __name__ == "__main__":')]
+    ns = {"np": np, "torch": torch, "json": json, "defaultdict": defaultdict}
+    exec(body, ns)
+    n_img, cap = 40, 3
+    img = torch.nn.functional.normalize(W.data_tensor("m2eval.img", (n_img, 32)), dim=-1)
+    txt = torch.nn.functional.normalize(img.repeat_interleave(cap, 0) * 0.6 + W.data_tensor("m2eval.txt", (n_img * cap, 32)) * 0.25, dim=-1)
+    t2i_gt = np.zeros((n_img * cap, n_img)); i2t_gt = np.zeros((n_img, n_img * cap))
+    for i in range(n_img):
+        for c in range(cap):
+            t2i_gt[i * cap + c, i] = 1; i2t_gt[i, i * cap + c] = 1
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns["calu_recall"](txt.numpy(), img.numpy(), t2i_gt, i2t_gt)
+    lines = buf.getvalue().strip().splitlines()
+    vals = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in lines}
+    rows = [{"image": f"img{i}.jpg", "caption": [f"A \u201cCaption\u201d {i} {c}" for c in range(2)]} for i in range(5)]
+    with tempfile.NamedTemporaryFile("w", suffix=".jsonl", delete=False) as f:
+        for r in rows:
+            f.write(json.dumps(r, ensure_ascii=False) + "\n")
+    texts, images, t2i, i2t = ns["get_data"](f.name)
+    save("metric_m2_recall.pt", {"img": img, "txt": txt, "t2i_gt": torch.from_numpy(t2i_gt).float(), "i2t_gt": torch.from_numpy(i2t_gt).float(),
+                                 "t2i_topk": torch.tensor(vals["t2i_topk"]), "i2t_topk": torch.tensor(vals["i2t_topk"]), "MR": torch.tensor(vals["MR"][0]),
+                                 "jsonl": [json.dumps(r, ensure_ascii=False) for r in rows], "texts": texts, "images": images,
+                                 "data.t2i_gt": torch.from_numpy(t2i).float(), "data.i2t_gt": torch.from_numpy(i2t).float()})
+
+
 def gen_e2e_clip_stage2():
     vtp = L.load_vtp("base_vtp")
     d = {}
@@ -615,8 +652,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "vilbert_biattention", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
-    fns = dict(vilbert_biattention=gen_vilbert_biattention, temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_eval_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "vilbert_biattention", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    fns = dict(m2_eval_recall=gen_m2_eval_recall, vilbert_biattention=gen_vilbert_biattention, temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
                e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

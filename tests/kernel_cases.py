@@ -506,6 +506,33 @@ def case_retrieval_metrics(dev, golden):
     assert torch.equal(grr.gt_ranks(g["sq.sim"].to(dev)).cpu().long(), ref_rank)
 
 
+def case_m2_eval_retrieval(dev, golden, tmp_dir):
+    """prj/M2_Encoder/eval_retrieval.py on the device path vs the reference's calu_recall / get_data run (metric_m2_recall.pt): the printed recalls
+    (rounded to 0.1 as the reference prints them) and the ground-truth matrices built from a jsonl with curly quotes / upper case."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m2 = os.path.join(root, "ant-multi-modal-framework_amd", "prj", "M2_Encoder")
+    if m2 not in sys.path:
+        sys.path.insert(0, m2)
+    import eval_retrieval as er
+
+    g = golden("metric_m2_recall.pt")
+    out = er.calu_recall(g["txt"].to(dev), g["img"].to(dev), g["t2i_gt"], g["i2t_gt"], verbose=False)
+    for k, want in zip((1, 5, 10), g["t2i_topk"].tolist()):
+        assert abs(round(out[f"t2i_r@{k}"], 1) - want) < 0.051, (k, out, want)
+    for k, want in zip((1, 5, 10), g["i2t_topk"].tolist()):
+        assert abs(round(out[f"i2t_r@{k}"], 1) - want) < 0.051, (k, out, want)
+    assert abs(round(out["MR"], 1) - float(g["MR"])) < 0.051
+    path = os.path.join(tmp_dir, "pairs.jsonl")
+    with open(path, "w") as f:
+        f.write("\n".join(g["jsonl"]) + "\n")
+    texts, images, t2i, i2t = er.get_data(path)
+    assert texts == g["texts"] and images == g["images"]
+    assert torch.equal(t2i, g["data.t2i_gt"]) and torch.equal(i2t, g["data.i2t_gt"])
+
+
 # ------------------------------------------------------------------------------ dropout (counter-based masks)
 def dropout_keep_np(idx, seed, p):
     """numpy twin of csrc/common.h::dropout_hash / DROPOUT_KEEP."""

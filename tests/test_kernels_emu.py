@@ -171,6 +171,10 @@ def test_retrieval_metrics(ops, golden):
     kc.case_retrieval_metrics(DEV, golden)
 
 
+def test_m2_eval_retrieval(ops, golden, tmp_path):
+    kc.case_m2_eval_retrieval(DEV, golden, str(tmp_path))
+
+
 def test_dropout_masks(ops):
     kc.case_dropout(ops, DEV)
 
