@@ -99,7 +99,9 @@ class ParamArena:
         stream, under the rest of the backward pass.  `allreduce_grads()` launches what is left and waits.
         reduce_dtype=torch.bfloat16 sends buckets as bf16 (half the xGMI bytes; the sum of W bf16 values carries ~3 significant digits)."""
         self._ov = None
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        import os
+
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not os.environ.get("ANTMMF_FORCE_COLLECTIVES")):
             return False
         key = (bucket_bytes,)
         if getattr(self, "_bucket_key", None) != key:
@@ -160,7 +162,9 @@ class ParamArena:
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         world = dist.get_world_size(group)
-        if world == 1:
+        import os
+
+        if world == 1 and not os.environ.get("ANTMMF_FORCE_COLLECTIVES"):
             return 1
         if getattr(self, "_ov", None) is None:
             self.arm_overlap(group, bucket_bytes, reduce_dtype)

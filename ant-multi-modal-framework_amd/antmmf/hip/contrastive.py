@@ -31,6 +31,14 @@ def _world(group):
     return 1, 0
 
 
+def _single(w):
+    """world size 1 skips the collectives -- unless a process group exists and ANTMMF_FORCE_COLLECTIVES=1 (GPU test: the real RCCL entry
+    points with one rank, the driver's boxes have a single GPU)."""
+    import os
+
+    return w == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("ANTMMF_FORCE_COLLECTIVES"))
+
+
 def _assert_equal_batch(n_rows, device, group):
     """The sharded losses and the MoCo queue assume the same number of rows on every rank (row0 = rank * B, all_gather_into_tensor /
     reduce_scatter_tensor take equal shares; the reference instead exchanges sizes and pads on every call,
@@ -50,7 +58,7 @@ def _assert_equal_batch(n_rows, device, group):
 
 def _all_gather(t, group):
     w, _ = _world(group)
-    if w == 1:
+    if _single(w):
         return t
     _assert_equal_batch(t.shape[0], t.device, group)
     out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -60,7 +68,7 @@ def _all_gather(t, group):
 
 def _reduce_scatter_sum(full, group):
     w, _ = _world(group)
-    if w == 1:
+    if _single(w):
         return full
     out = torch.empty((full.shape[0] // w,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
     dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=group)
@@ -72,7 +80,7 @@ def _all_gather_packed(tensors, group):
     [B, sum of widths] buffer, gathered, and split again (xGMI collectives are latency- and per-link-bound: one message instead of
     one per embedding set -- image + text + the two VL heads of the M2 step, text + clips of the video step)."""
     w, _ = _world(group)
-    if w == 1:
+    if _single(w):
         return list(tensors)
     B = tensors[0].shape[0]
     flat = [t.reshape(B, -1) for t in tensors]
@@ -88,7 +96,7 @@ def _all_gather_packed(tensors, group):
 def _reduce_scatter_packed(fulls, group):
     """ONE reduce-scatter(sum) for several [B_g, ...] gradients (the inverse of _all_gather_packed)."""
     w, _ = _world(group)
-    if w == 1:
+    if _single(w):
         return list(fulls)
     Bg = fulls[0].shape[0]
     flat = [f.reshape(Bg, -1) for f in fulls]
@@ -150,7 +158,7 @@ class _MilNceSharded(torch.autograd.Function):
         if weight is not None:
             coef = coef * weight.float()
         loss = (loss_rows * coef).sum()
-        if world > 1:
+        if not _single(world):
             dist.all_reduce(loss, group=group)
         ctx.save_for_backward(text, centre, T_all, V_all, Rm, Cm, denom, coef)
         ctx.meta = (n_clips, row0, world, group, B, D)
@@ -191,7 +199,7 @@ class _ClipItcSharded(torch.autograd.Function):
         li, lse_i = ops.softmax_ce_fwd(xi, row0, ls)
         lt, lse_t = ops.softmax_ce_fwd(xt, row0, ls)
         loss = (li.sum() + lt.sum()) * (0.5 / Bg)
-        if world > 1:
+        if not _single(world):
             dist.all_reduce(loss, group=group)
         ctx.save_for_backward(img, txt, I_all, T_all, xi, xt, lse_i, lse_t, ls)
         ctx.meta = (row0, world, group, B, Bg)
@@ -242,7 +250,7 @@ class _ClipItcPairSharded(torch.autograd.Function):
             losses.append((li.sum() + lt.sum()) * (0.5 / Bg))
             saved += [im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls]
         loss = torch.stack(losses)
-        if world > 1:
+        if not _single(world):
             dist.all_reduce(loss, group=group)
         ctx.save_for_backward(*saved)
         ctx.meta = (row0, world, group, B, Bg)

@@ -158,3 +158,51 @@ def test_m2_full_width_step_properties():
     opt.zero_grad()
     l1 = run()
     assert float(l1) < float(l0), (float(l0), float(l1))
+
+
+def test_rccl_entry_points_one_rank():
+    """SURVEY 8a C1 / 8e on the hardware the driver has (one GPU per box): the step's collectives through the REAL RCCL entry points with a
+    one-rank process group (backend "nccl" = RCCL; ANTMMF_FORCE_COLLECTIVES=1 keeps the world-1 shortcuts off): the packed all-gather /
+    reduce-scatter of the sharded losses, the device-side equal-batch assert, the loss all-reduce, and the flat-arena gradient all-reduce
+    started from inside backward (fp32 and bf16 buckets) -- the tiny M2 step must equal the run without a process group."""
+    code = r"""
+import os, sys, torch
+ROOT = %r
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "ant-multi-modal-framework_amd"),
+                os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "M2_Encoder"), ROOT]
+import torch.distributed as dist
+import model_cases as mc
+import weightgen as W
+from antmmf.hip.arena import HipAdamW
+dev = torch.device("cuda:0")
+def run(use_pg, dtype=None):
+    model = mc.build_tiny_m2(dev)
+    opt = HipAdamW([{"params": list(model.parameters())}], lr=1e-2, weight_decay=0.01)
+    img = (W.data_tensor("m2dp.image", (4, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1).to(dev)
+    ids = W.data_ints("m2dp.ids", (4, 12), 1, 300).to(dev)
+    mask = torch.ones(4, 12, dtype=torch.long, device=dev)
+    armed = opt.arena.arm_overlap(bucket_bytes=64 << 10, reduce_dtype=dtype) if use_pg else False
+    out = model({"image": [img], "text_ids": ids, "text_masks": mask})
+    loss = out["losses"]["itc_loss"] + out["losses"]["itc_vl_loss"]
+    loss.backward()
+    w = opt.arena.allreduce_grads()
+    opt.grad_scale = 1.0 / w
+    opt.step()
+    return float(loss), opt.arena.master.clone(), armed, getattr(opt.arena, "overlapped_buckets", 0)
+l0, m0, _, _ = run(False)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29688", ANTMMF_FORCE_COLLECTIVES="1")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+l1, m1, armed, early = run(True)
+l2, m2, _, _ = run(True, torch.bfloat16)
+torch.cuda.synchronize()
+dist.destroy_process_group()
+assert armed and early >= 1, (armed, early)
+assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.equal(m0, m1), (l0, l1, float((m0 - m1).abs().max()))
+torch.testing.assert_close(m2, m0, rtol=1e-2, atol=1e-3)
+print("okrccl", l0, l1, early)
+""" % (mc.ROOT,)
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ))
+    assert "okrccl" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
