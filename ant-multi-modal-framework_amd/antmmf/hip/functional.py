@@ -103,13 +103,9 @@ class GradSink:
         return self._fresh.get(id(p))
 
 
-def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False, bias=None):
-    """dW += dy^T x  (W stored [out, in]);  for W stored [in, out] (CLIP `proj`) dW += x^T dy.
-    bias: the Linear's bias parameter -- its gradient (column sums of dy) is taken inside the same wgrad launch."""
-    fuse_b = bias is not None and bias.requires_grad and not w_is_in_out
+def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
+    """dW += dy^T x  (W stored [out, in]);  for W stored [in, out] (CLIP `proj`) dW += x^T dy."""
     if W is None or not W.requires_grad:
-        if fuse_b:
-            _bgrad(sink, bias, dy2d)
         return
     out = sink.buf(W)
     tiles = ((out.shape[0] + 127) // 128) * ((out.shape[1] + 127) // 128)
@@ -120,7 +116,7 @@ def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False, bias=None):
     if w_is_in_out:
         ops.gemm_wgrad_(out, x2d, dy2d, split)
     else:
-        ops.gemm_wgrad_(out, dy2d, x2d, split, db=sink.buf(bias) if fuse_b else None)
+        ops.gemm_wgrad_(out, dy2d, x2d, split)
 
 
 def _bgrad(sink, b, dy2d):
@@ -412,7 +408,8 @@ class _TransformerLayer(torch.autograd.Function):
             g_n = ops.act_fwd(u, spec.act)
         # hidden dropout: the dense output's gradient is the masked / rescaled ds2; the residual branch keeps ds2 itself
         dy_w2 = ops.dropout_add(ds2.contiguous(), p_hid, seed + 2) if p_hid > 0 else ds2
-        _wgrad(sink, P["w2"], dy_w2, g_n, bias=P["b2"])
+        _wgrad(sink, P["w2"], dy_w2, g_n)
+        _bgrad(sink, P["b2"], dy_w2)
         del g_n
         if spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
@@ -426,7 +423,9 @@ class _TransformerLayer(torch.autograd.Function):
             du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act)  # (d(dense out) W2) * act'(u)
         ln_mid = ("ln2" if pre_ln else "ln1")
         h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
-        _wgrad(sink, P["w1"], du, h2, bias=None if b1_fused else P["b1"])
+        _wgrad(sink, P["w1"], du, h2)
+        if not b1_fused:
+            _bgrad(sink, P["b1"], du)
         del h2
         dgw, dgb = lnw(ln_mid)
         bo_fused = P["bo"] is not None and P["bo"].requires_grad and p_hid == 0  # out-projection bias gradient = column sums of dmid
@@ -446,7 +445,9 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             o_n = o2
         dy_wo = ops.dropout_add(dmid.contiguous(), p_hid, seed + 1) if p_hid > 0 else dmid
-        _wgrad(sink, P["wo"], dy_wo, o_n, bias=None if bo_fused else P["bo"])
+        _wgrad(sink, P["wo"], dy_wo, o_n)
+        if not bo_fused:
+            _bgrad(sink, P["bo"], dy_wo)
         del o_n
         do = dgrad(dy_wo, P["wo"])
         if spec.kind == "m2":
@@ -463,11 +464,13 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             h = x2
         if spec.packed_qkv:
-            _wgrad(sink, P["wqkv"], dqkv2, h, bias=P["bqkv"])
+            _wgrad(sink, P["wqkv"], dqkv2, h)
+            _bgrad(sink, P["bqkv"], dqkv2)
         else:
             for i, nm in enumerate("qkv"):
                 sl = dqkv2[:, i * d:(i + 1) * d]
-                _wgrad(sink, P["w" + nm], sl, h, bias=P["b" + nm])
+                _wgrad(sink, P["w" + nm], sl, h)
+                _bgrad(sink, P["b" + nm], sl)
         del h
         dx = None
         if ctx.needs_input_grad[0]:

@@ -284,15 +284,10 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
 _WGRAD_WS = {}
 
 
-def gemm_wgrad_(dW, dY, X, split_k_hint=1, db=None):
+def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     """dW[n_out, k_in] += dY[tokens, n_out]^T X[tokens, k_in]   (fp32 accumulate in place; bf16 token-major operands,
-    row-strided views allowed).  A per-device fp32 workspace for the token-split partial sums is kept and reused.
-    db (fp32 [n_out], optional): the bias gradient of the same Linear, db += column sums of dY, taken inside the wgrad kernel."""
-    _dev_ok(dW, dY, X, db); _f32(dW, "dW")
-    if db is not None:
-        _f32(db, "db"); _c(db, "db")
-        if db.numel() != dY.shape[1]:
-            raise ValueError("gemm_wgrad_: db must have n_out elements")
+    row-strided views allowed).  A per-device fp32 workspace for the token-split partial sums is kept and reused."""
+    _dev_ok(dW, dY, X); _f32(dW, "dW")
     for t, n in ((dY, "dY"), (X, "X")):
         if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
             raise ValueError(f"gemm_wgrad_: {n} must be a 2-D bf16 tensor with unit inner stride")
@@ -310,12 +305,8 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1, db=None):
     if GEMM_TRACE is not None and _lib.backend() == 1:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if db is not None:
-        _rc(_lib.load().antmmf_gemm_wgrad_bias_bf16(_p(dY), _p(X), _p(dW), _p(db), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
-                                                    int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bias_bf16")
-    else:
-        _rc(_lib.load().antmmf_gemm_wgrad_bf16(_p(dY), _p(X), _p(dW), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
-                                               int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
+    _rc(_lib.load().antmmf_gemm_wgrad_bf16(_p(dY), _p(X), _p(dW), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
+                                           int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
     if ev is not None:
         ev[1].record()
         GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_out * k_in, "tn", (n_out, k_in, tokens, "wgrad")))

@@ -45,7 +45,6 @@ struct GemmArgs {
     int act, c_dtype, accumulate, ksteps_per_split;
     float alpha;
     float* ws;   // split-K workspace [splits][I][J] fp32 (wgrad ring; NULL -> atomics)
-    float* bias_grad;  // wgrad k64 kernel: bias_grad[i] += sum over tokens of dY[token][i] (column sums of the P operand; nullable)
     int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
 };
 
@@ -1549,12 +1548,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
     const bool late = wave >= 4;
     uint32_t so = 0;
     bool first = true;   // first K-tile: K-tile 1 is complete, the refills that target it are skipped
-    // bias gradient of the Linear whose weight gradient this is: column sums of dY = sums over the tokens of the P fragments, which the
-    // waves with wj == 0 of the j0 == 0 tiles hold anyway (lane (l15, grp): output row 16 f' + l15, tokens 8 grp .. + 7 of each 32-token half)
-    const bool do_bias = g.bias_grad != nullptr && j0 == 0 && wj == 0;
-    float csum[TI];
-#pragma unroll
-    for (int a = 0; a < TI; ++a) csum[a] = 0.f;
     // WT: 0 steady, 1 = K-tile nk - 2, 2 = K-tile nk - 1
 #define TK_PIECES(PH, WT)                                                                                                           \
     do {                                                                                                                            \
@@ -1591,13 +1584,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
                 acc[4 * (PH & 1) + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[f], acc[4 * (PH & 1) + f][jt], 0, 0, 0); \
         if (PRIO) K64_SETPRIO(0);                                                                                                   \
         SCHED_FENCE();                                                                                                              \
-        if (do_bias) {  /* VALU work in the shadow of the MFMAs just issued */                                                      \
-            _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                                         \
-                float s_ = 0.f;                                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) s_ += bf2f((bf16_t)pb[f][e]);                                         \
-                csum[4 * (PH & 1) + f] += s_;                                                                                       \
-            }                                                                                                                       \
-        }                                                                                                                           \
         if (late) { TK_WAIT(PH, WT); K64_BARRIER(); }                                                                               \
     } while (0)
 #define TK_TILE(WT) do { TK_PHASE(0, WT); TK_PHASE(1, WT); TK_PHASE(2, WT); TK_PHASE(3, WT); so ^= STAGE; } while (0)
@@ -1610,15 +1596,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
 #undef TK_PHASE
 #undef TK_WAIT
 #undef TK_PIECES
-    if (do_bias) {  // sum the four token groups (lanes l15 + 16 grp), one atomic per output row and split
-#pragma unroll
-        for (int a = 0; a < TI; ++a) {
-            float v = csum[a];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (grp == 0) atomicAdd(g.bias_grad + i0 + wi * 128 + a * 16 + l15, v);
-        }
-    }
     wg_barrier_lds_only();  // every wave is past its last MFMA block and nothing is in flight: the stages are free
     if (g.ws) {
         store_partial_f32_staged<TI, TJ>(g.ws + (long)split * g.I * g.J + (long)i0 * g.J + j0, g.J, acc, wi, wj, lane, smem + wave * 16384);
@@ -1638,9 +1615,7 @@ extern "C" long antmmf_debug_gemm_k64_launches() { return g_k64_launches; }
 static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                      int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                      const void* residual, long ldr, void* aux, long ldaux, const void* gate, long ldgate,
-                     int accumulate, int split_k, float* workspace, long workspace_bytes, hipStream_t stream, float* bias_grad = nullptr,
-                     int* bias_done = nullptr) {
-    if (bias_done) *bias_done = 0;
+                     int accumulate, int split_k, float* workspace, long workspace_bytes, hipStream_t stream) {
     if (!P || !Q || !C || I < 0 || J < 0 || R <= 0) return ANTMMF_EINVAL;
     if (I == 0 || J == 0) return ANTMMF_OK;
     if ((J & 3) || (ldc & 3)) return ANTMMF_EINVAL;
@@ -1661,7 +1636,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.C = C; g.bias = bias; g.residual = (const bf16_t*)residual;
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
-    g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha; g.ws = nullptr; g.bias_grad = bias_grad;
+    g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha; g.ws = nullptr;
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
     static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");
     g.raster = raster_env ? atoi(raster_env) : 1;
@@ -1779,7 +1754,6 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             static bool once64 = false;
             if (!once64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_k64_kernel<K64F_PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once64 = true; }
             ++g_k64_launches;
-            if (bias_done && bias_grad) *bias_done = 1;   // the kernel adds the column sums of dY into bias_grad
             hipLaunchKernelGGL(gemm_tn_k64_kernel<K64F_PRIO>, dim3((unsigned)(tiles * k64_zs)), dim3(512), 131072, stream, g);
             if (ws64) {
                 const long nvec = (long)I * J / 4;
@@ -1811,19 +1785,6 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
 
 // dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in]  (fp32 accumulate), with a caller-owned fp32 workspace for the token-split
 // partial sums (the kernel picks the split; workspace_bytes >= 32 * n_out * k_in * 4 always suffices; NULL -> fp32 atomics).
-// wgrad + the bias gradient of the same Linear: db[n_out] += column sums of dY.  Folded into the BK = 64 wgrad kernel when that kernel runs (its
-// workgroups already hold dY's fragments); otherwise the column-sum kernel is launched behind the GEMM.  Replaces the separate HBM pass over dY.
-extern "C" int antmmf_colsum(const void* x, float* out, long rows, int cols, long ld, int dtype, hipStream_t s);
-extern "C" int antmmf_gemm_wgrad_bias_bf16(const void* dY, const void* X, float* dW, float* db, long tokens, int n_out, int k_in, long ld_dy, long ld_x,
-                                           long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
-    if (tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;
-    int done = 0;
-    const int rc = gemm_impl(dY, X, dW, n_out, k_in, (int)tokens, ld_dy, ld_x, ld_dw, 1, 1, ANTMMF_F32, 1.0f, nullptr, ANTMMF_ACT_NONE, nullptr, 0, nullptr, 0,
-                             nullptr, 0, 1, split_k_hint, workspace, workspace_bytes, stream, db, &done);
-    if (rc != ANTMMF_OK || !db || done) return rc;
-    return antmmf_colsum(dY, db, tokens, n_out, ld_dy, ANTMMF_BF16, stream);
-}
-
 extern "C" int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, long tokens, int n_out, int k_in, long ld_dy, long ld_x,
                                       long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
     if (tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;

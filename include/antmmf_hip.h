@@ -141,12 +141,6 @@ int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tok
                            int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes,
                            antmmf_stream_t stream);
 
-/* ---- the same wgrad plus the bias gradient of that Linear: db[n_out] += sum over tokens of dY (nullable).  The column sums are taken inside the
- * wgrad kernel from the dY fragments it already holds (no separate pass over dY); small / unaligned problems run antmmf_colsum behind the GEMM. */
-int antmmf_gemm_wgrad_bias_bf16(const void* dY, const void* X, float* dW, float* db, int64_t tokens, int n_out, int k_in,
-                                int64_t ld_dy, int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace,
-                                int64_t workspace_bytes, antmmf_stream_t stream);
-
 /* ---- fused multi-head attention, head_dim = 64, bf16, Nk <= 288 (whole key row in LDS):
  *   O[b,q,h,:] = softmax_k( scale * <Q[b,q,h,:], K[b,k,h,:]> + key_bias[b,k] ) V[b,k,h,:]
  * element (b, n, h, e) of Q lives at q + (b*Nq + n)*ldq + h*64 + e (K, V with Nk / ldk / ldv; O with ldo), so a packed
