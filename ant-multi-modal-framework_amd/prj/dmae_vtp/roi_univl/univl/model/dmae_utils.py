@@ -259,9 +259,11 @@ class DmaeUtils(nn.Module):
         return simi, margin_loss
 
     # ------------------------------------------------------------------ TPM-CL (reference :280-523)
-    def wti_interaction_row(self, text_feat, video_feat, text_mask, video_mask):
+    def wti_interaction_row(self, text_feat, video_feat, text_mask, video_mask, nblocks=1):
         """One score per ALIGNED pair c (text_feat[c] vs video_feat[c]).  As in the reference, the token weights are contracted with
-        'ct,bt->c' / 'cv,bv->c': the per-token maxima of every pair are weighted by the softmax weights SUMMED over the pair batch."""
+        'ct,bt->c' / 'cv,bv->c': the per-token maxima of every pair are weighted by the softmax weights SUMMED over the pair batch
+        -- the pair batch being one 8 x 16 caption x video block: with `nblocks` > 1 the leading dimension holds that many blocks back
+        to back and the sums stay inside each block."""
         text_feat, video_feat = text_feat.float(), video_feat.float()
         text_mask, video_mask = text_mask.float(), video_mask.float()
         if video_mask.shape[1] > video_feat.shape[1]:
@@ -275,13 +277,18 @@ class DmaeUtils(nn.Module):
         if "wti" in self.interaction:
             tw = self._masked_softmax(self.text_weight_fc, text_feat, text_mask)
             vw = self._masked_softmax(self.video_weight_fc, video_feat, video_mask)
+            if nblocks > 1:
+                per = tw.shape[0] // nblocks
+                tws = tw.view(nblocks, per, -1).sum(1).repeat_interleave(per, 0)
+                vws = vw.view(nblocks, per, -1).sum(1).repeat_interleave(per, 0)
+                return ((t2v * tws).sum(1) + (v2t * vws).sum(1)) / 2.0
             return ((t2v * tw.sum(0)).sum(1) + (v2t * vw.sum(0)).sum(1)) / 2.0
         return (t2v.sum(1) / text_mask.sum(-1) + v2t.sum(1) / video_mask.sum(-1)) / 2.0
 
-    def _loose_similarity_row(self, sequence_output, visual_output, attention_mask, video_mask, sim_header="meanP"):
+    def _loose_similarity_row(self, sequence_output, visual_output, attention_mask, video_mask, sim_header="meanP", nblocks=1):
         if "ti" not in self.interaction:
             raise NotImplementedError(f"interaction:{self.interaction} not implemented")
-        return self.wti_interaction_row(sequence_output.contiguous(), visual_output.contiguous(), attention_mask, video_mask)
+        return self.wti_interaction_row(sequence_output.contiguous(), visual_output.contiguous(), attention_mask, video_mask, nblocks)
 
     def _get_partial_output(self, sequence_output, visual_output, attention_mask, video_mask, xwp_type="linear", partial_type=-1):
         """The five [bt, bv] score matrices of one caption x video block that the margin losses use (full vs importance-masked tokens,
@@ -313,6 +320,46 @@ class DmaeUtils(nn.Module):
             out["tgh2vh"] = row(glob_partial, vis_i, wmask_i, vmask_i).reshape(bt, bv)
         return out
 
+    def _get_partial_output_blocks(self, sequence_output, visual_output, attention_mask, video_mask, bt=8, bv=16, partial_type=4):
+        """ALL 8 x 16 caption x video blocks of _get_partial_output in one batched pass (the reference walks them in a Python double loop to bound
+        its memory; on 288 GB the B_t x B_v pairs of a step fit at once): every per-pair operator is evaluated over the concatenation of the
+        blocks' pair batches -- pair orderings inside a block as in the reference ("_i" caption-major, "_j" video-major) -- and the one
+        operator that couples the pairs of a block (the token-weight sums of wti_interaction_row) keeps its sums inside the blocks.
+        Returns the five [B_t, B_v] matrices.  Requires B_t % bt == 0 and B_v % bv == 0 (the loop handles ragged edges)."""
+        sent, words = sequence_output
+        Bt, Bv = sent.shape[0], visual_output.shape[0]
+        nbt, nbv = Bt // bt, Bv // bv
+        nb, dev = nbt * nbv, sent.device
+        a = torch.arange(nbt, device=dev).repeat_interleave(nbv)            # caption-block index of block n
+        b = torch.arange(nbv, device=dev).repeat(nbt)                       # video-block index of block n
+        i_i, j_i = torch.arange(bt, device=dev).repeat_interleave(bv), torch.arange(bv, device=dev).repeat(bt)      # p = i bv + j
+        j_j, i_j = torch.arange(bv, device=dev).repeat_interleave(bt), torch.arange(bt, device=dev).repeat(bv)      # p = j bt + i
+        t_i = (a[:, None] * bt + i_i[None, :]).reshape(-1)
+        v_i = (b[:, None] * bv + j_i[None, :]).reshape(-1)
+        t_j = (a[:, None] * bt + i_j[None, :]).reshape(-1)
+        v_j = (b[:, None] * bv + j_j[None, :]).reshape(-1)
+        sent_j, wmask_j = sent[t_j], attention_mask[t_j]
+        words_i, wmask_i = words[t_i], attention_mask[t_i]
+        vis_i, vmask_i = visual_output[v_i], video_mask[v_i]
+        vis_j, vmask_j = visual_output[v_j], video_mask[v_j]
+        word_w = self.v2t_linear_xwp(vis_i, words_i)
+        frame_w = self.t2v_linear_xwp(sent_j, vis_j)
+        glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)
+        glob = (glob / glob.norm(dim=-1, keepdim=True)).unsqueeze(1)
+        words_masked, _ = self.tis_selector(words_i.float(), word_w)
+        glob_partial = torch.einsum("abd,ab->ad", words_masked, word_w).unsqueeze(1)
+        vis_masked, _ = self.tis_selector(vis_j.float(), frame_w)
+        vis_partial, vmask_p, _ = self._agg_visual_feat(vis_masked, vmask_j, sim_header=self.sim_header)
+        row = lambda x, y, mx, my: self._loose_similarity_row(x, y, mx, my, sim_header=self.sim_header, nblocks=nb)  # noqa: E731
+
+        def grid(x, video_major):   # [nb * bt * bv] scores -> [B_t, B_v]
+            blk = x.view(nb, bv, bt).transpose(1, 2) if video_major else x.view(nb, bt, bv)
+            return blk.reshape(nbt, nbv, bt, bv).permute(0, 2, 1, 3).reshape(Bt, Bv)
+
+        return {"t2vhh": grid(row(sent_j, vis_partial, wmask_j, vmask_p), True), "t2vh": grid(row(sent_j, vis_i, wmask_j, vmask_i), False),
+                "tg2vh": grid(row(glob, vis_i, wmask_i, vmask_i), False), "tg2vhh": grid(row(glob, vis_partial, wmask_i, vmask_p), True),
+                "tgh2vh": grid(row(glob_partial, vis_i, wmask_i, vmask_i), False)}
+
     def _get_partial_loss(self, sim_matrix, sim_matrix_bar):
         """MarginRankingLoss(margin)(diag(anchor), diag(partial), +1): the full-token score of a true pair must beat its
         importance-masked score by the margin."""
@@ -325,6 +372,9 @@ class DmaeUtils(nn.Module):
         if not (self.training and partial_type >= 2):
             return 0.0
         names = ("t2vh", "t2vhh", "tg2vh", "tg2vhh", "tgh2vh")
+        if sent.shape[0] % 8 == 0 and visual_output.shape[0] % 16 == 0 and sent.shape[0] * visual_output.shape[0] > 128 and not self.config.get("l3_partial_loop", False):
+            M = self._get_partial_output_blocks(sequence_output, visual_output, attention_mask, video_mask, 8, 16, partial_type)
+            return self._partial_losses(M, partial_type)
         rows = {n: [] for n in names}
         for t0 in range(0, sent.shape[0], 8):          # the reference's block sizes: 8 captions x 16 videos
             cols = {n: [] for n in names}
@@ -337,6 +387,9 @@ class DmaeUtils(nn.Module):
             for n in names:
                 rows[n].append(torch.cat(cols[n], dim=-1))
         M = {n: torch.cat(rows[n], dim=0) for n in names}
+        return self._partial_losses(M, partial_type)
+
+    def _partial_losses(self, M, partial_type):
         if get_world_size() > 1:
             M = {n: gather_tensor(m.contiguous(), method="cat", back_gradient=True, pad_tensors=True) for n, m in M.items()}
         loss = 0.0

@@ -57,7 +57,7 @@ CLIP_B16 = dict(image_encoder=dict(type="VitImageEncoder", params=dict(model_nam
                                                                         num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=512,
                                                                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=768, is_proj=True)))
 VTP_WORKLOADS = {
-    "vtp8": dict(prj="base_vtp", n_clips=8, seq=77, default_batch=128,
+    "vtp8": dict(prj="base_vtp", n_clips=8, seq=77, default_batch=64,
                  model=dict(training_head_type="video_text_retrieval", arch_type="clip", training_stage="stage1+stage2", with_moco=False,
                             with_cross_encoder=True, hidden_size=768, **CLIP_B16)),
     "dmae12": dict(prj="dmae_vtp", n_clips=12, seq=30, default_batch=128,
@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="l14", choices=sorted(list(M2_WORKLOADS) + list(VTP_WORKLOADS)))
-    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for the M2 workloads, 128 videos for vtp8 / dmae12)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for the M2 workloads, 64 / 128 videos for vtp8 / dmae12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recompute-ffn-norm", action="store_true", help="do not keep ffn_layernorm(gelu(u)) for backward (saves ~65 GiB at 1024 pairs/GPU, costs ~3 %%)")
     ap.add_argument("--gemm-table", default=None, help="write per-shape GEMM timing (from the live HIP-event trace) to this file")

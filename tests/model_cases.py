@@ -536,6 +536,42 @@ def case_dmae_tpmcl(dev, golden):
     return res
 
 
+def case_dmae_tpmcl_blocks(dev, sim_header="meanP"):
+    """TPM-CL over SEVERAL 8 x 16 caption x video blocks: the batched evaluation of all blocks at once (product path at bench sizes) equals
+    the reference-shaped Python double loop over the blocks (`l3_partial_loop`; the loop form is what ops_dmae_tpmcl.pt pins on one block):
+    loss, input gradients, parameter gradients."""
+    from antmmf.common.configuration import Configuration
+
+    mod = load_dmae_utils()
+    Bt, Bv, Nw, V, D = 16, 32, 12, 4, 128
+    out = {}
+    for loop in (True, False):
+        du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header=sim_header, l3_partial_type=4,
+                                              l3_max_frames=V, l3_max_words=Nw, l3_partial_loop=loop)))
+        W.fill_module_(du)
+        du.tis_selector.thresh.fill_(0.6)
+        du = du.to(dev).train()
+        norm = lambda x: x / x.norm(dim=-1, keepdim=True)  # noqa: E731
+        t = norm(W.data_tensor("tpmb.text", (Bt, 1, D))).to(dev).requires_grad_(True)
+        w_ = norm(W.data_tensor("tpmb.word", (Bt, Nw, D))).to(dev).requires_grad_(True)
+        v = norm(W.data_tensor("tpmb.video", (Bv, V + 1, D))).to(dev).requires_grad_(True)
+        wm = torch.ones(Bt, Nw, device=dev)
+        wm[3, 7:] = 0
+        wm[10, 4:] = 0
+        vm = torch.ones(Bv, V + 1, device=dev)
+        loss = du.get_partial_similarity((t, w_), v, wm, vm, 4)
+        loss.backward()
+        out[loop] = (float(loss), t.grad.clone(), w_.grad.clone(), v.grad.clone(), {n: p.grad.clone() for n, p in du.named_parameters() if p.grad is not None})
+    (l0, dt0, dw0, dv0, g0), (l1, dt1, dw1, dv1, g1) = out[True], out[False]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    for nm, a, b in (("dtext", dt0, dt1), ("dword", dw0, dw1), ("dvideo", dv0, dv1)):
+        torch.testing.assert_close(b, a, rtol=2e-3, atol=1e-6 + 2e-3 * float(a.abs().max()), msg=nm)
+    assert set(g0) == set(g1)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=5e-3, atol=1e-6 + 5e-3 * float(g0[n].abs().max()), msg=n)
+    return dict(loss=(l0, l1), params=len(g0))
+
+
 def case_dmae_wti(dev, golden):
     """DmaeUtils.wti_interaction on the HIP path (split GEMM + fused reduction kernel) vs the reference run: wti / att_wti, with and
     without the second-best-frame term, forward + gradients of the features and of the weight heads."""

@@ -95,6 +95,10 @@ def test_dmae_tpmcl_vs_reference(golden):
     print(mc.case_dmae_tpmcl(torch.device("cpu"), golden))
 
 
+def test_dmae_tpmcl_batched_blocks_equal_block_loop():
+    print(mc.case_dmae_tpmcl_blocks(torch.device("cpu")))
+
+
 def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(torch.device("cpu"), golden))
 

@@ -71,6 +71,10 @@ def test_dmae_tpmcl_vs_reference(golden):
     print(mc.case_dmae_tpmcl(DEV, golden))
 
 
+def test_dmae_tpmcl_batched_blocks_equal_block_loop():
+    print(mc.case_dmae_tpmcl_blocks(DEV))
+
+
 def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(DEV, golden))
 
@@ -197,7 +201,9 @@ l2, m2, _, _ = run(True, torch.bfloat16)
 torch.cuda.synchronize()
 dist.destroy_process_group()
 assert armed and early >= 1, (armed, early)
-assert abs(l0 - l1) <= 1e-6 * abs(l0) and torch.equal(m0, m1), (l0, l1, float((m0 - m1).abs().max()))
+# (not bit-equal run to run: the embedding-table gradient is a scatter of fp32 atomics)
+assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+torch.testing.assert_close(m1, m0, rtol=1e-4, atol=5e-5)
 torch.testing.assert_close(m2, m0, rtol=1e-2, atol=1e-3)
 print("okrccl", l0, l1, early)
 """ % (mc.ROOT,)
