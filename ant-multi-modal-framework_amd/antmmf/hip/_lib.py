@@ -93,8 +93,13 @@ def load():
             raise HipLibraryError(f"{path} does not export {name}") from e
         fn.argtypes = args
         fn.restype = c_int
+    be = lib.antmmf_backend()
+    if be == 0 and not (os.environ.get("PYTEST_CURRENT_TEST") or os.environ.get("ANTMMF_ALLOW_EMULATOR")):
+        # the CPU lane emulator is test infrastructure: the product path never runs on it (ANTMMF_HIP_LIB could point it there)
+        raise HipLibraryError(f"{path} is the CPU lane EMULATOR build of the kernels (tests/emu); it is only accepted under pytest "
+                              f"(or with ANTMMF_ALLOW_EMULATOR=1 for debugging). The product path needs the gfx950 library.")
     _lib = lib
-    _backend = lib.antmmf_backend()
+    _backend = be
     return lib
 
 

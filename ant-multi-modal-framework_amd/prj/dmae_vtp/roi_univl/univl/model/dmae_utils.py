@@ -330,18 +330,22 @@ class DmaeUtils(nn.Module):
         Bt, Bv = sent.shape[0], visual_output.shape[0]
         nbt, nbv = Bt // bt, Bv // bv
         nb, dev = nbt * nbv, sent.device
-        a = torch.arange(nbt, device=dev).repeat_interleave(nbv)            # caption-block index of block n
-        b = torch.arange(nbv, device=dev).repeat(nbt)                       # video-block index of block n
-        i_i, j_i = torch.arange(bt, device=dev).repeat_interleave(bv), torch.arange(bv, device=dev).repeat(bt)      # p = i bv + j
-        j_j, i_j = torch.arange(bv, device=dev).repeat_interleave(bt), torch.arange(bt, device=dev).repeat(bv)      # p = j bt + i
-        t_i = (a[:, None] * bt + i_i[None, :]).reshape(-1)
-        v_i = (b[:, None] * bv + j_i[None, :]).reshape(-1)
-        t_j = (a[:, None] * bt + i_j[None, :]).reshape(-1)
-        v_j = (b[:, None] * bv + j_j[None, :]).reshape(-1)
-        sent_j, wmask_j = sent[t_j], attention_mask[t_j]
-        words_i, wmask_i = words[t_i], attention_mask[t_i]
-        vis_i, vmask_i = visual_output[v_i], video_mask[v_i]
-        vis_j, vmask_j = visual_output[v_j], video_mask[v_j]
+        # pair batches as broadcast views (backward = a reduction over the broadcast axes, no index_put): block n = a nbv + b covers captions
+        # a bt + i and videos b bv + j; caption-major pairs [a, b, i, j], video-major pairs [a, b, j, i]
+        def cap(x, video_major):
+            x = x.reshape(nbt, 1, 1, bt, *x.shape[1:]) if video_major else x.reshape(nbt, 1, bt, 1, *x.shape[1:])
+            full = (nbt, nbv, bv, bt) if video_major else (nbt, nbv, bt, bv)
+            return x.expand(*full, *x.shape[4:]).reshape(nb * bt * bv, *x.shape[4:])
+
+        def vid(x, video_major):
+            x = x.reshape(1, nbv, bv, 1, *x.shape[1:]) if video_major else x.reshape(1, nbv, 1, bv, *x.shape[1:])
+            full = (nbt, nbv, bv, bt) if video_major else (nbt, nbv, bt, bv)
+            return x.expand(*full, *x.shape[4:]).reshape(nb * bt * bv, *x.shape[4:])
+
+        sent_j, wmask_j = cap(sent, True), cap(attention_mask, True)
+        words_i, wmask_i = cap(words, False), cap(attention_mask, False)
+        vis_i, vmask_i = vid(visual_output, False), vid(video_mask, False)
+        vis_j, vmask_j = vid(visual_output, True), vid(video_mask, True)
         word_w = self.v2t_linear_xwp(vis_i, words_i)
         frame_w = self.t2v_linear_xwp(sent_j, vis_j)
         glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)

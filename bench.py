@@ -284,8 +284,11 @@ def make_trainer(a, device, world):
             torch.manual_seed(1234)
             super().load_model()   # build_model("univl") from the config: the registry path of prj/*_vtp
 
+    mattrs = dict(w["model"])
+    if a.workload == "vtp8":   # all caption rows of the rank in ONE cross-encoder call (the reference chunks by 5 rows to bound its memory): 256-aligned token counts
+        mattrs["cross_chunk_rows"] = a.batch if a.batch is not None else w["default_batch"]
     cfg = Configuration({"training_parameters": tp, "optimizer_attributes": {"type": "AdamW", "params": {"lr": 1e-4, "weight_decay": 0.05, "betas": [0.9, 0.98], "eps": 1e-6}},
-                         "model_attributes": {"univl": dict(w["model"])}})
+                         "model_attributes": {"univl": mattrs}})
     return VtpTrainer(cfg)
 
 

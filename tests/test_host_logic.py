@@ -105,6 +105,17 @@ def test_hip_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
     _lib.reset_for_tests()
     with pytest.raises(_lib.HipLibraryError):
         _lib.load()
+    # the emulator build is refused outside pytest (it is test infrastructure, never a product backend)
+    emu_lib = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+    if os.path.isfile(emu_lib):
+        import subprocess
+
+        code = ("import os, sys; sys.path.insert(0, %r); os.environ['ANTMMF_HIP_LIB'] = %r; os.environ.pop('PYTEST_CURRENT_TEST', None);"
+                "from antmmf.hip import _lib\n"
+                "try:\n    _lib.load(); print('loaded')\nexcept _lib.HipLibraryError as e:\n    print('refused' if 'EMULATOR' in str(e) else 'other')" % (PKG, emu_lib))
+        env = {k: v for k, v in os.environ.items() if k not in ("PYTEST_CURRENT_TEST", "ANTMMF_ALLOW_EMULATOR")}
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert "refused" in out.stdout, out.stdout + out.stderr
     monkeypatch.delenv("ANTMMF_HIP_LIB")
     _lib.reset_for_tests()
 
