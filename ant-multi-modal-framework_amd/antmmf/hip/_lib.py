@@ -24,6 +24,7 @@ _SIGNATURES = {
     "antmmf_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, P],
     "antmmf_act_layernorm_fwd": [P, P, P, P, P, P, L, I, F, I, I, P],
     "antmmf_act_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, L, P],
+    "antmmf_layernorm_bwd_renorm": [P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, P],
     "antmmf_act_fwd": [P, P, L, I, I, P],
     "antmmf_act_bwd": [P, P, P, L, I, I, P],
     "antmmf_l2norm_fwd": [P, P, P, L, I, F, I, I, P],

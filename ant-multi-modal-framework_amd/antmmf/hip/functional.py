@@ -288,6 +288,7 @@ def _packed_qkv_weight_t(P, spec):
 # widest recompute: one full pass over the 4d-wide tensor per layer) -- worth it when HBM allows (288 GB on MI355X: the
 # ViT-L/14 step at 1024 pairs/GPU peaks at ~175 GiB without it).  Set through set_keep_ffn_norm().
 KEEP_FFN_NORM = False
+COLSUM_HANDOFFS = [0]   # diagnostic: fc2 bias gradients taken from the next layer's ln1 backward instead of a column-sum pass
 
 
 def set_keep_ffn_norm(flag):
@@ -409,7 +410,14 @@ class _TransformerLayer(torch.autograd.Function):
         # hidden dropout: the dense output's gradient is the masked / rescaled ds2; the residual branch keeps ds2 itself
         dy_w2 = ops.dropout_add(ds2.contiguous(), p_hid, seed + 2) if p_hid > 0 else ds2
         _wgrad(sink, P["w2"], dy_w2, g_n)
-        _bgrad(sink, P["b2"], dy_w2)
+        # fc2's bias gradient = column sums of the incoming gradient.  When that gradient is the dx of the NEXT layer's ln1 backward, that
+        # kernel has already summed its columns (handed over on the tensor, valid only while the tensor is unmodified: _version check)
+        handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0) else None
+        if handed is not None and handed[1] == dy._version and handed[0].shape[0] == d and P["b2"] is not None and P["b2"].requires_grad:
+            sink.buf(P["b2"]).add_(handed[0])
+            COLSUM_HANDOFFS[0] += 1
+        else:
+            _bgrad(sink, P["b2"], dy_w2)
         del g_n
         if spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
@@ -421,46 +429,52 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             b1_fused = False
             du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act)  # (d(dense out) W2) * act'(u)
+        # The normalised tensors the wgrads need (h2, o_n, h) are not kept by the forward pass and not recomputed either: the LayerNorm
+        # backward of the same tensor re-emits them (layernorm_bwd_renorm: one extra write instead of a read + write pass).
         ln_mid = ("ln2" if pre_ln else "ln1")
-        h2, _, _ = ops.layernorm_fwd(mid, f32(P[ln_mid + "_w"]), f32(P[ln_mid + "_b"]), spec.eps, want_stats=False)
-        _wgrad(sink, P["w1"], du, h2)
-        if not b1_fused:
-            _bgrad(sink, P["b1"], du)
-        del h2
         dgw, dgb = lnw(ln_mid)
         bo_fused = P["bo"] is not None and P["bo"].requires_grad and p_hid == 0  # out-projection bias gradient = column sums of dmid
         bo_sum = sink.buf(P["bo"]) if bo_fused else None
         if pre_ln:
             dh2 = dgrad(du, P["w1"])
-            dmid = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2, dxsum=bo_sum)  # + residual path
+            dmid, h2 = ops.layernorm_bwd_renorm(dh2, mid, m2_, r2, f32(P["ln2_w"]), f32(P["ln2_b"]), dgw, dgb, dres=ds2, dxsum=bo_sum)  # + residual path
+            del dh2
         else:
             da = dgrad(du, P["w1"], residual=ds2)  # bert: a feeds the MLP and the residual
-            dmid = ops.layernorm_bwd(da, mid, m2_, r2, f32(P["ln1_w"]), dgw, dgb, dxsum=bo_sum)
+            dmid, h2 = ops.layernorm_bwd_renorm(da, mid, m2_, r2, f32(P["ln1_w"]), f32(P["ln1_b"]), dgw, dgb, dxsum=bo_sum)
+            del da
+        _wgrad(sink, P["w1"], du, h2)
+        if not b1_fused:
+            _bgrad(sink, P["b1"], du)
+        del h2
         del du
 
         # ---- attention half
         o2 = o.view(T, d)
+        dy_wo = ops.dropout_add(dmid.contiguous(), p_hid, seed + 1) if p_hid > 0 else dmid
+        do = dgrad(dy_wo, P["wo"])
         if spec.kind == "m2":
-            o_n, _, _ = ops.layernorm_fwd(o2, f32(P["inner_w"]), f32(P["inner_b"]), spec.eps, want_stats=False)
+            dgw, dgb = lnw("inner")
+            do, o_n = ops.layernorm_bwd_renorm(do, o2, mi, ri, f32(P["inner_w"]), f32(P["inner_b"]), dgw, dgb)
         else:
             o_n = o2
-        dy_wo = ops.dropout_add(dmid.contiguous(), p_hid, seed + 1) if p_hid > 0 else dmid
         _wgrad(sink, P["wo"], dy_wo, o_n)
         if not bo_fused:
             _bgrad(sink, P["bo"], dy_wo)
         del o_n
-        do = dgrad(dy_wo, P["wo"])
-        if spec.kind == "m2":
-            dgw, dgb = lnw("inner")
-            do = ops.layernorm_bwd(do, o2, mi, ri, f32(P["inner_w"]), dgw, dgb)
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
                           dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dropout_p=p_att, dropout_seed=seed)
         del do
         dqkv2 = dqkv.view(T, 3 * d)
-        if pre_ln:
-            h, _, _ = ops.layernorm_fwd(x2, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps, want_stats=False)
+        dx = None
+        if pre_ln:   # (also when x itself needs no gradient: ln1's own parameters do)
+            dh = ops.gemm(dqkv2, _packed_qkv_weight_t(P, spec))
+            dgw, dgb = lnw("ln1")
+            dx_colsum = torch.zeros(d, dtype=torch.float32, device=dh.device) if ctx.needs_input_grad[0] else None
+            dx, h = ops.layernorm_bwd_renorm(dh, x2, m1, r1, f32(P["ln1_w"]), f32(P["ln1_b"]), dgw, dgb, dres=dmid, dxsum=dx_colsum)
+            del dh
         else:
             h = x2
         if spec.packed_qkv:
@@ -472,16 +486,14 @@ class _TransformerLayer(torch.autograd.Function):
                 _wgrad(sink, P["w" + nm], sl, h)
                 _bgrad(sink, P["b" + nm], sl)
         del h
-        dx = None
         if ctx.needs_input_grad[0]:
-            wqkv_t = _packed_qkv_weight_t(P, spec)
-            if pre_ln:
-                dh = ops.gemm(dqkv2, wqkv_t)
-                dgw, dgb = lnw("ln1")
-                dx = ops.layernorm_bwd(dh, x2, m1, r1, f32(P["ln1_w"]), dgw, dgb, dres=dmid)
-            else:
-                dx = ops.gemm(dqkv2, wqkv_t, residual=dmid)
+            if not pre_ln:
+                dx = ops.gemm(dqkv2, _packed_qkv_weight_t(P, spec), residual=dmid)
             dx = dx.view(B, N, d)
+            if pre_ln:
+                dx._antmmf_colsum = (dx_colsum, dx._version)   # for the previous layer's fc2 bias gradient (see above)
+        else:
+            dx = None
         grads = [sink.result(p, p is not None and ctx.needs_input_grad[4 + i]) for i, p in enumerate(params)]
         arena = next((getattr(p, "_antmmf_arena", None) for p in params if p is not None), None)
         if arena is not None:

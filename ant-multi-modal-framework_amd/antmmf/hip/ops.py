@@ -97,6 +97,24 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, 
     return dx
 
 
+def layernorm_bwd_renorm(dy, x, mean, rstd, gamma, beta, dgamma=None, dbeta=None, dres=None, dxsum=None):
+    """Plain LayerNorm backward that also returns y = LN(x) again (one extra write instead of a recompute pass): -> (dx, y)."""
+    _dev_ok(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, dres, dxsum)
+    _f32(gamma, "gamma"); _f32(beta, "beta")
+    if dxsum is not None:
+        _f32(dxsum, "dxsum")
+    _c(dy, "dy"); _c(x, "x")
+    if dres is not None:
+        _c(dres, "dres")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty_like(x)
+    y = torch.empty_like(x)
+    _rc(_lib.load().antmmf_layernorm_bwd_renorm(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dres), _p(dx), _p(y),
+                                                _p(dgamma), _p(dbeta), _p(dxsum), rows, cols, _dt(x), _stream()), "antmmf_layernorm_bwd_renorm")
+    return dx, y
+
+
 # ------------------------------------------------------------------------------ activations
 def act_fwd(u, act):
     _dev_ok(u); _c(u, "u")

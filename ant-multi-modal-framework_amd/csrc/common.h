@@ -73,12 +73,51 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
     *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
-// wave-wide (64-lane) butterfly reductions
+// ---- two fp32 per register pair: hipcc turns arithmetic on this type into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two results per
+// lane per issue slot) -- the row-wise kernels with a fused GELU were VALU-bound, not HBM-bound, on scalar fp32 code
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t f2_splat(float a) { return (f2_t){a, a}; }
+__device__ __forceinline__ f2_t f2_bf(uint32_t w) { return (f2_t){bf_lo(w), bf_hi(w)}; }
+template <typename T> __device__ __forceinline__ void ld8_f2(const T* p, f2_t (&v)[4]);
+template <> __device__ __forceinline__ void ld8_f2<float>(const float* p, f2_t (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = (f2_t){a.x, a.y}; v[1] = (f2_t){a.z, a.w}; v[2] = (f2_t){b.x, b.y}; v[3] = (f2_t){b.z, b.w};
+}
+template <> __device__ __forceinline__ void ld8_f2<bf16_t>(const bf16_t* p, f2_t (&v)[4]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = f2_bf(a.x); v[1] = f2_bf(a.y); v[2] = f2_bf(a.z); v[3] = f2_bf(a.w);
+}
+template <typename T> __device__ __forceinline__ void st8_f2(T* p, const f2_t (&v)[4]);
+template <> __device__ __forceinline__ void st8_f2<float>(float* p, const f2_t (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+}
+template <> __device__ __forceinline__ void st8_f2<bf16_t>(bf16_t* p, const f2_t (&v)[4]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
+}
+
+// wave-wide (64-lane) sum, the same value in every lane.  Device: four DPP adds (xor 1, xor 2, half-row mirror, row mirror: every
+// lane of a 16-lane row holds the row sum) + four v_readlane -- no LDS round trips (the ds_bpermute butterfly is a chain of six
+// dependent LDS accesses per sum, which is what the row-wise kernels were waiting on).  The emulator keeps the shuffle butterfly.
+#ifdef ANTMMF_EMULATE
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+#else
+#define ANTMMF_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
+__device__ __forceinline__ float wave_sum(float v) {
+    v = ANTMMF_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
+    v = ANTMMF_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
+    v = ANTMMF_DPP_ADD(v, 0x141);  // row_half_mirror
+    v = ANTMMF_DPP_ADD(v, 0x140);  // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -186,6 +225,19 @@ __device__ __forceinline__ void gelu_erf_fwd_grad(float x, float& z, float& dz) 
     z = x * cdf;
     dz = cdf + x * 0.39894228040143268f * e;
 }
+// the same formula on two elements per lane (packed fp32 math; rcp / exp stay one per element)
+__device__ __forceinline__ void gelu_erf_fwd_grad2(f2_t x, f2_t& z, f2_t& dz) {
+    const f2_t ax = (f2_t){fabsf(x.x), fabsf(x.y)};
+    const f2_t d = 1.0f + 0.23164189f * ax;
+    const f2_t t = (f2_t){fast_rcp(d.x), fast_rcp(d.y)};
+    const f2_t a = -0.5f * x * x;
+    const f2_t e = (f2_t){__expf(a.x), __expf(a.y)};
+    const f2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f2_t half_erf = 0.5f - 0.5f * poly * e;  // 0.5 erf(|x|/sqrt2) >= 0
+    const f2_t cdf = 0.5f + (f2_t){copysignf(half_erf.x, x.x), copysignf(half_erf.y, x.y)};
+    z = x * cdf;
+    dz = cdf + x * 0.39894228040143268f * e;
+}
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
         case ANTMMF_ACT_GELU_ERF: { float z, dz; gelu_erf_fwd_grad(x, z, dz); return z; }
@@ -211,6 +263,12 @@ __device__ __forceinline__ void act_fwd_grad(float x, int act, float& z, float& 
     if (ACT == ANTMMF_ACT_NONE) { z = x; dz = 1.0f; }
     else if (ACT == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad(x, z, dz);
     else { z = act_fwd(x, act); dz = act_grad(x, act); }
+}
+template <int ACT>
+__device__ __forceinline__ void act_fwd_grad2(f2_t x, int act, f2_t& z, f2_t& dz) {
+    if (ACT == ANTMMF_ACT_NONE) { z = x; dz = f2_splat(1.0f); }
+    else if (ACT == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad2(x, z, dz);
+    else { z = (f2_t){act_fwd(x.x, act), act_fwd(x.y, act)}; dz = (f2_t){act_grad(x.x, act), act_grad(x.y, act)}; }
 }
 
 static inline int antmmf_check_launch() { return hipGetLastError() == hipSuccess ? ANTMMF_OK : ANTMMF_ELAUNCH; }

@@ -17,15 +17,30 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ reductions over a "row group" (a wave or a 4-wave workgroup)
+// Workgroup sums go through one of two LDS slots, alternated by the caller (`ph`): ONE barrier per reduction -- a slot is rewritten two
+// reductions later, i.e. behind a barrier every wave has reached after its reads of that slot.
 template <bool BLOCK>
-__device__ __forceinline__ float row_sum(float v, float* sh) {
+__device__ __forceinline__ float row_sum(float v, float (*sh)[8], int& ph) {
     v = wave_sum(v);
     if (!BLOCK) return v;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s = sh[ph];
+    ph ^= 1;
+    if (lane == 0) s[wave] = v;
     __syncthreads();
-    if (lane == 0) sh[wave] = v;
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+template <bool BLOCK>
+__device__ __forceinline__ void row_sum2(float& a, float& b, float (*sh)[8], int& ph) {
+    a = wave_sum(a); b = wave_sum(b);
+    if (!BLOCK) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s = sh[ph];
+    ph ^= 1;
+    if (lane == 0) { s[wave] = a; s[4 + wave] = b; }
     __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    a = (s[0] + s[1]) + (s[2] + s[3]);
+    b = (s[4] + s[5]) + (s[6] + s[7]);
 }
 
 // raw (still packed) 8-element vector of a row: lets the NEXT row's loads be issued before the current row is touched
@@ -33,87 +48,92 @@ template <typename T> struct raw8;
 template <> struct raw8<bf16_t> {
     uint4 v;
     __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
-    __device__ __forceinline__ void unpack(float (&f)[8]) const {
-        f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
-        f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
-    }
+    __device__ __forceinline__ void unpack(f2_t (&f)[4]) const { f[0] = f2_bf(v.x); f[1] = f2_bf(v.y); f[2] = f2_bf(v.z); f[3] = f2_bf(v.w); }
 };
 template <> struct raw8<float> {
     float4 a, b;
     __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
-    __device__ __forceinline__ void unpack(float (&f)[8]) const {
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    __device__ __forceinline__ void unpack(f2_t (&f)[4]) const {
+        f[0] = (f2_t){a.x, a.y}; f[1] = (f2_t){a.z, a.w}; f[2] = (f2_t){b.x, b.y}; f[3] = (f2_t){b.z, b.w};
     }
 };
 
 // BLOCK = false: wave per row, lane handles vectors lane + 64 i.  BLOCK = true: workgroup per row, thread handles vectors tid + 256 i.
-// Both walk rows with a grid stride and keep the next row's loads in flight while the current one is reduced.
+// Both walk rows with a grid stride and keep the next row's loads in flight while the current one is reduced.  All per-element
+// arithmetic is on f2_t (two elements per lane per VALU slot).
 template <typename T, int VPL, bool BLOCK, int ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      long rows, int cols, float eps, int act) {
-    __shared__ float sh[4];
+    __shared__ float sh[2][8];
+    int ph = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = cols >> 3;
     const int v0 = BLOCK ? threadIdx.x : lane, vstep = BLOCK ? 256 : 64;
     const float inv_n = 1.0f / (float)cols;
     const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
     long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
-    raw8<T> nx[VPL];
-    auto fetch = [&](long r) {
+    // two rows in flight ahead of the one being reduced (BLOCK: 8 VGPRs per row and thread): nxa / nxb alternate
+    raw8<T> nxa[VPL], nxb[VPL];
+    auto fetch = [&](raw8<T> (&nx)[VPL], long r) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i)
             if (v0 + vstep * i < nvec) nx[i].load(x + r * cols + (v0 + vstep * i) * 8);
     };
-    if (row < rows) fetch(row);
-    for (; row < rows; row += rstep) {
-        float v[VPL][8];
-        float s = 0.f;
+    auto body = [&](raw8<T> (&nx)[VPL], long row) {
+        f2_t v[VPL][4];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
                 nx[i].unpack(v[i]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+                for (int e = 0; e < 4; ++e) v[i][e] = f2_splat(0.f);
             }
         }
-        if (row + rstep < rows) fetch(row + rstep);
+        if (row + 2 * rstep < rows) fetch(nx, row + 2 * rstep);
+        f2_t s2 = f2_splat(0.f);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float dz_unused; act_fwd_grad<ACT>(v[i][e], act, v[i][e], dz_unused); s += v[i][e]; }
+                for (int e = 0; e < 4; ++e) { f2_t dz_unused; act_fwd_grad2<ACT>(v[i][e], act, v[i][e], dz_unused); s2 += v[i][e]; }
             }
         }
-        const float mean = row_sum<BLOCK>(s, sh) * inv_n;
-        float q = 0.f;
+        const float mean = row_sum<BLOCK>(s2.x + s2.y, sh, ph) * inv_n;
+        f2_t q2 = f2_splat(0.f);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+                for (int e = 0; e < 4; ++e) { v[i][e] = v[i][e] - mean; q2 += v[i][e] * v[i][e]; }   // v is centred from here on
             }
         }
-        const float rstd = rsqrtf(row_sum<BLOCK>(q, sh) * inv_n + eps);
+        const float rstd = rsqrtf(row_sum<BLOCK>(q2.x + q2.y, sh, ph) * inv_n + eps);
         T* yr = y + row * cols;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
             if (vi < nvec) {
-                float g[8], b[8], o[8];
-                ld8<float>(gamma + vi * 8, g);
-                ld8<float>(beta + vi * 8, b);
+                f2_t g[4], b[4], o[4];
+                ld8_f2<float>(gamma + vi * 8, g);
+                ld8_f2<float>(beta + vi * 8, b);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-                st8<T>(yr + vi * 8, o);
+                for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g[e] + b[e];
+                st8_f2<T>(yr + vi * 8, o);
             }
         }
         if ((BLOCK ? threadIdx.x : lane) == 0) {
             if (mean_out) mean_out[row] = mean;
             if (rstd_out) rstd_out[row] = rstd;
         }
+    };
+    if (row < rows) fetch(nxa, row);
+    if (row + rstep < rows) fetch(nxb, row + rstep);
+    for (; row < rows; row += 2 * rstep) {
+        body(nxa, row);
+        if (row + rstep < rows) body(nxb, row + rstep);
     }
 }
 
@@ -122,16 +142,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // output this LayerNorm reads (fc1 for the fused gelu + ffn_layernorm; the attention out-projection for ln2 with the
 // residual gradient added), which would otherwise be a separate full read of dx.
 // Column sums leave through `partials` ([grid][NS][cols], reduced by ln_partials_reduce_kernel) or, without it, atomics.
-template <typename T, int VPL, bool BLOCK, int ACT, bool DXSUM>
+// YOUT (plain LayerNorm only): the forward output y = zhat * gamma + beta is written as well -- the backward pass of a transformer layer
+// needs LN(x) again as the wgrad operand of the Linear behind it, and this kernel already holds zhat: one extra write instead of a separate
+// recompute pass (read + write).
+template <typename T, int VPL, bool BLOCK, int ACT, bool DXSUM, bool YOUT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dxsum, long rows, int cols, int act,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, const float* __restrict__ beta, T* __restrict__ yout) {
     constexpr int NS = DXSUM ? 3 : 2;
-    ANTMMF_DYN_LDS(float, red);  // wave-per-row: [NS][cols] cross-wave column sums; workgroup-per-row: unused
-    __shared__ float sh[4];
+    ANTMMF_DYN_LDS(float, red);  // wave-per-row: [NS][cols] cross-wave column sums (+ [cols] beta with YOUT); workgroup-per-row: gamma (+ beta)
+    __shared__ float sh[2][8];
+    int ph = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = cols >> 3;
     const int v0 = BLOCK ? threadIdx.x : lane, vstep = BLOCK ? 256 : 64;
@@ -141,17 +165,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     // gamma: registers for the wave-per-row variant; the workgroup-per-row variant (wide rows, three accumulator sets live) keeps it
     // in LDS instead -- 16 VGPRs less, which is the difference between 2 and 3 resident waves per SIMD for the fused-GELU backward
-    float ag[VPL][8], ab[VPL][8], ad[DXSUM ? VPL : 1][8], gm[BLOCK ? 1 : VPL][8];
+    f2_t ag[VPL][4], ab[VPL][4], ad[DXSUM ? VPL : 1][4], gm[BLOCK ? 1 : VPL][4];
+    float* const beta_s = red + (BLOCK ? 1 : NS) * cols;   // YOUT only
     if (BLOCK) {
         for (int i = threadIdx.x; i < cols; i += 256) red[i] = gamma[i];
-        __syncthreads();
     }
+    if (YOUT) {
+        for (int i = threadIdx.x; i < cols; i += 256) beta_s[i] = beta[i];
+    }
+    if (BLOCK || YOUT) __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int vi = v0 + vstep * i;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; if (!BLOCK) gm[i][e] = 0.f; if (DXSUM) ad[i][e] = 0.f; }
-        if (!BLOCK && vi < nvec) ld8<float>(gamma + vi * 8, gm[i]);
+        for (int e = 0; e < 4; ++e) {
+            ag[i][e] = f2_splat(0.f); ab[i][e] = f2_splat(0.f);
+            if (!BLOCK) gm[i][e] = f2_splat(0.f);
+            if (DXSUM) ad[i][e] = f2_splat(0.f);
+        }
+        if (!BLOCK && vi < nvec) ld8_f2<float>(gamma + vi * 8, gm[i]);
     }
     const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
     long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
@@ -172,8 +204,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     if (row < rows) fetch(row);
     for (; row < rows; row += rstep) {
         const float mean = nmean, rstd = nrstd;
-        float zh[VPL][8], g[VPL][8], da[VPL][8], rs[VPL][8];
-        float s1 = 0.f, s2 = 0.f;
+        f2_t zh[VPL][4], g[VPL][4], da[VPL][4], rs[VPL][4];
+        f2_t s1v = f2_splat(0.f), s2v = f2_splat(0.f);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
@@ -186,36 +218,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
-                float gmv[8];
-                if (BLOCK) ld8<float>(red + (v0 + vstep * i) * 8, gmv);
+                f2_t gmv[4], yv[4];
+                if (BLOCK) ld8_f2<float>(red + (v0 + vstep * i) * 8, gmv);
+                if (YOUT) ld8_f2<float>(beta_s + (v0 + vstep * i) * 8, yv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float z;
-                    const float dv = g[i][e];
-                    act_fwd_grad<ACT>(zh[i][e], act, z, da[i][e]);
+                for (int e = 0; e < 4; ++e) {
+                    f2_t z;
+                    const f2_t dv = g[i][e];
+                    act_fwd_grad2<ACT>(zh[i][e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
+                    if (YOUT) yv[e] = zh[i][e] * (BLOCK ? gmv[e] : gm[i][e]) + yv[e];
                     g[i][e] = dv * (BLOCK ? gmv[e] : gm[i][e]);
-                    s1 += g[i][e];
-                    s2 += g[i][e] * zh[i][e];
+                    s1v += g[i][e];
+                    s2v += g[i][e] * zh[i][e];
                     ag[i][e] += dv * zh[i][e];
                     ab[i][e] += dv;
                 }
+                if (YOUT) st8_f2<T>(yout + row * cols + (v0 + vstep * i) * 8, yv);
             }
         }
-        const float c1 = row_sum<BLOCK>(s1, sh) * inv_n, c2 = row_sum<BLOCK>(s2, sh) * inv_n;
+        float c1 = s1v.x + s1v.y, c2 = s2v.x + s2v.y;
+        row_sum2<BLOCK>(c1, c2, sh, ph);
+        c1 *= inv_n; c2 *= inv_n;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
             if (vi < nvec) {
-                float o[8];
+                f2_t o[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     o[e] = rstd * (g[i][e] - c1 - zh[i][e] * c2);
                     if (ACT != ANTMMF_ACT_NONE) o[e] *= da[i][e];
                     if (dres) o[e] += rs[i][e];
                     if (DXSUM) ad[i][e] += o[e];
                 }
-                st8<T>(dx + row * cols + vi * 8, o);
+                st8_f2<T>(dx + row * cols + vi * 8, o);
             }
         }
     }
@@ -225,8 +262,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
             if (vi < nvec) {
-                st8<float>(pg + vi * 8, ag[i]); st8<float>(pg + cols + vi * 8, ab[i]);
-                if (DXSUM) st8<float>(pg + 2 * cols + vi * 8, ad[i]);
+                st8_f2<float>(pg + vi * 8, ag[i]); st8_f2<float>(pg + cols + vi * 8, ab[i]);
+                if (DXSUM) st8_f2<float>(pg + 2 * cols + vi * 8, ad[i]);
             }
         }
         return;
@@ -238,9 +275,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (vi < nvec) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if (dgamma) atomicAdd(&dgamma[vi * 8 + e], ag[i][e]);
-                    if (dbeta) atomicAdd(&dbeta[vi * 8 + e], ab[i][e]);
-                    if (DXSUM) atomicAdd(&dxsum[vi * 8 + e], ad[i][e]);
+                    if (dgamma) atomicAdd(&dgamma[vi * 8 + e], ag[i][e >> 1][e & 1]);
+                    if (dbeta) atomicAdd(&dbeta[vi * 8 + e], ab[i][e >> 1][e & 1]);
+                    if (DXSUM) atomicAdd(&dxsum[vi * 8 + e], ad[i][e >> 1][e & 1]);
                 }
             }
         }
@@ -253,9 +290,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         if (vi < nvec) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(&red[vi * 8 + e], ag[i][e]);
-                atomicAdd(&red[cols + vi * 8 + e], ab[i][e]);
-                if (DXSUM) atomicAdd(&red[2 * cols + vi * 8 + e], ad[i][e]);
+                atomicAdd(&red[vi * 8 + e], ag[i][e >> 1][e & 1]);
+                atomicAdd(&red[cols + vi * 8 + e], ab[i][e >> 1][e & 1]);
+                if (DXSUM) atomicAdd(&red[2 * cols + vi * 8 + e], ad[i][e >> 1][e & 1]);
             }
         }
     }
@@ -310,8 +347,11 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
 #define LN_FWD_A(V, BLK, GRID, A) hipLaunchKernelGGL((ln_fwd_kernel<T, V, BLK, A>), dim3(GRID), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, cols, eps, act)
 #define LN_FWD(V, BLK, GRID) do { if (act == ANTMMF_ACT_NONE) LN_FWD_A(V, BLK, GRID, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_FWD_A(V, BLK, GRID, ANTMMF_ACT_GELU_ERF); else LN_FWD_A(V, BLK, GRID, -1); } while (0)
     const int gw = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096), gb = (int)(rows < 4096 ? rows : 4096);
+    static const int wide_wave = getenv("ANTMMF_LN_WIDE_WAVE") ? atoi(getenv("ANTMMF_LN_WIDE_WAVE")) : 0;
     if (nvec <= 64) LN_FWD(1, false, gw);
     else if (nvec <= 128) LN_FWD(2, false, gw);
+    else if (wide_wave && nvec <= 256) LN_FWD(4, false, gw);
+    else if (wide_wave && nvec <= 512) LN_FWD(8, false, gw);
     else if (nvec <= 256) LN_FWD(1, true, gb);
     else if (nvec <= 512) LN_FWD(2, true, gb);
     else return ANTMMF_EINVAL;
@@ -323,7 +363,7 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
                          const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, long rows, int cols, int act,
-                         float* partials, long partial_elems, hipStream_t s) {
+                         float* partials, long partial_elems, const float* beta, void* yout, hipStream_t s) {
     const int nvec = cols / 8;
     const long want = (rows + 3) / 4;
     const bool wide = nvec > 128;
@@ -333,18 +373,21 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
     const int gw = (int)(want < 512 ? want : 512);
     const int gb = (int)(rows < 1024 ? rows : 1024);
     if (!(wide && partials && partial_elems >= (long)gb * ns * cols)) partials = nullptr;
-    const size_t lds = (size_t)ns * cols * sizeof(float);
-#define LN_BWD_D(V, BLK, GRID, LDS, A, D) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials)
+    const size_t lds = (size_t)(ns + (yout ? 1 : 0)) * cols * sizeof(float);
+    const size_t ldsb = (size_t)(1 + (yout ? 1 : 0)) * cols * sizeof(float);
+#define LN_BWD_Y(V, BLK, GRID, LDS, A, D, Y) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D, Y>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials, beta, (T*)yout)
+#define LN_BWD_D(V, BLK, GRID, LDS, A, D) do { if (yout && A == ANTMMF_ACT_NONE) LN_BWD_Y(V, BLK, GRID, LDS, ANTMMF_ACT_NONE, D, true); else LN_BWD_Y(V, BLK, GRID, LDS, A, D, false); } while (0)
 #define LN_BWD_A(V, BLK, GRID, LDS, A) do { if (dxsum) LN_BWD_D(V, BLK, GRID, LDS, A, true); else LN_BWD_D(V, BLK, GRID, LDS, A, false); } while (0)
 #define LN_BWD(V, BLK, GRID, LDS) do { if (act == ANTMMF_ACT_NONE) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_GELU_ERF); else LN_BWD_A(V, BLK, GRID, LDS, -1); } while (0)
     if (nvec <= 64) LN_BWD(1, false, gw, lds);
     else if (nvec <= 128) LN_BWD(2, false, gw, lds);
-    else if (nvec <= 256) LN_BWD(1, true, gb, (size_t)cols * sizeof(float));
-    else if (nvec <= 512) LN_BWD(2, true, gb, (size_t)cols * sizeof(float));
+    else if (nvec <= 256) LN_BWD(1, true, gb, ldsb);
+    else if (nvec <= 512) LN_BWD(2, true, gb, ldsb);
     else return ANTMMF_EINVAL;
 #undef LN_BWD
 #undef LN_BWD_A
 #undef LN_BWD_D
+#undef LN_BWD_Y
     if (partials && (dgamma || dbeta || dxsum))
         hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((ns * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb, cols, ns, dgamma, dbeta, dxsum);
     return antmmf_check_launch();
@@ -366,8 +409,19 @@ extern "C" int antmmf_act_layernorm_bwd(const void* dy, const void* x, const flo
                                         int dtype, float* partials, long partial_elems, hipStream_t stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !ln_args_ok(rows, cols)) return ANTMMF_EINVAL;
     if (rows == 0) return ANTMMF_OK;
-    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, stream)
-         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, stream)
+    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, nullptr, nullptr, stream)
+         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, act, partials, partial_elems, nullptr, nullptr, stream)
+                                : ANTMMF_EINVAL;
+}
+
+// plain LayerNorm backward that ALSO re-emits the forward output y = LN(x) (the layer backward needs it as a wgrad operand)
+extern "C" int antmmf_layernorm_bwd_renorm(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                           const float* beta, const void* dres, void* dx, void* y, float* dgamma, float* dbeta, float* dxsum,
+                                           long rows, int cols, int dtype, hipStream_t stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !y || !ln_args_ok(rows, cols)) return ANTMMF_EINVAL;
+    if (rows == 0) return ANTMMF_OK;
+    return dtype == ANTMMF_BF16 ? ln_bwd_launch<bf16_t>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, ANTMMF_ACT_NONE, nullptr, 0, beta, y, stream)
+         : dtype == ANTMMF_F32  ? ln_bwd_launch<float>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, dxsum, rows, cols, ANTMMF_ACT_NONE, nullptr, 0, beta, y, stream)
                                 : ANTMMF_EINVAL;
 }
 

@@ -61,6 +61,12 @@ int antmmf_act_layernorm_fwd(const void* x, const float* gamma, const float* bet
 int antmmf_act_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                              const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int cols,
                              int act, int dtype, float* partials, int64_t partial_elems, antmmf_stream_t stream);
+/* Plain LayerNorm backward that also re-emits y = LN(x) (same rounding as antmmf_layernorm_fwd): the backward pass of a transformer
+ * layer needs LN(x) again as the wgrad operand of the Linear behind it (encoder.py:34,77 recomputes nothing -- torch keeps every
+ * LayerNorm output alive; this build keeps none and gets it back for one extra write). */
+int antmmf_layernorm_bwd_renorm(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const void* dres, void* dx, void* y, float* dgamma, float* dbeta, float* dxsum,
+                                int64_t rows, int cols, int dtype, antmmf_stream_t stream);
 
 /* ---- activations (n % 8 == 0): g = act(u);  du = dg * act'(u). */
 int antmmf_act_fwd(const void* u, void* g, int64_t n, int act, int dtype, antmmf_stream_t stream);

@@ -462,7 +462,7 @@ def gen_e2e_clip_stage2():
         model.dropout.p = 0.0  # the only stochastic op on the path (BERT dropouts are 0 in this config)
         out = model(batch["image"], batch["caption"])
         loss = out["losses"]["level1_similarity_loss"] + out["losses"]["level2_similarity_loss"]
-        loss.backward()
+        loss.backward(retain_graph=(tag == "plain"))
         d.update({f"s2.{tag}.loss1": out["losses"]["level1_similarity_loss"], f"s2.{tag}.loss2": out["losses"]["level2_similarity_loss"],
                   f"s2.{tag}.l2_simi": out["l2_simi"], f"s2.{tag}.l1_simi": out["l1_simi"]})
         for n, p in model.named_parameters():
@@ -470,6 +470,17 @@ def gen_e2e_clip_stage2():
                 d[f"s2.{tag}.gnorm.{n}"] = p.grad.norm()
                 if tag == "plain":
                     d[f"s2.{tag}.gfull.{n}"] = p.grad.to(torch.bfloat16)
+        if tag == "plain":
+            # a second scalar of the same graph whose gradient does NOT cancel (the level-2 loss is a softmax over nearly identical pair
+            # scores: its parameter gradient is a difference of almost equal terms and bf16 noise dominates its direction): fixed random
+            # weights on the cross-encoder pair scores
+            model.zero_grad(set_to_none=True)
+            pin = (out["l2_simi"] * W.data_tensor("s2.pin", tuple(out["l2_simi"].shape))).sum()
+            pin.backward()
+            d["s2.pin.value"] = pin.detach()
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    d[f"s2.pin.gfull.{n}"] = p.grad.to(torch.bfloat16)
     save("e2e_clip_stage2.pt", d)
 
 

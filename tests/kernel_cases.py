@@ -64,6 +64,17 @@ def case_layernorm(ops, dev, dtype, rows=13, cols=128, eps=1e-5):
     check("ln.dx", dx, xr.grad + dres, rt, at)
     check("ln.dgamma", dgam, gr.grad, 1e-4 if dtype != BF else 2e-2, 1e-4 if dtype != BF else 2e-2)
     check("ln.dbeta", dbet, br.grad, 1e-4, 1e-4)
+    # backward that re-emits the forward output: same dx / parameter gradients as the plain backward, y identical to layernorm_fwd
+    dgam2, dbet2, dxs2 = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dx2, y2 = ops.layernorm_bwd_renorm(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), b.to(dev), dgam2, dbet2, dres.to(dev, dtype), dxsum=dxs2)
+    assert torch.equal(y2, y), float((y2.float() - y.float()).abs().max())
+    assert torch.equal(dx2, dx), float((dx2.float() - dx.float()).abs().max())
+    check("ln.renorm.dgamma", dgam2, dgam, 1e-4, 1e-4)
+    check("ln.renorm.dbeta", dbet2, dbet, 1e-4, 1e-4)
+    check("ln.renorm.dxsum", dxs2, dxs, 1e-4, 1e-4)
+    dx3, y3 = ops.layernorm_bwd_renorm(dy.to(dev, dtype), x.to(dev, dtype), mean, rstd, g.to(dev), b.to(dev))
+    assert torch.equal(y3, y)
+    check("ln.renorm.dx_nores", dx3, xr.grad, rt, at)
 
 
 def case_act_layernorm(ops, dev, dtype, rows=9, cols=512, act="gelu"):

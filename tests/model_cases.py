@@ -248,8 +248,30 @@ def case_univl_stage2(dev, golden, mining=False):
     cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
     out = model(img_input, cap_input)
     l1, l2 = out["losses"]["level1_similarity_loss"], out["losses"]["level2_similarity_loss"]
-    (l1 + l2).backward()
+    (l1 + l2).backward(retain_graph=not mining)
     if not mining:
+        loss_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        # (1) THE gradient check of this path: a scalar of the same graph whose gradient does not cancel -- fixed random weights on the
+        # cross-encoder pair scores (tests/golden/make_golden.py gen_e2e_clip_stage2, "s2.pin"): every parameter of both towers, the cross
+        # encoder and the score head against the reference's gradient, at the same gates as stage 1 / stage 3 / M2
+        model.zero_grad(set_to_none=True)
+        pin = (out["l2_simi"].float() * W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).to(dev)).sum()
+        pin.backward()
+        assert abs(float(pin) - float(g["s2.pin.value"])) <= 5e-2 * max(1.0, abs(float(g["s2.pin.value"]))), (float(pin), float(g["s2.pin.value"]))
+        # Gates: bf16 storage of the gradients that enter the post-LN BERT blocks puts a noise floor under this comparison (LayerNorm backward
+        # projects the common-mode part of its incoming gradient out, and what is left carries the rounding noise of the whole).  Measured
+        # (min cosine / worst norm / whole-model cosine): lane emulator 0.984 / 7.6 % / 0.993; MI355X 0.954 / 11 % / 0.985, and 0.974 / 8 % / 0.989
+        # with the round-1 LayerNorm kernels (another rounding order: the numbers move by this much between two correct builds).  With
+        # all-positive pair weights the text tower's share is almost entirely common mode (cosine 0.64): that floor, not an indexing error, is
+        # what limits these gates -- the same towers pass at 0.995 / 5 % in stage 1, and the loss gradient below is far noisier still.
+        pin_dirs = assert_grad_directions(model.named_parameters(), g, "s2.pin.", min_cos=0.93, max_norm_rel=0.16, min_checked=50)
+        prow = [(p.grad.detach().float().flatten().cpu(), g[f"s2.pin.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
+                if p.grad is not None and f"s2.pin.gfull.{n}" in g]
+        pgot, pref = torch.cat([r[0] for r in prow]), torch.cat([r[1] for r in prow])
+        pin_dirs["global_cos"] = float(torch.dot(pgot, pref) / (pgot.norm() * pref.norm()))
+        assert pin_dirs["global_cos"] >= 0.975, pin_dirs
+        for n, p in model.named_parameters():   # the checks below are on the LOSS gradient again
+            p.grad = loss_grads.get(n)
         ref1, ref2 = float(g["s2.plain.loss1"]), float(g["s2.plain.loss2"])
         assert abs(float(l1) - ref1) <= 1e-3 * abs(ref1), (float(l1), ref1)
         assert abs(float(l2) - ref2) <= 2e-3 * abs(ref2), (float(l2), ref2)   # cross-encoder scores through 2 more bf16 layers + an MLP
@@ -261,11 +283,13 @@ def case_univl_stage2(dev, golden, mining=False):
                 worst.append((abs(float(p.grad.float().norm()) - float(g[key])), float(g[key]), n))
         top = max(w[1] for w in worst)
         rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-4 * top), reverse=True)
-        assert len(rel) > 50 and rel[0][0] < 0.2, rel[:5]
+        # (2) the loss gradient itself: loose by necessity (see below; measured worst norm deviation 0.15-0.41 depending on the rounding order
+        # of the LayerNorm sums) -- the tight statement about this graph's backward pass is (1)
+        assert len(rel) > 50 and rel[0][0] < 0.6, rel[:5]
         # the level-2 loss is a softmax over pair scores that are nearly the same function of the shared text-tower weights at random init: its
         # parameter gradient is a sum of almost-cancelling per-pair terms, so bf16 rounding of the activations shows up in the DIRECTION
         # (measured: cosine 0.84-0.97 on the text tower, >= 0.995 everywhere in stage 1 / stage 3 / M2); a sign or permutation error would be << 0.9
-        dirs = assert_grad_directions(model.named_parameters(), g, "s2.plain.", min_cos=0.8, max_norm_rel=0.2, min_checked=50)
+        dirs = assert_grad_directions(model.named_parameters(), g, "s2.plain.", min_cos=0.8, max_norm_rel=0.6, min_checked=50)
         # (quantitatively: the softmax gradient rows sum to zero, so only the per-pair DEVIATION of d score / d theta counts -- ~1 % of the common
         # part at random init -- and bf16's 0.2-0.4 % rounding of that common part is 20-40 % of it).  Whole-model direction as a second view:
         rows = [(p.grad.detach().float().flatten().cpu(), g[f"s2.plain.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
@@ -273,7 +297,7 @@ def case_univl_stage2(dev, golden, mining=False):
         got, ref = torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
         dirs["global_cos"] = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
         assert dirs["global_cos"] >= 0.9, dirs
-        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs)
+        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs, pin_directions=pin_dirs)
     from oracle import step as ostep
 
     P = tiny_models.clip_arch_params(stage2=True)
@@ -639,7 +663,12 @@ def case_m2_towers(dev, golden, rtol=5e-2):
     logits_vl = model.logit_vl_scale.exp() * oi["cls_vlffn_feats"] @ ot["cls_vlffn_feats"].t()
     check("m2.logits", logits, g["logits"], rtol, 4e-2)
     pin = (logits * W.data_tensor("m2.wl", (3, 3)).to(dev)).sum() + (logits_vl * W.data_tensor("m2.wvl", (3, 3)).to(dev)).sum()
+    from antmmf.hip import functional as HF
+    handoffs0 = HF.COLSUM_HANDOFFS[0]
     pin.backward()
+    # stacked layers: every fc2 bias gradient but the last layer's comes from the next layer's ln1 backward (no column-sum pass); the
+    # gradient checks below (all parameters, fc2 biases included) are what proves the handed-over sums are the right ones
+    assert HF.COLSUM_HANDOFFS[0] - handoffs0 >= 2, HF.COLSUM_HANDOFFS[0] - handoffs0
     worst = []
     for n, p in model.named_parameters():
         if f"gnorm.{n}" not in g:
