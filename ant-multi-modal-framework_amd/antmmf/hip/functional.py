@@ -17,6 +17,8 @@ Reference modules replaced by `transformer_layer`:
 import math
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import ops
@@ -412,7 +414,7 @@ class _TransformerLayer(torch.autograd.Function):
         _wgrad(sink, P["w2"], dy_w2, g_n)
         # fc2's bias gradient = column sums of the incoming gradient.  When that gradient is the dx of the NEXT layer's ln1 backward, that
         # kernel has already summed its columns (handed over on the tensor, valid only while the tensor is unmodified: _version check)
-        handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0) else None
+        handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0 and not os.environ.get("ANTMMF_DEBUG_NO_HANDOFF")) else None
         if handed is not None and handed[1] == dy._version and handed[0].shape[0] == d and P["b2"] is not None and P["b2"].requires_grad:
             sink.buf(P["b2"]).add_(handed[0])
             COLSUM_HANDOFFS[0] += 1

@@ -99,7 +99,7 @@ template <> __device__ __forceinline__ void st8_f2<bf16_t>(bf16_t* p, const f2_t
 // wave-wide (64-lane) sum, the same value in every lane.  Device: four DPP adds (xor 1, xor 2, half-row mirror, row mirror: every
 // lane of a 16-lane row holds the row sum) + four v_readlane -- no LDS round trips (the ds_bpermute butterfly is a chain of six
 // dependent LDS accesses per sum, which is what the row-wise kernels were waiting on).  The emulator keeps the shuffle butterfly.
-#ifdef ANTMMF_EMULATE
+#if defined(ANTMMF_EMULATE) || defined(ANTMMF_SHFL_SUM)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1226,19 +1226,23 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             }
             const int cj = jw + (lane >> 5) * 16 + (grp & 1) * 8;  // + 32 p
             bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+            // all 16 residual vectors of the wave's tile are requested up front (64 VGPRs: the K loop's fragment registers are free here): ONE
+            // exposed L2 / HBM latency per output tile instead of one per half -- at R = 1024 (16 K-tiles per tile) each cost ~10 % of the tile
+            // (the generic epilogue keeps two halves of 8: with gate / aux operands live as well, 16 vectors spill)
+            constexpr int NH = GENERIC ? 2 : 1, NV = 16 / NH;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {   // two halves of the rows: 8 residual vectors in flight at a time
-                u32x4_t rv[8];
+            for (int h = 0; h < NH; ++h) {
+                u32x4_t rv[NV];
                 if (RES || (GENERIC && g.residual)) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int it = h * 4 + (q >> 1), p2 = q & 1;
+                    for (int q = 0; q < NV; ++q) {
+                        const int it = h * (NV / 2) + (q >> 1), p2 = q & 1;
                         rv[q] = *reinterpret_cast<const u32x4_t*>(g.residual + (long)(iw + it * 16) * g.ldr + cj + 32 * p2);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int it = h * 4 + (q >> 1), p2 = q & 1, a = 2 * p2, b = 2 * p2 + 1;
+                for (int q = 0; q < NV; ++q) {
+                    const int it = h * (NV / 2) + (q >> 1), p2 = q & 1, a = 2 * p2, b = 2 * p2 + 1;
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

