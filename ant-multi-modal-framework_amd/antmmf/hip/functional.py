@@ -285,10 +285,10 @@ def _packed_qkv_weight_t(P, spec):
                       lambda: torch.cat([compute_copy_t(P["wq"]), compute_copy_t(P["wk"]), compute_copy_t(P["wv"])], dim=1))
 
 
-# Activation-memory policy.  By default a layer saves 20 B per token-channel (x, qkv, o, mid, u) and recomputes every
-# normalised tensor in backward.  KEEP_FFN_NORM additionally keeps g_n = ffn_layernorm(gelu(u)) (+8 B per token-channel, the
-# widest recompute: one full pass over the 4d-wide tensor per layer) -- worth it when HBM allows (288 GB on MI355X: the
-# ViT-L/14 step at 1024 pairs/GPU peaks at ~175 GiB without it).  Set through set_keep_ffn_norm().
+# Activation-memory policy.  By default a layer saves 20 B per token-channel (x, qkv, o, mid, u); the normalised tensors come back out of
+# the LayerNorm backward kernels (layernorm_bwd_renorm).  KEEP_FFN_NORM additionally keeps fc2's input g_n = ffn_layernorm(gelu(u)) (M2) or
+# act(u) (CLIP / BERT layers) (+8 B per token-channel, the widest recompute: one full pass over the 4d-wide tensor per layer) -- worth it
+# when HBM allows (288 GB on MI355X: the ViT-L/14 step at 1024 pairs/GPU peaks at ~175 GiB without it).  Set through set_keep_ffn_norm().
 KEEP_FFN_NORM = False
 COLSUM_HANDOFFS = [0]   # diagnostic: fc2 bias gradients taken from the next layer's ln1 backward instead of a column-sum pass
 
@@ -357,7 +357,7 @@ class _TransformerLayer(torch.autograd.Function):
             y = ops.dropout_add(ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"])), p_hid, seed + 2, residual=res)
         else:
             y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
-        kept_gn = g_n if (KEEP_FFN_NORM and spec.kind == "m2") else None
+        kept_gn = g_n if KEEP_FFN_NORM else None   # m2: ffn_layernorm(gelu(u)); clip / bert: act(u) -- either way fc2's wgrad operand
         del g_n
         st_y = None
         s2 = None
