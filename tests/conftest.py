@@ -12,6 +12,16 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini): 4 workers for the CPU suite, none for the GPU suite (-m gpu) or when ANTMMF_TEST_WORKERS says otherwise."""
+    if os.environ.get("ANTMMF_TEST_WORKERS"):
+        return int(os.environ["ANTMMF_TEST_WORKERS"])
+    mark = config.getoption("markexpr", "") or ""
+    if "gpu" in mark and "not gpu" not in mark:
+        return 0
+    return min(4, os.cpu_count() or 1)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
