@@ -44,6 +44,8 @@ _SIGNATURES = {
     "antmmf_gemm_wgrad_bf16": [P, P, P, L, I, I, L, L, L, I, P, L, P],
     "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, F, U64, P],
     "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
+    "antmmf_attention_fwd_hd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, F, U64, P],
+    "antmmf_attention_bwd_hd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
     "antmmf_milnce_fwd": [P, P, I, I, I, I, I, P, P, P],
     "antmmf_milnce_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P],
     "antmmf_softmax_ce_fwd": [P, I, I, I, P, F, P, P, P],

@@ -347,21 +347,28 @@ def _tok_ld(t, name):
     return t.stride(1)
 
 
+def _head_dim(D, heads):
+    if D % heads or D // heads not in (64, 128):
+        raise ValueError(f"attention: head size {D}/{heads} is not supported by the HIP kernels (64 or 128)")
+    return D // heads
+
+
 def attention_fwd(q, k, v, heads, scale, key_bias=None, dropout_p=0.0, dropout_seed=0):
-    """dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_seed, element index)."""
+    """dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_seed, element index).  Head size =
+    q.shape[-1] / heads: 64 or 128."""
     _dev_ok(q, k, v, key_bias)
     B, Nq, D = q.shape
     Nk = k.shape[1]
-    assert D == heads * 64, "head_dim must be 64"
+    dh = _head_dim(D, heads)
     o = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=q.device)
     lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
     if key_bias is not None:
         _f32(key_bias, "key_bias"); _c(key_bias, "key_bias")
         assert tuple(key_bias.shape) == (B, Nk)
-    _rc(_lib.load().antmmf_attention_fwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), B, heads, Nq, Nk,
-                                         _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, float(scale), float(dropout_p),
-                                         int(dropout_seed), _stream()),
-        "antmmf_attention_fwd")
+    _rc(_lib.load().antmmf_attention_fwd_hd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), B, heads, dh, Nq, Nk,
+                                            _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, float(scale), float(dropout_p),
+                                            int(dropout_seed), _stream()),
+        "antmmf_attention_fwd_hd")
     return o, lse
 
 
@@ -369,6 +376,7 @@ def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk
     _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
     B, Nq, D = q.shape
     Nk = k.shape[1]
+    dh = _head_dim(D, heads)
     _c(o, "o"); _c(d_o, "d_o")
     if dq is None:
         dq = torch.empty(B, Nq, D, dtype=torch.bfloat16, device=q.device)
@@ -376,11 +384,11 @@ def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk
         dk = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
     if dv is None:
         dv = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
-    _rc(_lib.load().antmmf_attention_bwd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
-                                         B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
-                                         _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), float(dropout_p),
-                                         int(dropout_seed), _stream()),
-        "antmmf_attention_bwd")
+    _rc(_lib.load().antmmf_attention_bwd_hd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
+                                            B, heads, dh, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
+                                            _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), float(dropout_p),
+                                            int(dropout_seed), _stream()),
+        "antmmf_attention_bwd_hd")
     return dq, dk, dv
 
 

@@ -10,8 +10,8 @@ MI355X design: per stream ONE packed [3 A, d_in] projection GEMM (the reference 
 the streams swapped -- stream-2 queries over stream-1 keys / values under stream 1's additive mask, and vice versa -- with the
 attention-probability dropout of each direction applied INSIDE the kernel from a counter-based mask (nothing [B, h, Nq, Nk]-shaped reaches HBM).
 The additive masks are the reference's extended masks `[B, 1, 1, N]` (0 / -10000); they are passed to the kernel as per-key biases [B, N].
-Head size: the attention kernels are built for 64 (every tower of the contrastive path); another `bi_hidden_size / bi_num_attention_heads`
-raises NotImplementedError.  `visualization=True` (returning the probability tensors) is not available from the fused kernel and raises."""
+Head size: 64 (every tower of the contrastive path) or 128 (ViLBERT's own bi_hidden_size 1024 / 8 heads); another
+`bi_hidden_size / bi_num_attention_heads` raises NotImplementedError.  `visualization=True` (returning the probability tensors) is not available from the fused kernel and raises."""
 import math
 
 import torch
@@ -51,8 +51,8 @@ class BertBiAttention(nn.Module):
         self.num_attention_heads = config.bi_num_attention_heads
         self.attention_head_size = int(config.bi_hidden_size / config.bi_num_attention_heads)
         self.all_head_size = self.num_attention_heads * self.attention_head_size
-        if self.attention_head_size != 64:
-            raise NotImplementedError(f"BertBiAttention on the HIP path: head size {self.attention_head_size} (the attention kernels are built for 64)")
+        if self.attention_head_size not in (64, 128):
+            raise NotImplementedError(f"BertBiAttention on the HIP path: head size {self.attention_head_size} (the attention kernels are built for 64 and 128)")
         self.query1 = nn.Linear(config.v_hidden_size, self.all_head_size)
         self.key1 = nn.Linear(config.v_hidden_size, self.all_head_size)
         self.value1 = nn.Linear(config.v_hidden_size, self.all_head_size)

@@ -63,27 +63,38 @@ struct AttnArgs {
     uint64_t drop_seed;
 };
 
-__device__ __forceinline__ int attn_swz(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
+// Head size DH = 64 (every tower of the contrastive path) or 128 (ViLBERT co-attention, vilbert.py:326-416 with bi_hidden_size 1024 / 8 heads):
+// token tiles [tokens][DH] with 2 DH-byte rows; the 16-B slot index of a row is XOR-swizzled so that BOTH access patterns sweep all 64 banks:
+// 16 consecutive rows x one slot (ds_read_b128 fragments) and 8 consecutive rows x one 32-B slot pair (transposing reads).
+template <int DH>
+__device__ __forceinline__ int attn_swz(int row) {
+    return DH == 64 ? ((((row >> 1) & 3) << 1) | ((row >> 3) & 1))    // 128-B rows: two rows per bank sweep, 4 slot pairs
+                    : (((row & 7) << 1) | ((row >> 3) & 1));          // 256-B rows: one row per bank sweep, 8 slot pairs
+}
 
-// rows [0, n_pad) x 64 bf16 -> swizzled token tile; rows >= n_valid are zero
+// rows [0, n_pad) x DH bf16 -> swizzled token tile; rows >= n_valid are zero
+template <int DH>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* __restrict__ src, long ld, int n_valid, int n_pad) {
-    for (int id = threadIdx.x; id < n_pad * 8; id += ATTN_THREADS) {
-        const int row = id >> 3, slot = id & 7;
+    constexpr int NS = DH / 8;
+    for (int id = threadIdx.x; id < n_pad * NS; id += ATTN_THREADS) {
+        const int row = id / NS, slot = id % NS;
         const uint4 v = row < n_valid ? *reinterpret_cast<const uint4*>(src + (long)row * ld + slot * 8) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + row * 128 + ((slot ^ attn_swz(row)) << 4)) = v;
+        *reinterpret_cast<uint4*>(dst + row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4)) = v;
     }
 }
 // fragment "token `row`, head-dim 8 slot .. 8 slot + 7" (A or B operand with the head dim as the contraction)
+template <int DH>
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row, int slot) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((slot ^ attn_swz(row)) << 4));
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4));
 }
 // A fragment "head-dim row 16 dt + l15, token slots of 32-token chunk c" (tokens {32c+4g..+3, 32c+16+4g..+3}): the
 // transposed view of the row-major tile, two transposing reads
+template <int DH>
 __device__ __forceinline__ bf16x8_t frag_tokens(const char* tile, int c, int dt, int grp, int l15) {
     const int row = 32 * c + 4 * grp + (l15 >> 2);           // row this lane supplies to the 4 x 16 block
     const int slot = 2 * dt + ((l15 >> 1) & 1), sub = (l15 & 1) << 3;
-    const bf16x4_t lo = lds_read_tr16(tile + row * 128 + ((slot ^ attn_swz(row)) << 4) + sub);
-    const bf16x4_t hi = lds_read_tr16(tile + (row + 16) * 128 + ((slot ^ attn_swz(row + 16)) << 4) + sub);
+    const bf16x4_t lo = lds_read_tr16(tile + row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4) + sub);
+    const bf16x4_t hi = lds_read_tr16(tile + (row + 16) * (2 * DH) + ((slot ^ attn_swz<DH>(row + 16)) << 4) + sub);
     return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ bf16x8_t pack_frag(const float (&lo)[4], const float (&hi)[4]) {
@@ -107,17 +118,17 @@ __device__ __forceinline__ void stage_key_bias(float* kb, const AttnArgs& a, int
 // ---- forward ----------------------------------------------------------------------------------------
 // DROP: attention-probability dropout compiled in (a separate instantiation: the mask arithmetic in the inner loops costs registers
 // -- with it folded in at run time the no-dropout backward dropped from 3 to 2 waves per SIMD and ran 1.7x slower)
-template <int NCH, bool DROP>  // keys padded to 32 * NCH
-__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArgs a) {
+template <int NCH, bool DROP, int DH>  // keys padded to 32 * NCH
+__global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
-    constexpr int NKP = 32 * NCH, NT = 2 * NCH;
+    constexpr int NKP = 32 * NCH, NT = 2 * NCH, RB = 2 * DH, KM = DH / 32, DT = DH / 16;
     char* Ks = smem;
-    char* Vs = smem + NKP * 128;
-    float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
+    char* Vs = smem + NKP * RB;
+    float* kb = reinterpret_cast<float*>(Vs + NKP * RB);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
-    stage_rows(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
+    stage_rows<DH>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, a.Nk, NKP);
+    stage_rows<DH>(Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -127,23 +138,34 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
     // processed (PMC: 68 % of the wave cycles were spent parked on s_waitcnt with the loads issued at the point of use)
     auto q_ptr = [&](int qt) {
         const int qi = qt * 16 + l15;
-        return a.q + ((long)b * a.Nq + (qi < a.Nq ? qi : a.Nq - 1)) * a.ldq + h * 64 + grp * 8;
+        return a.q + ((long)b * a.Nq + (qi < a.Nq ? qi : a.Nq - 1)) * a.ldq + h * DH + grp * 8;
     };
-    bf16x8_t nq0 = {}, nq1 = {};
-    if (wave < nqt) { const bf16_t* p0 = q_ptr(wave); nq0 = load_frag_global(p0); nq1 = load_frag_global(p0 + 32); }
+    bf16x8_t nq[KM] = {};
+    if (wave < nqt) {
+        const bf16_t* p0 = q_ptr(wave);
+#pragma unroll
+        for (int j = 0; j < KM; ++j) nq[j] = load_frag_global(p0 + 32 * j);
+    }
     for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
         const int qi = qt * 16 + l15;
         const int qrow = qi < a.Nq ? qi : a.Nq - 1;
-        const bf16x8_t qf0 = nq0, qf1 = nq1;
-        if (qt + ATTN_THREADS / 64 < nqt) { const bf16_t* p1 = q_ptr(qt + ATTN_THREADS / 64); nq0 = load_frag_global(p1); nq1 = load_frag_global(p1 + 32); }
+        bf16x8_t qf[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) qf[j] = nq[j];
+        if (qt + ATTN_THREADS / 64 < nqt) {
+            const bf16_t* p1 = q_ptr(qt + ATTN_THREADS / 64);
+#pragma unroll
+            for (int j = 0; j < KM; ++j) nq[j] = load_frag_global(p1 + 32 * j);
+        }
         float s[NT][4];
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t % 3 == 0) LDS_FENCE();
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, grp), qf0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, 4 + grp), qf1, acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < KM; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, 16 * t + l15, 4 * j + grp), qf[j], acc, 0, 0, 0);
             const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
             s[t][0] = acc[0] * scale2 + bias.x; s[t][1] = acc[1] * scale2 + bias.y;
             s[t][2] = acc[2] * scale2 + bias.z; s[t][3] = acc[3] * scale2 + bias.w;
@@ -171,14 +193,14 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
 #pragma unroll
         for (int c = 0; c < NCH; ++c) pf[c] = pack_frag(s[2 * c], s[2 * c + 1]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             LDS_FENCE();
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
             if (qi < a.Nq)
-                *reinterpret_cast<uint2*>(a.o + ((long)b * a.Nq + qi) * a.ldo + h * 64 + 16 * dt + 4 * grp) =
+                *reinterpret_cast<uint2*>(a.o + ((long)b * a.Nq + qi) * a.ldo + h * DH + 16 * dt + 4 * grp) =
                     make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
         }
         if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
@@ -186,8 +208,11 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_fwd_kernel(const AttnArg
 }
 
 // ---- backward 1: dQ (one workgroup per (b, h); K and V token tiles in LDS; waves walk query tiles) ----
+// Head size 64, written out: the same statements as the DH-templated kernel below, but hipcc's schedule of THIS form is the tuned one (the
+// templated form compiles the 96-key variant to 108 VGPRs instead of 60 -- 4 instead of 8 waves per SIMD -- and the text tower's backward
+// ran 10 % slower with it).
 template <int NCH, bool DROP>
-__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq64_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int NKP = 32 * NCH;
     char* Ks = smem;
@@ -195,8 +220,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
     float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
-    stage_rows(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
+    stage_rows<64>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
+    stage_rows<64>(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -248,10 +273,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * c + hh;
                 f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, grp), qf0, sa, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, 16 * t + l15, 4 + grp), qf1, sa, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, 16 * t + l15, grp), df0, da, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, 16 * t + l15, 4 + grp), df1, da, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Ks, 16 * t + l15, grp), qf0, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Ks, 16 * t + l15, 4 + grp), qf1, sa, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Vs, 16 * t + l15, grp), df0, da, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Vs, 16 * t + l15, 4 + grp), df1, da, 0, 0, 0);
                 const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
                 const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
@@ -271,36 +296,139 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq_kernel(const Attn
             f32x4_t g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
             if (qi < a.Nq)
                 *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * 64 + 16 * dt + 4 * grp) =
                     make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
         }
     }
 }
+#undef DQ_FETCH
+
+// ---- backward 1, any head size (used for 128)
+template <int NCH, bool DROP, int DH>
+__global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dq_kernel(const AttnArgs a) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int NKP = 32 * NCH, RB = 2 * DH, KM = DH / 32, DT = DH / 16;
+    char* Ks = smem;
+    char* Vs = smem + NKP * RB;
+    float* kb = reinterpret_cast<float*>(Vs + NKP * RB);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    stage_rows<DH>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, a.Nk, NKP);
+    stage_rows<DH>(Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
+    stage_key_bias(kb, a, b, NKP);
+    __syncthreads();
+
+    const float scale2 = a.scale * LOG2E;
+    const int nqt = (a.Nq + 15) >> 4;
+    // (unlike the forward / dK-dV kernels this one loads its tile operands at the point of use: with a one-tile-ahead prefetch hipcc
+    // hoists the unrolled LDS fragment reads as well and lands at 256 VGPRs + scratch, i.e. 2 waves per SIMD -- measured slower)
+    bf16x8_t nq[KM] = {}, nd[KM] = {};
+    float nlse = 0.f;
+#define DQ_FETCH(QT)                                                                                      \
+    do {                                                                                                  \
+        const int qi_ = (QT) * 16 + l15;                                                                  \
+        const long tok_ = (long)b * a.Nq + (qi_ < a.Nq ? qi_ : a.Nq - 1);                                 \
+        const bf16_t* qp_ = a.q + tok_ * a.ldq + h * DH + grp * 8;                                        \
+        const bf16_t* dop_ = a.d_o + tok_ * a.lddo + h * DH + grp * 8;                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < KM; ++j_) nq[j_] = load_frag_global(qp_ + 32 * j_);       \
+        _Pragma("unroll") for (int j_ = 0; j_ < KM; ++j_) nd[j_] = load_frag_global(dop_ + 32 * j_);      \
+        nlse = a.lse[((long)b * a.heads + h) * a.Nq + (qi_ < a.Nq ? qi_ : a.Nq - 1)];                     \
+    } while (0)
+    for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
+        const int qi = qt * 16 + l15;
+        const int qrow = qi < a.Nq ? qi : a.Nq - 1;
+        DQ_FETCH(qt);
+        bf16x8_t qf[KM], df[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) { qf[j] = nq[j]; df[j] = nd[j]; }
+        const float lse = nlse;
+        // D_q = <dO[q], O[q]> : this lane covers dh 8g..8g+7 of every 32-wide slice.  (O is fetched here, not a tile ahead: prefetching it
+        // as well pushes the kernel over the 3-waves-per-SIMD register budget; its latency hides behind the first score MFMAs.)
+        const bf16_t* op = a.o + ((long)b * a.Nq + qrow) * a.ldo + h * DH + grp * 8;
+        float dsum = 0.f;
+        {
+            uint32_t dw[4 * KM], ow[4 * KM];
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                union { bf16x8_t f; uint4 u; } d0;
+                d0.f = df[j];
+                const uint4 o0 = *reinterpret_cast<const uint4*>(op + 32 * j);
+                dw[4 * j] = d0.u.x; dw[4 * j + 1] = d0.u.y; dw[4 * j + 2] = d0.u.z; dw[4 * j + 3] = d0.u.w;
+                ow[4 * j] = o0.x; ow[4 * j + 1] = o0.y; ow[4 * j + 2] = o0.z; ow[4 * j + 3] = o0.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4 * KM; ++e) dsum += bf_lo(dw[e]) * bf_lo(ow[e]) + bf_hi(dw[e]) * bf_hi(ow[e]);
+        }
+        dsum = grp_sum(dsum);
+        // fully masked query (lse = -inf): subtracting +inf makes every z = -inf and exp2(z) = 0 without per-element selects
+        const float lse2 = lse == -INFINITY ? INFINITY : lse * LOG2E;
+        const uint32_t dbase = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
+        bf16x8_t dsf[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            LDS_FENCE();
+            float ds[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int t = 2 * c + hh;
+                f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < KM; ++j) sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, 16 * t + l15, 4 * j + grp), qf[j], sa, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Vs, 16 * t + l15, 4 * j + grp), df[j], da, 0, 0, 0);
+                const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
+                const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = EXP2F(sa[r] * scale2 + bb[r] - lse2);  // masked key: bias = -inf -> p = 0
+                    float dp = da[r];
+                    if (DROP) dp = DROPOUT_KEEP(dbase + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr) ? dp * a.drop_scale : 0.f;
+                    ds[hh][r] = p * (dp - dsum);
+                }
+            }
+            dsf[c] = pack_frag(ds[0], ds[1]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            LDS_FENCE();
+            f32x4_t g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
+            if (qi < a.Nq)
+                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * DH + 16 * dt + 4 * grp) =
+                    make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
+        }
+    }
+}
+
+#undef DQ_FETCH
 
 // ---- backward 2: dK, dV (one workgroup per (b, h); Q and dO token tiles, lse, D in LDS; waves own key tiles) ----
-template <bool DROP>
-__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const AttnArgs a, int NQP) {
+template <bool DROP, int DH>
+__global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a, int NQP) {
     ANTMMF_DYN_LDS(char, smem);
+    constexpr int RB = 2 * DH, KM = DH / 32, DT = DH / 16, NS = DH / 8;
     char* Qs = smem;
-    char* Ds = Qs + NQP * 128;
-    float* lse_s = reinterpret_cast<float*>(Ds + NQP * 128);
+    char* Ds = Qs + NQP * RB;
+    float* lse_s = reinterpret_cast<float*>(Ds + NQP * RB);
     float* dsum_s = lse_s + NQP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * 64;
-    const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * 64;
-    const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
-    stage_rows(Qs, qbase, a.ldq, a.Nq, NQP);
-    stage_rows(Ds, dobase, a.lddo, a.Nq, NQP);
+    const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * DH;
+    const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * DH;
+    const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * DH;
+    stage_rows<DH>(Qs, qbase, a.ldq, a.Nq, NQP);
+    stage_rows<DH>(Ds, dobase, a.lddo, a.Nq, NQP);
     for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {
         float d = 0.f, l = INFINITY;  // padding queries: p = 0
         if (i < a.Nq) {
             l = a.lse[((long)b * a.heads + h) * a.Nq + i];
             l = l == -INFINITY ? INFINITY : l * LOG2E;  // fully masked query: z - inf = -inf -> p = 0
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
+            for (int v = 0; v < NS; ++v) {
                 float x[8], y[8];
                 ld8<bf16_t>(dobase + (long)i * a.lddo + v * 8, x);
                 ld8<bf16_t>(obase + (long)i * a.ldo + v * 8, y);
@@ -320,24 +448,25 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
     for (int kt = wave; kt < nkt; kt += ATTN_THREADS / 64) {
         const int ki = kt * 16 + l15;
         const int krow = ki < a.Nk ? ki : a.Nk - 1;
-        const bf16_t* kp = a.k + ((long)b * a.Nk + krow) * a.ldk + h * 64 + grp * 8;
-        const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
-        const bf16x8_t kf0 = load_frag_global(kp), kf1 = load_frag_global(kp + 32);
-        const bf16x8_t vf0 = load_frag_global(vp), vf1 = load_frag_global(vp + 32);
-        const float kbias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
-        f32x4_t dk[4], dv[4];
+        const bf16_t* kp = a.k + ((long)b * a.Nk + krow) * a.ldk + h * DH + grp * 8;
+        const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * DH + grp * 8;
+        bf16x8_t kf[KM], vf[KM];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < KM; ++j) { kf[j] = load_frag_global(kp + 32 * j); vf[j] = load_frag_global(vp + 32 * j); }
+        const float kbias = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        f32x4_t dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
         for (int c = 0; c < nqc; ++c) {
             float p[2][4], ds[2][4];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int q0 = 32 * c + 16 * hh;
                 f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, q0 + l15, grp), kf0, sa, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, q0 + l15, 4 + grp), kf1, sa, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ds, q0 + l15, grp), vf0, da, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ds, q0 + l15, 4 + grp), vf1, da, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Qs, q0 + l15, 4 * j + grp), kf[j], sa, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) da = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ds, q0 + l15, 4 * j + grp), vf[j], da, 0, 0, 0);
                 // lane holds (key = l15, q = q0 + 4g + r)
                 const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + 4 * grp);
                 const float4 d4 = *reinterpret_cast<const float4*>(dsum_s + q0 + 4 * grp);
@@ -358,15 +487,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
             }
             const bf16x8_t pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Ds, c, dt, grp, l15), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens(Qs, c, dt, grp, l15), dsf, dk[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Ds, c, dt, grp, l15), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Qs, c, dt, grp, l15), dsf, dk[dt], 0, 0, 0);
             }
         }
         if (ki < a.Nk) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const long off = h * 64 + 16 * dt + 4 * grp;
+            for (int dt = 0; dt < DT; ++dt) {
+                const long off = h * DH + 16 * dt + 4 * grp;
                 *reinterpret_cast<uint2*>(a.dv + ((long)b * a.Nk + ki) * a.lddv + off) =
                     make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
                 *reinterpret_cast<uint2*>(a.dk + ((long)b * a.Nk + ki) * a.lddk + off) =
@@ -377,35 +506,61 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dkv_kernel(const Att
 }
 
 // ---- C ABI --------------------------------------------------------------------------------------------
-static bool attn_args_ok(const AttnArgs& a) {
-    return a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0 && a.Nk <= 288 && a.Nq <= 288 && !(a.ldq & 7) && !(a.ldk & 7) && !(a.ldv & 7) && !(a.ldo & 3);
+static bool attn_args_ok(const AttnArgs& a, int dh) {
+    return (dh == 64 || dh == 128) && a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0 && a.Nk <= 288 && a.Nq <= 288 && !(a.ldq & 7) && !(a.ldk & 7) &&
+           !(a.ldv & 7) && !(a.ldo & 3);
 }
 template <typename K>
 static void set_lds(K kern, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
-extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
-                                    int B, int heads, int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, float scale,
-                                    float dropout_p, uint64_t dropout_seed, hipStream_t stream) {
-    AttnArgs a{};
-    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
-    a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)o; a.lse = lse;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
-    if (!q || !k || !v || !o || !lse || !attn_args_ok(a)) return ANTMMF_EINVAL;
-    const int nch = (Nk + 31) / 32;
-    const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
-#define FWD(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
-        if (a.drop_thr) { set_lds(attn_fwd_kernel<N, true>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, true>), grid, block, lds, stream, a); } \
-        else { set_lds(attn_fwd_kernel<N, false>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, false>), grid, block, lds, stream, a); } } while (0)
+template <int DH>
+static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
+    const int nch = (a.Nk + 31) / 32;
+    const dim3 grid((unsigned)(a.B * a.heads)), block(ATTN_THREADS);
+#define FWD(N) do { const size_t lds = (size_t)(32 * N) * (4 * DH) + (32 * N) * 4; \
+        if (a.drop_thr) { set_lds(attn_fwd_kernel<N, true, DH>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, true, DH>), grid, block, lds, stream, a); } \
+        else { set_lds(attn_fwd_kernel<N, false, DH>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, false, DH>), grid, block, lds, stream, a); } } while (0)
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
     return antmmf_check_launch();
 }
 
-extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
-                                    const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq, int Nk, long ldq, long ldk,
-                                    long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, float dropout_p,
-                                    uint64_t dropout_seed, hipStream_t stream) {
+template <int DH>
+static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
+    const int nch = (a.Nk + 31) / 32;
+    const dim3 grid((unsigned)(a.B * a.heads)), block(ATTN_THREADS);
+#define BWDQ_K(KERN, LDS) do { set_lds(KERN, LDS); hipLaunchKernelGGL(KERN, grid, block, LDS, stream, a); } while (0)
+#define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * (4 * DH) + (32 * N) * 4; \
+        if constexpr (DH == 64) { if (a.drop_thr) BWDQ_K((attn_bwd_dq64_kernel<N, true>), lds); else BWDQ_K((attn_bwd_dq64_kernel<N, false>), lds); } \
+        else { if (a.drop_thr) BWDQ_K((attn_bwd_dq_kernel<N, true, DH>), lds); else BWDQ_K((attn_bwd_dq_kernel<N, false, DH>), lds); } } while (0)
+    if (nch <= 1) BWDQ(1); else if (nch <= 3) BWDQ(3); else if (nch <= 7) BWDQ(7); else BWDQ(9);
+#undef BWDQ
+#undef BWDQ_K
+    int rc = antmmf_check_launch();
+    if (rc) return rc;
+    const int nqp = ((a.Nq + 31) / 32) * 32;
+    const size_t lds2 = (size_t)nqp * (4 * DH) + (size_t)nqp * 8;
+    if (a.drop_thr) { set_lds(attn_bwd_dkv_kernel<true, DH>, lds2); hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, DH>), grid, block, lds2, stream, a, nqp); }
+    else { set_lds(attn_bwd_dkv_kernel<false, DH>, lds2); hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, DH>), grid, block, lds2, stream, a, nqp); }
+    return antmmf_check_launch();
+}
+
+extern "C" int antmmf_attention_fwd_hd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
+                                       int B, int heads, int head_dim, int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, float scale,
+                                       float dropout_p, uint64_t dropout_seed, hipStream_t stream) {
+    AttnArgs a{};
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
+    a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)o; a.lse = lse;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (!q || !k || !v || !o || !lse || !attn_args_ok(a, head_dim)) return ANTMMF_EINVAL;
+    return head_dim == 64 ? attn_fwd_launch<64>(a, stream) : attn_fwd_launch<128>(a, stream);
+}
+
+extern "C" int antmmf_attention_bwd_hd(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
+                                       const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int head_dim, int Nq, int Nk, long ldq, long ldk,
+                                       long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, float dropout_p,
+                                       uint64_t dropout_seed, hipStream_t stream) {
     AttnArgs a{};
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
     a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
@@ -413,20 +568,22 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
     a.lse = const_cast<float*>(lse); a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
-    if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !attn_args_ok(a) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))
+    if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !attn_args_ok(a, head_dim) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))
         return ANTMMF_EINVAL;
-    const int nch = (Nk + 31) / 32;
-    const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
-#define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4; \
-        if (a.drop_thr) { set_lds(attn_bwd_dq_kernel<N, true>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N, true>), grid, block, lds, stream, a); } \
-        else { set_lds(attn_bwd_dq_kernel<N, false>, lds); hipLaunchKernelGGL((attn_bwd_dq_kernel<N, false>), grid, block, lds, stream, a); } } while (0)
-    if (nch <= 1) BWDQ(1); else if (nch <= 3) BWDQ(3); else if (nch <= 7) BWDQ(7); else BWDQ(9);
-#undef BWDQ
-    int rc = antmmf_check_launch();
-    if (rc) return rc;
-    const int nqp = ((Nq + 31) / 32) * 32;
-    const size_t lds2 = (size_t)nqp * 256 + (size_t)nqp * 8;
-    if (a.drop_thr) { set_lds(attn_bwd_dkv_kernel<true>, lds2); hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, lds2, stream, a, nqp); }
-    else { set_lds(attn_bwd_dkv_kernel<false>, lds2); hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, lds2, stream, a, nqp); }
-    return antmmf_check_launch();
+    return head_dim == 64 ? attn_bwd_launch<64>(a, stream) : attn_bwd_launch<128>(a, stream);
+}
+
+// head size 64: the entry points every tower of the contrastive path uses
+extern "C" int antmmf_attention_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
+                                    int B, int heads, int Nq, int Nk, long ldq, long ldk, long ldv, long ldo, float scale,
+                                    float dropout_p, uint64_t dropout_seed, hipStream_t stream) {
+    return antmmf_attention_fwd_hd(q, k, v, key_bias, o, lse, B, heads, 64, Nq, Nk, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, stream);
+}
+
+extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
+                                    const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int Nq, int Nk, long ldq, long ldk,
+                                    long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, float dropout_p,
+                                    uint64_t dropout_seed, hipStream_t stream) {
+    return antmmf_attention_bwd_hd(q, k, v, key_bias, o, lse, d_o, dq, dk, dv, B, heads, 64, Nq, Nk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale,
+                                   dropout_p, dropout_seed, stream);
 }

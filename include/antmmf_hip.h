@@ -163,6 +163,17 @@ int antmmf_attention_bwd(const void* q, const void* k, const void* v, const floa
                          int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                          int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed,
                          antmmf_stream_t stream);
+/* The same pair with an explicit head size: 64 or 128 (ViLBERT's bi_hidden_size 1024 / 8 heads, antmmf/models/vilbert.py:326-339); element
+ * (b, n, h, e) lives at base + (b*N + n)*ld + h*head_dim + e.  The two entry points above are head_dim = 64. */
+int antmmf_attention_fwd_hd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
+                            int B, int heads, int head_dim, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                            float scale, float dropout_p, uint64_t dropout_seed, antmmf_stream_t stream);
+int antmmf_attention_bwd_hd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
+                            const float* lse, const void* d_o, void* dq, void* dk, void* dv, int B, int heads, int head_dim, int Nq,
+                            int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                            int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed,
+                            antmmf_stream_t stream);
+
 /* dropout_p > 0: attention-probability dropout (BertSelfAttention, modeling_bert.py:157) with a counter-based mask
  * keep(seed, ((b * heads + h) * Nq + q) * Nk + k) that forward and backward regenerate identically (nothing is stored);
  * pass the same (dropout_p, dropout_seed) to both calls. */

@@ -384,29 +384,33 @@ def gen_temporal_head():
 
 def gen_vilbert_biattention():
     """antmmf/models/vilbert.py BertBiAttention (:285-416), executed unmodified (only the class body is taken from the file: the
-    module's top-level imports pull the whole antmmf package).  128-wide co-attention with 2 heads of 64, vision width 96, text width 128,
+    module's top-level imports pull the whole antmmf package).  Co-attention with 2 heads of 64 and of 128, vision width 96, text width 128,
     ragged key masks on both streams, eval-mode (dropout off) outputs and every gradient."""
     import math as _math
     src = open(f"{L.REF}/antmmf/models/vilbert.py").read()
     body = src[src.index("class BertBiAttention(nn.Module):"):src.index("class BertBiOutput(nn.Module):")]
     ns = {"nn": torch.nn, "torch": torch, "math": _math}
     exec(body, ns)
-    cfg = L.AttrDict(dict(bi_hidden_size=128, bi_num_attention_heads=2, v_hidden_size=96, hidden_size=128, v_attention_probs_dropout_prob=0.1,
-                          attention_probs_dropout_prob=0.1, visualization=False))
-    m = ns["BertBiAttention"](cfg)
-    W.fill_module_(m)
-    m.eval()
-    B, Nv, Nt = 3, 9, 14
-    x1 = (W.data_tensor("bi.x1", (B, Nv, 96)) * 0.7).requires_grad_(True)
-    x2 = (W.data_tensor("bi.x2", (B, Nt, 128)) * 0.7).requires_grad_(True)
-    len1, len2 = torch.tensor([9, 4, 7]), torch.tensor([14, 14, 5])
-    m1 = ((torch.arange(Nv)[None] >= len1[:, None]).float() * -10000.0)[:, None, None, :]
-    m2 = ((torch.arange(Nt)[None] >= len2[:, None]).float() * -10000.0)[:, None, None, :]
-    c1, c2, _ = m(x1, m1, x2, m2)
-    g1, g2 = W.data_tensor("bi.g1", (B, Nt, 128)), W.data_tensor("bi.g2", (B, Nv, 128))
-    ((c1 * g1).sum() + (c2 * g2).sum()).backward()
-    d = {"x1": x1.detach(), "x2": x2.detach(), "mask1": m1, "mask2": m2, "ctx1": c1, "ctx2": c2, "g1": g1, "g2": g2, "dx1": x1.grad, "dx2": x2.grad}
-    d.update(grads_of(m))
+    d = {}
+    # two head sizes: 64 (2 heads over 128) and 128 (2 heads over 256 -- ViLBERT's own bi_hidden_size 1024 / 8 heads ratio); keys of the second "h128."
+    for prefix, bi_hidden in (("", 128), ("h128.", 256)):
+        cfg = L.AttrDict(dict(bi_hidden_size=bi_hidden, bi_num_attention_heads=2, v_hidden_size=96, hidden_size=128, v_attention_probs_dropout_prob=0.1,
+                              attention_probs_dropout_prob=0.1, visualization=False))
+        m = ns["BertBiAttention"](cfg)
+        W.fill_module_(m)
+        m.eval()
+        B, Nv, Nt = 3, 9, 14
+        x1 = (W.data_tensor("bi.x1", (B, Nv, 96)) * 0.7).requires_grad_(True)
+        x2 = (W.data_tensor("bi.x2", (B, Nt, 128)) * 0.7).requires_grad_(True)
+        len1, len2 = torch.tensor([9, 4, 7]), torch.tensor([14, 14, 5])
+        m1 = ((torch.arange(Nv)[None] >= len1[:, None]).float() * -10000.0)[:, None, None, :]
+        m2 = ((torch.arange(Nt)[None] >= len2[:, None]).float() * -10000.0)[:, None, None, :]
+        c1, c2, _ = m(x1, m1, x2, m2)
+        g1, g2 = W.data_tensor("bi.g1", (B, Nt, bi_hidden)), W.data_tensor("bi.g2", (B, Nv, bi_hidden))
+        ((c1 * g1).sum() + (c2 * g2).sum()).backward()
+        one = {"x1": x1.detach(), "x2": x2.detach(), "mask1": m1, "mask2": m2, "ctx1": c1, "ctx2": c2, "g1": g1, "g2": g2, "dx1": x1.grad, "dx2": x2.grad}
+        one.update(grads_of(m))
+        d.update({prefix + k: v for k, v in one.items()})
     save("ops_vilbert_biattention.pt", d)
 
 

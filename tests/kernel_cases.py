@@ -342,8 +342,8 @@ def _attn_ref(qh, kh, vh, scale, key_bias):
     return oops.attention_core(qh, kh, vh, scale, key_bias)
 
 
-def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packed=True, seed=50):
-    D = heads * 64
+def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packed=True, seed=50, head_dim=64):
+    D = heads * head_dim
     if packed and Nq == Nk:
         qkv = q(rnd((B, Nq, 3 * D), seed))
         qt, kt, vt = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
@@ -357,14 +357,14 @@ def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packe
         lengths = torch.tensor([Nk, max(1, Nk // 3)] * B)[:B]
         valid = torch.arange(Nk)[None, :] < lengths[:, None]
         key_bias = torch.zeros(B, Nk).masked_fill(~valid, -10000.0 if bias_kind == "bert" else float("-inf"))
-    scale = 0.125
+    scale = head_dim ** -0.5
     d_o = q(rnd((B, Nq, D), seed + 3))
     qr, kr, vr = (t.clone().requires_grad_(True) for t in (qt, kt, vt))
     ref = oops.merge_heads(_attn_ref(oops.split_heads(qr, heads), oops.split_heads(kr, heads), oops.split_heads(vr, heads), scale, key_bias))
     ref.backward(d_o)
     kb = None if key_bias is None else key_bias.to(dev)
     o, lse = ops.attention_fwd(qd, kd, vd, heads, scale, kb)
-    tag = f"attn[{B},{heads},{Nq},{Nk},{bias_kind}]"
+    tag = f"attn[{B},{heads}x{head_dim},{Nq},{Nk},{bias_kind}]"
     check(tag + ".o", o, ref, 2e-2, 2e-2)
     s = torch.matmul(oops.split_heads(qt, heads), oops.split_heads(kt, heads).transpose(-1, -2)) * scale
     if key_bias is not None:

@@ -83,8 +83,9 @@ def test_bert_layer_dropout_vs_oracle_same_masks():
     print(mc.case_bert_layer_dropout(DEV))
 
 
-def test_vilbert_biattention_vs_reference(golden):
-    print(mc.case_vilbert_biattention(DEV, golden))
+@pytest.mark.parametrize("head_size", [64, 128])
+def test_vilbert_biattention_vs_reference(golden, head_size):
+    print(mc.case_vilbert_biattention(DEV, golden, head_size))
 
 
 def test_temporal_head_vs_oracle_and_reference(golden):

@@ -156,6 +156,12 @@ def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 
 
+def test_attention_head_size_128(ops):
+    """ViLBERT's co-attention head size (bi_hidden_size 1024 / 8 heads): 256-B token rows, its own LDS swizzle, 4 MFMAs per score tile."""
+    kc.case_attention(ops, DEV, B=1, heads=2, Nq=19, Nk=19, bias_kind="none", head_dim=128)
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=13, Nk=37, bias_kind="bert", packed=False, head_dim=128)
+
+
 def test_moco_and_ema(ops):
     kc.case_moco(ops, DEV)
     kc.case_moco(ops, DEV, R=5, Np=1, K=64)

@@ -156,6 +156,9 @@ def test_gemm_persistent_uneven_rounds(ops):
     dict(B=2, heads=16, Nq=257, Nk=257, bias_kind="none"),
     dict(B=2, heads=2, Nq=21, Nk=77, bias_kind="bert", packed=False),
     dict(B=2, heads=2, Nq=288, Nk=33, bias_kind="inf", packed=False),
+    dict(B=2, heads=8, Nq=100, Nk=100, bias_kind="none", head_dim=128),               # ViLBERT: 8 heads x 128, 100 regions
+    dict(B=3, heads=8, Nq=37, Nk=100, bias_kind="bert", packed=False, head_dim=128),  # text queries over image regions, additive mask
+    dict(B=2, heads=2, Nq=288, Nk=257, bias_kind="inf", packed=False, head_dim=128),  # the largest tiles (147 KB of LDS)
 ])
 def test_attention(ops, cfg):
     kc.case_attention(ops, DEV, **cfg)
