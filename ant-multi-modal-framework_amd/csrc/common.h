@@ -264,10 +264,21 @@ __device__ __forceinline__ void act_fwd_grad(float x, int act, float& z, float& 
     else if (ACT == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad(x, z, dz);
     else { z = act_fwd(x, act); dz = act_grad(x, act); }
 }
+// QuickGELU on two elements per lane: s = sigmoid(1.702 x), z = x s, dz = s (1 + 1.702 x (1 - s))
+__device__ __forceinline__ void quick_gelu_fwd_grad2(f2_t x, f2_t& z, f2_t& dz) {
+    const f2_t a = -1.702f * x;
+    const f2_t d = 1.0f + (f2_t){__expf(a.x), __expf(a.y)};
+    const f2_t s = (f2_t){fast_rcp(d.x), fast_rcp(d.y)};
+    z = x * s;
+    dz = s + s * (1.702f * x * (1.0f - s));
+}
+// ACT >= 0: compile-time activation; ACT = -1: the run-time id (wave-uniform branch), still on packed math for the two GELUs
 template <int ACT>
 __device__ __forceinline__ void act_fwd_grad2(f2_t x, int act, f2_t& z, f2_t& dz) {
     if (ACT == ANTMMF_ACT_NONE) { z = x; dz = f2_splat(1.0f); }
     else if (ACT == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad2(x, z, dz);
+    else if (act == ANTMMF_ACT_GELU_ERF) gelu_erf_fwd_grad2(x, z, dz);
+    else if (act == ANTMMF_ACT_QUICK_GELU) quick_gelu_fwd_grad2(x, z, dz);
     else { z = (f2_t){act_fwd(x.x, act), act_fwd(x.y, act)}; dz = (f2_t){act_grad(x.x, act), act_grad(x.y, act)}; }
 }
 

@@ -46,6 +46,7 @@ struct GemmArgs {
     float alpha;
     float* ws;   // split-K workspace [splits][I][J] fp32 (wgrad ring; NULL -> atomics)
     int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
+    int debug_nostore;  // ablations (antmmf_debug_set_gemm_variant bit 11 / 12): the staged epilogue skips its global stores / stores without the nt hint
 };
 
 
@@ -695,12 +696,12 @@ __device__ __forceinline__ void epilogue_store_bf16_staged_raw(const GemmArgs& g
         for (int pass = 0; pass < NRD; ++pass) {
             const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
             const int gi = i0 + wi * (16 * TI) + ps * TIP * 16 + row, gj = j0 + wj * (16 * TJ) + ls * 8;
-            if (gi < g.I) {
+            if (gi < g.I && g.debug_nostore != 1) {
                 bf16_t* dst = C + (long)gi * g.ldc + gj;
                 // non-temporal: the 0.5 GB output streams past an L2 that should keep the operand panels (same-box A/B of the step:
                 // 1203.5 / 1203.6 vs 1193.8 / 1195.4 pairs/s; -1..2 % cycles per tile)
 #ifndef ANTMMF_EMULATE
-                if (gj + 8 <= g.J) __builtin_nontemporal_store(val[pass], reinterpret_cast<u32x4_t*>(dst));
+                if (gj + 8 <= g.J) { if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(dst) = val[pass]; else __builtin_nontemporal_store(val[pass], reinterpret_cast<u32x4_t*>(dst)); }
 #else
                 if (gj + 8 <= g.J) *reinterpret_cast<u32x4_t*>(dst) = val[pass];
 #endif
@@ -1209,6 +1210,11 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             // bias in the fragment layout, then bf16 rows staged through this wave's 4 KiB above the ring (asm LDS traffic: pieces of the
             // next tile are in flight and hipcc would drain them in front of any LDS access it can see)
             if (EPI & 1) epilogue_apply_operands<TI, TJ, EPI & 1>(g, acc, i0, j0, wi, wj, lane);
+            // (Measured and not kept: vmcnt is ONE in-order counter for LDS-DMA pieces and stores, so behind the 16 stores below the next tile's first
+            // waits sit on the stores -- an ablation without the stores gains 6 ... 12 % on the R = 1024 shapes.  Issuing the next tile's first two
+            // pieces in front of the stores and letting its first five waits allow 16 more operations in flight (every piece they cover is older
+            // than the stores) kept the results bit-identical and made every shape 1.5 ... 4 % SLOWER: the vector-memory path itself is in order,
+            // the pieces queue behind the store burst whatever the counter allows.  profiles/r2_gemm_store_ablation.txt)
             epilogue_store_bf16_staged_raw<TI, TJ, 4>(g, acc, i0, j0, wi, wj, lane, smem + 2 * STAGE + wave * 4096);
         } else {
             // ---- epilogue straight from the accumulators.  lane (l15, grp) holds out[i = it 16 + l15][j = jt 16 + 4 PB(grp) + r],
@@ -1262,13 +1268,23 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                             const u32x4_t av = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                             *reinterpret_cast<u32x4_t*>(g.aux + row * g.ldaux + col) = av;
                         }
+                        // activation / its derivative on two elements per VALU slot: with scalar fp32 code this epilogue cost more issue cycles
+                        // than a 12-K-tile main loop (fc1 of the ViT-B/16 tower: 632 TFLOP/s against 1300 for the plain shapes)
                         if (g.gate) {
                             const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g.gate + row * g.ldgate + col);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[2 * e] *= act_grad(bf_lo(gv[e]), g.act); v[2 * e + 1] *= act_grad(bf_hi(gv[e]), g.act); }
+                            for (int e = 0; e < 4; ++e) {
+                                f2_t z_unused, dz;
+                                act_fwd_grad2<-1>(f2_bf(gv[e]), g.act, z_unused, dz);
+                                v[2 * e] *= dz.x; v[2 * e + 1] *= dz.y;
+                            }
                         } else if (g.act != ANTMMF_ACT_NONE) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], g.act);
+                            for (int e = 0; e < 4; ++e) {
+                                f2_t z, dz_unused;
+                                act_fwd_grad2<-1>((f2_t){v[2 * e], v[2 * e + 1]}, g.act, z, dz_unused);
+                                v[2 * e] = z.x; v[2 * e + 1] = z.y;
+                            }
                         }
                     }
                     if (RES || (GENERIC && g.residual)) {
@@ -1644,6 +1660,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
     static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");
     g.raster = raster_env ? atoi(raster_env) : 1;
+    g.debug_nostore = g_gemm_variant > 0 ? ((g_gemm_variant & 2048) ? 1 : (g_gemm_variant & 4096) ? 2 : 0) : 0;
     const int splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     const long tiles = (long)((I + 127) / 128) * ((J + 127) / 128);
     if (tiles > 0x7fffffffL) return ANTMMF_EINVAL;
