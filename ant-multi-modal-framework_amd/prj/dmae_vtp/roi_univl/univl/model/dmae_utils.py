@@ -109,11 +109,23 @@ class LinearXWeightPredictor(nn.Module):
         self.attn_proj = nn.Sequential(nn.LayerNorm([num_tokens, embed_dim * 2]), nn.Linear(embed_dim * 2, embed_dim // 2, bias=False), nn.GELU(),
                                        nn.Linear(embed_dim // 2, 1, bias=False), nn.Sigmoid())
 
+    # rows (pairs x tokens) from which the 2D -> D/2 Linear of the MLP runs on the bf16 MFMA GEMM (fp32 accumulation) instead of torch's fp32 matmul:
+    # with all 8 x 16 blocks of a step batched it is 0.26 TFLOP per predictor and direction, and a rocBLAS fp32 GEMM on it was 5 % of the dmae12 step.
+    # (The reference applies .float() to the inputs, but under its autocast context F.linear runs in bf16 there as well.)  None: never.
+    MFMA_MIN_ROWS = 8192
+
     def forward(self, q, k):
         if not self._qk_same_embed_dim:
             q, k = self.q_proj(q), self.k_proj(k)
         q = self.qk_proj(q.float().transpose(-2, -1)).transpose(-1, -2)
-        w = self.attn_proj(torch.cat([q, k.float()], dim=-1)).squeeze(-1)
+        x = torch.cat([q, k.float()], dim=-1)
+        rows = x.shape[0] * x.shape[1]
+        if self.MFMA_MIN_ROWS is not None and rows >= self.MFMA_MIN_ROWS and x.shape[-1] % 64 == 0:
+            ln, fc_a, act, fc_b, sig = self.attn_proj
+            h = HF.linear(ln(x).to(torch.bfloat16), fc_a.weight)
+            w = sig(fc_b(act(h.float()))).squeeze(-1)
+        else:
+            w = self.attn_proj(x).squeeze(-1)
         return w / w.sum(dim=1, keepdim=True)
 
 

@@ -588,7 +588,37 @@ def case_dmae_tpmcl_blocks(dev, sim_header="meanP"):
     assert set(g0) == set(g1)
     for n in g0:
         torch.testing.assert_close(g1[n], g0[n], rtol=5e-3, atol=1e-6 + 5e-3 * float(g0[n].abs().max()), msg=n)
-    return dict(loss=(l0, l1), params=len(g0))
+    # the weight predictors' 2D -> D/2 Linear on the bf16 MFMA GEMM (what the product does from 8192 pair-tokens on; forced here): same loss to 1e-3,
+    # every gradient within bf16 distance of the fp32-matmul run
+    du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header=sim_header, l3_partial_type=4,
+                                          l3_max_frames=V, l3_max_words=Nw)))
+    W.fill_module_(du)
+    du.tis_selector.thresh.fill_(0.6)
+    du = du.to(dev).train()
+    saved = mod.LinearXWeightPredictor.MFMA_MIN_ROWS
+    mod.LinearXWeightPredictor.MFMA_MIN_ROWS = 0
+    try:
+        t = norm(W.data_tensor("tpmb.text", (Bt, 1, D))).to(dev).requires_grad_(True)
+        w_ = norm(W.data_tensor("tpmb.word", (Bt, Nw, D))).to(dev).requires_grad_(True)
+        v = norm(W.data_tensor("tpmb.video", (Bv, V + 1, D))).to(dev).requires_grad_(True)
+        loss = du.get_partial_similarity((t, w_), v, wm, vm, 4)
+        loss.backward()
+    finally:
+        mod.LinearXWeightPredictor.MFMA_MIN_ROWS = saved
+    assert abs(float(loss) - l1) <= 1e-3 * abs(l1), (float(loss), l1)
+    g2 = {n: p.grad for n, p in du.named_parameters() if p.grad is not None}
+    assert set(g2) == set(g1)
+    worst = 1.0
+    top = max(float(x.float().norm()) for x in g1.values())
+    for nm, a, b in [("dtext", dt1, t.grad), ("dword", dw1, w_.grad), ("dvideo", dv1, v.grad)] + [(n, g1[n], g2[n]) for n in g1]:
+        a, b = a.float().flatten(), b.float().flatten()
+        if float(a.norm()) < 1e-4 * top:   # e.g. the weight heads' biases: zero by the shift invariance of the masked softmax
+            assert float(b.norm()) < 1e-3 * top, (nm, float(b.norm()))
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        worst = min(worst, cos)
+        assert cos >= 0.99 and abs(float(b.norm()) - float(a.norm())) <= 0.05 * float(a.norm()), (nm, cos, float(a.norm()), float(b.norm()))
+    return dict(loss=(l0, l1, float(loss)), params=len(g0), bf16_predictor_min_cos=worst)
 
 
 def case_dmae_wti(dev, golden):
