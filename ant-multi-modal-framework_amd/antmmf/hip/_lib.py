@@ -31,6 +31,7 @@ _SIGNATURES = {
     "antmmf_l2norm_bwd": [P, P, P, P, L, I, I, I, P],
     "antmmf_colsum": [P, P, L, I, L, I, P],
     "antmmf_transpose_bf16": [P, P, I, I, P],
+    "antmmf_transpose_bf16_batched": [P, P, P, I, L, P],
     "antmmf_cast_f32_bf16": [P, P, L, P],
     "antmmf_patchify": [P, P, I, I, I, I, I, I, F, F, I, P],
     "antmmf_assemble_tokens": [P, P, P, P, P, L, I, I, P],

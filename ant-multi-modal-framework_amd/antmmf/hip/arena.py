@@ -205,9 +205,10 @@ class HipAdamW(torch.optim.Optimizer):
             b1, b2 = g["betas"]
             ops.adamw_step_(a.master[s:e], a.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.shadow[s:e], g["lr"], b1, b2,
                             g["eps"], g["weight_decay"], self._step, self.grad_scale)
-        from .functional import bump_weight_version
+        from .functional import bump_weight_version, refresh_transposes
 
         bump_weight_version()
+        refresh_transposes(a)   # the transposed weight copies of the next backward, one launch
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -60,7 +60,10 @@ def bump_weight_version():
 
 def compute_copy_t(p):
     """bf16 TRANSPOSE of a 2-D master weight ([out, in] -> [in, out]); lets dgrad (dX = dY W) run the all-r-contiguous
-    LDS-DMA GEMM.  Cached on the parameter until the next optimizer step (weights are tiny next to activations)."""
+    LDS-DMA GEMM.  Cached on the parameter until the next optimizer step (weights are tiny next to activations).  Arena parameters that
+    asked for it once are re-transposed by the optimizer step in ONE launch (refresh_transposes) instead of one launch each here."""
+    if getattr(p, "_antmmf_bf16", None) is not None and getattr(p, "_antmmf_ver", None) != p._version:
+        compute_copy(p)          # an out-of-band write to the master: refreshes the shadow and bumps the weight version
     ver = _T_CACHE_VERSION[0]
     c = getattr(p, "_antmmf_bf16_t", None)
     if c is not None and c[0] == ver and getattr(p, "_antmmf_main_grad", None) is not None:
@@ -68,9 +71,43 @@ def compute_copy_t(p):
     t = ops.transpose_bf16(compute_copy(p).contiguous())
     try:
         p._antmmf_bf16_t = (ver, t)
+        arena = getattr(p, "_antmmf_arena", None)
+        if arena is not None and p.dim() == 2:
+            reg = arena.__dict__.setdefault("_t_registry", {})
+            reg.setdefault(id(p), p)
     except AttributeError:
         pass
     return t
+
+
+def refresh_transposes(arena):
+    """After an optimizer step (the bf16 shadow is fresh, the weight version just bumped): every transposed copy that the previous step's
+    backward asked for, in one launch out of the arena's shadow into one persistent buffer."""
+    reg = getattr(arena, "_t_registry", None)
+    if not reg:
+        return
+    plan = getattr(arena, "_t_plan", None)
+    if plan is None or plan["count"] != len(reg):
+        params = list(reg.values())
+        rows, tiles, out_off = [], 0, 0
+        for p in params:
+            r, c = p.shape
+            rows.append([p._antmmf_offset, out_off, r, c, tiles])
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+            out_off += (r * c + 7) // 8 * 8
+        dev = arena.shadow.device
+        plan = dict(count=len(reg), params=params, tiles=tiles, table=torch.tensor(rows, dtype=torch.int64, device=dev).contiguous(),
+                    out=torch.empty(out_off, dtype=BF, device=dev), offs=[r[1] for r in rows])
+        arena._t_plan = plan
+    ver = _T_CACHE_VERSION[0]
+    stale = [p for p in plan["params"] if getattr(p, "_antmmf_ver", None) != p._version]
+    for p in stale:          # a parameter written outside the optimizer since: its shadow is refreshed by compute_copy, per parameter
+        compute_copy(p)
+    ver = _T_CACHE_VERSION[0]
+    ops.transpose_bf16_batched(arena.shadow, plan["out"], plan["table"], plan["count"], plan["tiles"])
+    for p, off in zip(plan["params"], plan["offs"]):
+        r, c = p.shape
+        p._antmmf_bf16_t = (ver, plan["out"][off:off + r * c].view(c, r))
 
 
 def dgrad(dy2d, weight, weight_layout="oi", **epi):

@@ -181,6 +181,14 @@ def transpose_bf16(x):
     return out
 
 
+def transpose_bf16_batched(in_base, out_base, table, n_mats, total_tiles):
+    """out_base[out_off : out_off + rows * cols] = in_base[in_off : ...].view(rows, cols).t() for every row of `table` (see antmmf_hip.h)."""
+    _dev_ok(in_base, out_base, table)
+    assert in_base.dtype == torch.bfloat16 and out_base.dtype == torch.bfloat16 and table.dtype == torch.int64 and table.is_contiguous()
+    _rc(_lib.load().antmmf_transpose_bf16_batched(_p(in_base), _p(out_base), _p(table), int(n_mats), int(total_tiles), _stream()),
+        "antmmf_transpose_bf16_batched")
+
+
 def cast_bf16(x, out=None):
     _dev_ok(x, out); _c(x, "x"); _f32(x, "x")
     if out is None:

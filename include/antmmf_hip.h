@@ -83,6 +83,10 @@ int antmmf_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void
 int antmmf_colsum(const void* x, float* out, int64_t rows, int cols, int64_t ld, int dtype, antmmf_stream_t stream);
 /* ---- out[c][r] = in[r][c] for a bf16 matrix. */
 int antmmf_transpose_bf16(const void* in, void* out, int rows, int cols, antmmf_stream_t stream);
+/* All transposed weight copies of a step in one launch.  table (device memory): 5 int64 per matrix = element offset into in_base, element
+ * offset into out_base, rows, cols, index of the matrix's first 64 x 64 tile; total_tiles = sum of ceil(rows/64) * ceil(cols/64). */
+int antmmf_transpose_bf16_batched(const void* in_base, void* out_base, const int64_t* table, int n_mats, int64_t total_tiles,
+                                  antmmf_stream_t stream);
 /* ---- flat fp32 -> bf16 cast. */
 int antmmf_cast_f32_bf16(const float* in, void* out, int64_t n, antmmf_stream_t stream);
 

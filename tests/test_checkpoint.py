@@ -218,3 +218,31 @@ def test_hip_adamw_loads_reference_torch_adamw_state(tmp_path):
     with pytest.raises(ValueError):
         tr.optimizer.load_state_dict({"state": {0: dict(step=torch.tensor(1.0), exp_avg=torch.zeros(3), exp_avg_sq=torch.zeros(3))},
                                       "param_groups": tr.optimizer.state_dict()["param_groups"]})
+
+
+def test_optimizer_step_refreshes_transposed_weight_copies_in_one_launch():
+    """The transposed bf16 weight copies dgrad uses (compute_copy_t) are re-made by HipAdamW.step() for every arena parameter that asked for one --
+    a single batched launch out of the fresh shadow -- and are exactly shadow.t(); an out-of-band write still invalidates them."""
+    from antmmf.hip import functional as F
+    from antmmf.hip.arena import HipAdamW
+
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(70, 130, generator=g)), torch.nn.Parameter(torch.randn(64, 64, generator=g)),
+          torch.nn.Parameter(torch.randn(130, generator=g)), torch.nn.Parameter(torch.randn(9, 200, generator=g))]
+    opt = HipAdamW([{"params": ps}], lr=1e-2, weight_decay=0.01)
+    for p in (ps[0], ps[1], ps[3]):
+        t = F.compute_copy_t(p)                                   # first use: per-parameter launch, registers the parameter
+        assert torch.equal(t, F.compute_copy(p).t())
+    for step in range(2):
+        for p in ps:
+            p.grad.copy_(torch.randn(p.shape, generator=g))
+        opt.step()
+        for p in (ps[0], ps[1], ps[3]):
+            ver, t = p._antmmf_bf16_t
+            assert ver == F._T_CACHE_VERSION[0] and t.shape == (p.shape[1], p.shape[0])
+            assert torch.equal(t, F.compute_copy(p).t()), step     # the batched launch wrote shadow.t()
+            assert F.compute_copy_t(p) is t                        # and the backward pass finds it: no launch of its own
+    with torch.no_grad():
+        ps[0].clamp_(-0.1, 0.1)                                    # a write the optimizer did not make
+    t = F.compute_copy_t(ps[0])
+    assert float(t.float().abs().max()) <= 0.1 + 1e-3 and torch.equal(t, F.compute_copy(ps[0]).t())
