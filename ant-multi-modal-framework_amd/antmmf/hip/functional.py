@@ -387,8 +387,10 @@ class _TransformerLayer(torch.autograd.Function):
             g_n, mf, rf = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, act=spec.act)
             st_f = (mf, rf)
         else:
+            # u: the pre-activation -- or, when the activation output itself is kept for backward (KEEP_FFN_NORM), act'(pre-activation): the
+            # backward then needs no transcendental in the dgrad epilogue (the GELU-derivative epilogue ran at half the speed of the plain ones)
             u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
-            g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u)
+            g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u, aux_grad=KEEP_FFN_NORM)
         res = mid if pre_ln else h2
         if p_hid > 0:
             y = ops.dropout_add(ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"])), p_hid, seed + 2, residual=res)
@@ -409,6 +411,7 @@ class _TransformerLayer(torch.autograd.Function):
         saved.append(kept_gn)
         ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.shape, ctx.nsaved, ctx.drop = spec, (B, N, d), len(saved), (p_att, p_hid, seed)
+        ctx.u_is_grad = bool(KEEP_FFN_NORM and spec.kind != "m2")
         return y.view(B, N, d)
 
     @staticmethod
@@ -467,7 +470,7 @@ class _TransformerLayer(torch.autograd.Function):
             del dgn
         else:
             b1_fused = False
-            du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act)  # (d(dense out) W2) * act'(u)
+            du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act, gate_is_grad=ctx.u_is_grad)  # (d(dense out) W2) * act'(u)
         # The normalised tensors the wgrads need (h2, o_n, h) are not kept by the forward pass and not recomputed either: the LayerNorm
         # backward of the same tensor re-emits them (layernorm_bwd_renorm: one extra write instead of a read + write pass).
         ln_mid = ("ln2" if pre_ln else "ln1")

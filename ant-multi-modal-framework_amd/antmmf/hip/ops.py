@@ -278,9 +278,10 @@ GEMM_TRACE = None
 
 
 def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None,
-         residual=None, aux=None, gate=None, accumulate=False, split_k=1):
+         residual=None, aux=None, gate=None, accumulate=False, split_k=1, aux_grad=False, gate_is_grad=False):
     """out[i, j] = epi(alpha * sum_r P[i, r] Q[j, r]).  P is [I, R] (or [R, I] when p_rmajor), Q likewise.
-    2-D operands with unit inner stride; row strides are passed through (views of packed buffers are fine)."""
+    2-D operands with unit inner stride; row strides are passed through (views of packed buffers are fine).
+    aux_grad: `aux` receives act'(pre-activation) instead of the pre-activation; gate_is_grad: `gate` holds act' already."""
     _dev_ok(P, Q, out, bias, residual, aux, gate)
     for t, n in ((P, "P"), (Q, "Q")):
         if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
@@ -306,7 +307,8 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     _rc(_lib.load().antmmf_gemm_bf16(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0),
-                                     int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias), ACT_IDS[act],
+                                     int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias),
+                                     ACT_IDS[act] | (0x100 if aux_grad else 0) | (0x200 if gate_is_grad else 0),
                                      _p(residual), ld(residual), _p(aux), ld(aux), _p(gate), ld(gate), int(accumulate),
                                      int(split_k), _stream()), "antmmf_gemm_bf16")
     if ev is not None:

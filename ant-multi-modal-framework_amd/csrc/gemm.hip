@@ -46,6 +46,7 @@ struct GemmArgs {
     float alpha;
     float* ws;   // split-K workspace [splits][I][J] fp32 (wgrad ring; NULL -> atomics)
     int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
+    int aux_grad, gate_grad;  // ANTMMF_ACT_AUX_GRAD: aux receives act'(pre-activation) instead of the pre-activation; ANTMMF_ACT_GATE_GRAD: gate holds act' already
     int debug_nostore;  // ablations (antmmf_debug_set_gemm_variant bit 11 / 12): the staged epilogue skips its global stores / stores without the nt hint
 };
 
@@ -109,11 +110,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
-            if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (g.aux) {
+                if (g.aux_grad) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(act_grad(v[0], g.act), act_grad(v[1], g.act)), pack_bf2(act_grad(v[2], g.act), act_grad(v[3], g.act)));
+                else *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
             if (g.gate) {
                 const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
-                v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
-                v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+                if (g.gate_grad) { v[0] *= bf_lo(u.x); v[1] *= bf_hi(u.x); v[2] *= bf_lo(u.y); v[3] *= bf_hi(u.y); }
+                else {
+                    v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
+                    v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+                }
             } else if (g.act != ANTMMF_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
@@ -180,11 +187,17 @@ __device__ __forceinline__ void gemm_epilogue_bf16_staged(const GemmArgs& g, f32
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
             if (GENERIC) {
-                if (g.aux) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (g.aux) {
+                    if (g.aux_grad) *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(act_grad(v[0], g.act), act_grad(v[1], g.act)), pack_bf2(act_grad(v[2], g.act), act_grad(v[3], g.act)));
+                    else *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
                 if (g.gate) {
                     const uint2 u = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
-                    v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
-                    v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+                    if (g.gate_grad) { v[0] *= bf_lo(u.x); v[1] *= bf_hi(u.x); v[2] *= bf_lo(u.y); v[3] *= bf_hi(u.y); }
+                    else {
+                        v[0] *= act_grad(bf_lo(u.x), g.act); v[1] *= act_grad(bf_hi(u.x), g.act);
+                        v[2] *= act_grad(bf_lo(u.y), g.act); v[3] *= act_grad(bf_hi(u.y), g.act);
+                    }
                 } else if (g.act != ANTMMF_ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], g.act);
@@ -1264,8 +1277,16 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                             const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col), b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
                             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                         }
+                        f2_t zz[4], dd[4];   // activation and derivative of the four value pairs (both come out of one evaluation)
+                        const bool want_act = !g.gate && g.act != ANTMMF_ACT_NONE;
+                        if (want_act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) act_fwd_grad2<-1>((f2_t){v[2 * e], v[2 * e + 1]}, g.act, zz[e], dd[e]);
+                        }
                         if (g.aux) {
-                            const u32x4_t av = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                            u32x4_t av;
+                            if (g.aux_grad && want_act) av = (u32x4_t){pack_bf2(dd[0].x, dd[0].y), pack_bf2(dd[1].x, dd[1].y), pack_bf2(dd[2].x, dd[2].y), pack_bf2(dd[3].x, dd[3].y)};
+                            else av = (u32x4_t){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                             *reinterpret_cast<u32x4_t*>(g.aux + row * g.ldaux + col) = av;
                         }
                         // activation / its derivative on two elements per VALU slot: with scalar fp32 code this epilogue cost more issue cycles
@@ -1274,17 +1295,13 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                             const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g.gate + row * g.ldgate + col);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                f2_t z_unused, dz;
-                                act_fwd_grad2<-1>(f2_bf(gv[e]), g.act, z_unused, dz);
+                                f2_t z_unused, dz = f2_bf(gv[e]);   // gate_grad: the forward pass stored act'(pre-activation) itself
+                                if (!g.gate_grad) act_fwd_grad2<-1>(f2_bf(gv[e]), g.act, z_unused, dz);
                                 v[2 * e] *= dz.x; v[2 * e + 1] *= dz.y;
                             }
-                        } else if (g.act != ANTMMF_ACT_NONE) {
+                        } else if (want_act) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                f2_t z, dz_unused;
-                                act_fwd_grad2<-1>((f2_t){v[2 * e], v[2 * e + 1]}, g.act, z, dz_unused);
-                                v[2 * e] = z.x; v[2 * e + 1] = z.y;
-                            }
+                            for (int e = 0; e < 4; ++e) { v[2 * e] = zz[e].x; v[2 * e + 1] = zz[e].y; }
                         }
                     }
                     if (RES || (GENERIC && g.residual)) {
@@ -1656,6 +1673,8 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.C = C; g.bias = bias; g.residual = (const bf16_t*)residual;
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
+    g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
+    act &= 0xff;
     g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha; g.ws = nullptr;
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
     static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");

@@ -30,6 +30,11 @@ extern "C" {
 #define ANTMMF_ACT_GELU_ERF 1   /* modeling_bert.py:31-37; torchscale feedforward_network.py:80-86,120 */
 #define ANTMMF_ACT_QUICK_GELU 2 /* clip/model.py:222-224 */
 #define ANTMMF_ACT_RELU 3
+/* OR-ed into the `act` argument of antmmf_gemm_bf16 (the activation id is act & 0xff):
+ *   AUX_GRAD:  `aux` receives act'(pre-activation) instead of the pre-activation (forward of an FFN whose activation output is kept);
+ *   GATE_GRAD: `gate` already holds act'(...) -- the epilogue multiplies by it as is (the matching dgrad: no transcendental in the epilogue). */
+#define ANTMMF_ACT_AUX_GRAD 0x100
+#define ANTMMF_ACT_GATE_GRAD 0x200
 
 typedef void* antmmf_stream_t; /* hipStream_t */
 

@@ -227,6 +227,17 @@ def case_gemm(ops, dev, I=70, J=40, R=72):
     ur = u.clone().requires_grad_(True)
     oops.gelu_erf(ur).backward(dY @ Wt)
     check("gemm.nn.gate", dx, ur.grad, 2e-2, 1e-2)
+    # the same pair with the derivative handed over instead of the pre-activation: forward aux = act'(pre), dgrad gate = that derivative
+    for act, fn in (("quick_gelu", oops.quick_gelu), ("gelu", oops.gelu_erf)):
+        aux2 = torch.empty(I, J, dtype=BF, device=dev)
+        y2 = ops.gemm(Xd, Wd, bias=bias.to(dev), act=act, aux=aux2, aux_grad=True)
+        pr = pre.clone().requires_grad_(True)
+        fn(pr).backward(torch.ones_like(pre))
+        check(f"gemm.nt.aux_grad.{act}", aux2, pr.grad, 2e-2, 1e-2)
+        check(f"gemm.nt.aux_grad.{act}.y", y2, fn(pre), 2e-2, 1e-2)
+        d = q(rnd((I, R), 46)) * 0.5 + 0.5
+        dx2 = ops.gemm(dY.to(dev, BF), Wd, q_rmajor=True, gate=d.to(dev, BF), act=act, gate_is_grad=True)
+        check(f"gemm.nn.gate_is_grad.{act}", dx2, (dY @ Wt) * d, 2e-2, 1e-2)
     # wgrad: dW = dY^T X  (both r-major, reduction over tokens), fp32 accumulate, with and without split-k
     for split in (1, 2):
         dw = torch.full((J, R), 0.25, device=dev)
@@ -315,6 +326,14 @@ def case_gemm_k64(ops, dev, I=512, J=512, R=192, quick=False):
     ur = u.clone().requires_grad_(True)
     oops.gelu_erf(ur).backward(ref)
     check("gemm.k64.gate", dx, ur.grad, 2e-2, 1e-2)
+    aux2 = torch.empty(I, J, dtype=BF, device=dev)
+    y2 = ops.gemm(Xd, Wd, bias=bias.to(dev), act="gelu", aux=aux2, aux_grad=True)
+    pr = (ref + bias).clone().requires_grad_(True)
+    oops.gelu_erf(pr).backward(torch.ones_like(ref))
+    check("gemm.k64.aux_grad", aux2, pr.grad, 2e-2, 1e-2)
+    check("gemm.k64.aux_grad.y", y2, oops.gelu_erf(ref + bias), 2e-2, 1e-2)
+    dx2 = ops.gemm(Xd, Wd, gate=u.to(dev, BF), act="gelu", gate_is_grad=True)
+    check("gemm.k64.gate_is_grad", dx2, ref * u, 2e-2, 1e-2)
     packed = torch.zeros(I, 2 * J, dtype=BF, device=dev)
     ops.gemm(Xd, Wd, out=packed[:, J:])
     check("gemm.k64.ldc", packed[:, J:], ref, 2e-2, 1e-2)

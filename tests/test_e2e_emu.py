@@ -45,6 +45,17 @@ def test_univl_stage1_two_clips(golden):
 
 
 @SLOW
+def test_univl_stage1_activation_output_kept(golden):
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    try:
+        print(mc.case_univl_stage1(torch.device("cpu"), golden, "b4n1", 1))
+    finally:
+        functional.set_keep_ffn_norm(False)
+
+
+@SLOW
 def test_m2_towers_vs_reference(golden):
     print(mc.case_m2_towers(torch.device("cpu"), golden))
 

@@ -27,6 +27,18 @@ def test_univl_stage1_two_clips(golden):
     print(mc.case_univl_stage1(DEV, golden, "b3n2", 2))
 
 
+def test_univl_stage1_activation_output_kept(golden):
+    """The CLIP / BERT FFNs with the activation output kept for backward (what the video workloads of bench.py run): the forward GEMM stores
+    act'(pre-activation) next to it and the dgrad epilogue multiplies by that -- same reference goldens, same gates."""
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    try:
+        print(mc.case_univl_stage1(DEV, golden, "b4n1", 1))
+    finally:
+        functional.set_keep_ffn_norm(False)
+
+
 def test_m2_towers_vs_reference(golden):
     print(mc.case_m2_towers(DEV, golden))
 
