@@ -978,7 +978,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                    ONEBAR = FLAGS & K64F_ONEBAR;
     // residual / generic epilogues run from registers (permuted Q rows + lane swap, 16-B accesses of 64-B row segments: the residual is read
     // coalesced); plain / bias epilogues stage through the 32 KiB of LDS above the ring (128-B row segments)
-    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4;
+    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4 || EPI == 8;   // EPI 8: out = acc * gate (the dgrad through an activation whose derivative was stored)
     const int lane = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
         } else {
             // ---- epilogue straight from the accumulators.  lane (l15, grp) holds out[i = it 16 + l15][j = jt 16 + 4 PB(grp) + r],
             // PB = {0, 2, 1, 3}; after the swap it holds 8 consecutive columns of fragment 2 p + (lane >> 5) at (grp & 1) * 8.
-            constexpr bool GENERIC = EPI == 4, BIAS = EPI & 1, RES = EPI & 2;
+            constexpr bool GENERIC = EPI == 4, GATEMUL = EPI == 8, BIAS = (EPI & 1) && !GATEMUL, RES = (EPI & 2) && !GATEMUL;
             const int pbg = ((grp & 1) << 1) | (grp >> 1);
             const int jw = j0 + wj * 64, iw = i0 + wi * 128 + l15;
             if (BIAS && !GENERIC) {
@@ -1252,11 +1252,13 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 u32x4_t rv[NV];
-                if (RES || (GENERIC && g.residual)) {
+                if (RES || GATEMUL || (GENERIC && g.residual)) {
+                    const bf16_t* rbase = GATEMUL ? g.gate : g.residual;
+                    const long rld = GATEMUL ? g.ldgate : g.ldr;
 #pragma unroll
                     for (int q = 0; q < NV; ++q) {
                         const int it = h * (NV / 2) + (q >> 1), p2 = q & 1;
-                        rv[q] = *reinterpret_cast<const u32x4_t*>(g.residual + (long)(iw + it * 16) * g.ldr + cj + 32 * p2);
+                        rv[q] = *reinterpret_cast<const u32x4_t*>(rbase + (long)(iw + it * 16) * rld + cj + 32 * p2);
                     }
                 }
 #pragma unroll
@@ -1304,7 +1306,10 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                             for (int e = 0; e < 4; ++e) { v[2 * e] = zz[e].x; v[2 * e + 1] = zz[e].y; }
                         }
                     }
-                    if (RES || (GENERIC && g.residual)) {
+                    if (GATEMUL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[2 * e] *= bf_lo(rv[q][e]); v[2 * e + 1] *= bf_hi(rv[q][e]); }
+                    } else if (RES || (GENERIC && g.residual)) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rv[q][e]); v[2 * e + 1] += bf_hi(rv[q][e]); }
                     }
@@ -1744,6 +1749,13 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \
     } while (0)
+        if (k64p && gate && g.gate_grad && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {
+            // out = acc * gate on the register-level epilogue of the residual kernels (16 gate vectors requested up front) instead of the generic one
+            ++g_k64_launches;
+            const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);
+            const unsigned gridp = pwgs < t8 ? pwgs : t8;
+            K64P_LAUNCH(8, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
+        } else
         switch (epi) {
             case 0: LAUNCH_NT(0); break;
             case 1: LAUNCH_NT(1); break;
