@@ -129,6 +129,35 @@ class LinearXWeightPredictor(nn.Module):
         return w / w.sum(dim=1, keepdim=True)
 
 
+    def forward_all_pairs(self, q_items, k_items):
+        """forward(q, k) for EVERY (k item, q item) pair without materialising the pair batch: -> [n_k, n_q, tokens].
+
+        The slab of a pair is cat(q'_j, k_i) with q' = qk_proj(q_j) depending on the q item only and k_i on the k item only, so
+          * its LayerNorm statistics are sums of per-item sums:  mu_ij = (s1q_j + s1k_i) / N,  E[x^2]_ij = (s2q_j + s2k_i) / N;
+          * the first Linear of the MLP is linear in the slab:  h_ij = r_ij (A_j + B_i) - r_ij mu_ij c + d  with
+            A_j = (gamma_q * q'_j) W_q^T,  B_i = (gamma_k * k_i) W_k^T  (one small GEMM per ITEM, not per pair),  c = gamma W^T,  d = beta W^T.
+        What is left per pair is the elementwise tail (GELU, the D/2 -> 1 dot, sigmoid, normalisation over the tokens).  The reference
+        (tpmcl_utils.py:35-50) evaluates the same function pair by pair on repeat / repeat_interleave copies; fp32 throughout, the result
+        differs from the pair-batch evaluation by summation order only."""
+        ln, fc_a, act, fc_b, sig = self.attn_proj
+        D = self.embed_dim
+        qp = self.qk_proj(q_items.float().transpose(-2, -1)).transpose(-1, -2)          # [n_q, T, D]
+        kf = k_items.float()                                                            # [n_k, T, D]
+        N = float(qp.shape[1] * 2 * D)
+        s1 = kf.sum(dim=(1, 2))[:, None] + qp.sum(dim=(1, 2))[None, :]                   # [n_k, n_q]
+        s2 = (kf * kf).sum(dim=(1, 2))[:, None] + (qp * qp).sum(dim=(1, 2))[None, :]
+        mu = s1 / N
+        r = torch.rsqrt((s2 / N - mu * mu).clamp_min(0.0) + ln.eps)
+        gam, bet, W = ln.weight.float(), ln.bias.float(), fc_a.weight.float()            # [T, 2D], [T, 2D], [D/2, 2D]
+        A = torch.matmul(qp * gam[None, :, :D], W[:, :D].t())                            # [n_q, T, D/2]
+        Bm = torch.matmul(kf * gam[None, :, D:], W[:, D:].t())                           # [n_k, T, D/2]
+        c = torch.matmul(gam, W.t())                                                     # [T, D/2]
+        d = torch.matmul(bet, W.t())
+        h = r[:, :, None, None] * (Bm[:, None] + A[None, :]) - (r * mu)[:, :, None, None] * c + d     # [n_k, n_q, T, D/2]
+        w = sig(fc_b(act(h))).squeeze(-1)                                                # [n_k, n_q, T]
+        return w / w.sum(dim=-1, keepdim=True)
+
+
 class TokenImportanceSelector(nn.Module):
     """Zero the most important tokens: those whose cumulative weight (descending order) is still below `thresh`
     (reference: tpmcl_utils.py:101-121).  Returns (masked tokens, keep policy)."""
@@ -358,8 +387,16 @@ class DmaeUtils(nn.Module):
         words_i, wmask_i = cap(words, False), cap(attention_mask, False)
         vis_i, vmask_i = vid(visual_output, False), vid(video_mask, False)
         vis_j, vmask_j = vid(visual_output, True), vid(video_mask, True)
-        word_w = self.v2t_linear_xwp(vis_i, words_i)
-        frame_w = self.t2v_linear_xwp(sent_j, vis_j)
+        if self.v2t_linear_xwp._qk_same_embed_dim and self.t2v_linear_xwp._qk_same_embed_dim and not self.config.get("l3_xwp_pair_batch", False):
+            # token-importance weights of all B_t x B_v pairs from per-caption / per-video pieces (LinearXWeightPredictor.forward_all_pairs),
+            # then laid out in the pair orders the rest of this function uses: caption-major [a, b, i, j] / video-major [a, b, j, i]
+            ww = self.v2t_linear_xwp.forward_all_pairs(visual_output, words)             # [B_t, B_v, Nw]   (k = words of caption i, q = video j)
+            fw = self.t2v_linear_xwp.forward_all_pairs(sent, visual_output)              # [B_v, B_t, V]    (k = frames of video j, q = caption i)
+            word_w = ww.reshape(nbt, bt, nbv, bv, -1).permute(0, 2, 1, 3, 4).reshape(nb * bt * bv, -1)
+            frame_w = fw.reshape(nbv, bv, nbt, bt, -1).permute(2, 0, 1, 3, 4).reshape(nb * bt * bv, -1)
+        else:
+            word_w = self.v2t_linear_xwp(vis_i, words_i)
+            frame_w = self.t2v_linear_xwp(sent_j, vis_j)
         glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)
         glob = (glob / glob.norm(dim=-1, keepdim=True)).unsqueeze(1)
         words_masked, _ = self.tis_selector(words_i.float(), word_w)

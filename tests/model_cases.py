@@ -556,8 +556,9 @@ def case_dmae_tpmcl(dev, golden):
 
 
 def case_dmae_tpmcl_blocks(dev, sim_header="meanP"):
-    """TPM-CL over SEVERAL 8 x 16 caption x video blocks: the batched evaluation of all blocks at once (product path at bench sizes) equals
-    the reference-shaped Python double loop over the blocks (`l3_partial_loop`; the loop form is what ops_dmae_tpmcl.pt pins on one block):
+    """TPM-CL over SEVERAL 8 x 16 caption x video blocks: the batched evaluation of all blocks at once (product path at bench sizes: token-importance
+    weights of all pairs from per-caption / per-video pieces, LinearXWeightPredictor.forward_all_pairs) equals the reference-shaped Python double
+    loop over the blocks with pair-batch predictors (`l3_partial_loop`; the loop form is what ops_dmae_tpmcl.pt pins on one block):
     loss, input gradients, parameter gradients."""
     from antmmf.common.configuration import Configuration
 
@@ -591,7 +592,7 @@ def case_dmae_tpmcl_blocks(dev, sim_header="meanP"):
     # the weight predictors' 2D -> D/2 Linear on the bf16 MFMA GEMM (what the product does from 8192 pair-tokens on; forced here): same loss to 1e-3,
     # every gradient within bf16 distance of the fp32-matmul run
     du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header=sim_header, l3_partial_type=4,
-                                          l3_max_frames=V, l3_max_words=Nw)))
+                                          l3_max_frames=V, l3_max_words=Nw, l3_xwp_pair_batch=True)))   # pair-batch predictors (not the all-pairs algebra)
     W.fill_module_(du)
     du.tis_selector.thresh.fill_(0.6)
     du = du.to(dev).train()
