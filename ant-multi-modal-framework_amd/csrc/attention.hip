@@ -72,14 +72,45 @@ __device__ __forceinline__ int attn_swz(int row) {
                     : (((row & 7) << 1) | ((row >> 3) & 1));          // 256-B rows: one row per bank sweep, 8 slot pairs
 }
 
-// rows [0, n_pad) x DH bf16 -> swizzled token tile; rows >= n_valid are zero
-template <int DH>
+// rows [0, n_pad) x DH bf16 -> swizzled token tile; rows >= n_valid are zero.  NPAD is a compile-time bound on n_pad: every thread requests ALL of
+// its 16-B vectors first and writes them to LDS afterwards.  (As a run-time loop -- one load, s_waitcnt vmcnt(0), one ds_write per trip -- staging K and
+// V cost twelve SERIAL HBM round trips per workgroup: most of a workgroup's lifetime, which is what the PMC pass saw as 63 % wait cycles.)
+template <int DH, int NPAD>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* __restrict__ src, long ld, int n_valid, int n_pad) {
-    constexpr int NS = DH / 8;
-    for (int id = threadIdx.x; id < n_pad * NS; id += ATTN_THREADS) {
-        const int row = id / NS, slot = id % NS;
-        const uint4 v = row < n_valid ? *reinterpret_cast<const uint4*>(src + (long)row * ld + slot * 8) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4)) = v;
+    constexpr int NS = DH / 8, TRIPS = (NPAD * NS + ATTN_THREADS - 1) / ATTN_THREADS;
+    uint4 v[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int id = threadIdx.x + i * ATTN_THREADS, row = id / NS, slot = id % NS;
+        v[i] = (id < n_pad * NS && row < n_valid) ? *reinterpret_cast<const uint4*>(src + (long)row * ld + slot * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int id = threadIdx.x + i * ATTN_THREADS, row = id / NS, slot = id % NS;
+        if (id < n_pad * NS) *reinterpret_cast<uint4*>(dst + row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4)) = v[i];
+    }
+}
+// two tiles at once (K and V, or Q and dO): all loads of both in flight together
+template <int DH, int NPAD>
+__device__ __forceinline__ void stage_rows2(char* dst0, const bf16_t* __restrict__ src0, long ld0, char* dst1, const bf16_t* __restrict__ src1, long ld1,
+                                            int n_valid, int n_pad) {
+    constexpr int NS = DH / 8, TRIPS = (NPAD * NS + ATTN_THREADS - 1) / ATTN_THREADS;
+    uint4 v0[TRIPS], v1[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int id = threadIdx.x + i * ATTN_THREADS, row = id / NS, slot = id % NS;
+        const bool ok = id < n_pad * NS && row < n_valid;
+        v0[i] = ok ? *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + slot * 8) : make_uint4(0, 0, 0, 0);
+        v1[i] = ok ? *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + slot * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int id = threadIdx.x + i * ATTN_THREADS, row = id / NS, slot = id % NS;
+        if (id < n_pad * NS) {
+            const int off = row * (2 * DH) + ((slot ^ attn_swz<DH>(row)) << 4);
+            *reinterpret_cast<uint4*>(dst0 + off) = v0[i];
+            *reinterpret_cast<uint4*>(dst1 + off) = v1[i];
+        }
     }
 }
 // fragment "token `row`, head-dim 8 slot .. 8 slot + 7" (A or B operand with the head dim as the contraction)
@@ -127,8 +158,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
     float* kb = reinterpret_cast<float*>(Vs + NKP * RB);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows<DH>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, a.Nk, NKP);
-    stage_rows<DH>(Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
+    stage_rows2<DH, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -220,8 +250,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq64_kernel(const At
     float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows<64>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
-    stage_rows<64>(Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
+    stage_rows2<64, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, Vs, a.v + (long)b * a.Nk * a.ldv + h * 64, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -315,8 +344,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dq_ke
     float* kb = reinterpret_cast<float*>(Vs + NKP * RB);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows<DH>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, a.Nk, NKP);
-    stage_rows<DH>(Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
+    stage_rows2<DH, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -420,8 +448,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
     const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * DH;
     const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * DH;
     const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * DH;
-    stage_rows<DH>(Qs, qbase, a.ldq, a.Nq, NQP);
-    stage_rows<DH>(Ds, dobase, a.lddo, a.Nq, NQP);
+    stage_rows2<DH, 288>(Qs, qbase, a.ldq, Ds, dobase, a.lddo, a.Nq, NQP);
     for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {
         float d = 0.f, l = INFINITY;  // padding queries: p = 0
         if (i < a.Nq) {
