@@ -121,7 +121,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     if (c0 < cols) {
-        for (long r = r0 + wave; r < r1; r += 4) {
+        // four rows per trip, all four loads requested before the first add (the one-load-per-trip loop was load -> s_waitcnt vmcnt(0) -> add)
+        long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ld8<T>(x + (r + 4 * u) * ld + c0, v[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+        }
+        for (; r < r1; r += 4) {
             float v[8];
             ld8<T>(x + r * ld + c0, v);
 #pragma unroll
