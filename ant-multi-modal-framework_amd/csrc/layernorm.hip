@@ -204,13 +204,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     if (row < rows) fetch(row);
     for (; row < rows; row += rstep) {
         const float mean = nmean, rstd = nrstd;
-        f2_t zh[VPL][4], g[VPL][4], da[VPL][4], rs[VPL][4];
+        constexpr bool REG = BLOCK && ACT != ANTMMF_ACT_NONE;   // register diet of the wide fused-GELU variant: g = dy * gamma is rebuilt from the raw dy
+        f2_t zh[VPL][4], g[REG ? 1 : VPL][4], da[VPL][4], rs[VPL][4];
+        raw8<T> cd[REG ? VPL : 1];
         f2_t s1v = f2_splat(0.f), s2v = f2_splat(0.f);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             if (v0 + vstep * i < nvec) {
                 nx[i].unpack(zh[i]);   // x for now
-                nd[i].unpack(g[i]);    // dy for now
+                if (REG) cd[i] = nd[i]; else nd[i].unpack(g[i]);    // dy for now
                 if (dres) nr[i].unpack(rs[i]);
             }
         }
@@ -221,16 +223,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 f2_t gmv[4], yv[4];
                 if (BLOCK) ld8_f2<float>(red + (v0 + vstep * i) * 8, gmv);
                 if (YOUT) ld8_f2<float>(beta_s + (v0 + vstep * i) * 8, yv);
+                f2_t dvv[4];
+                if (REG) cd[i].unpack(dvv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     f2_t z;
-                    const f2_t dv = g[i][e];
+                    const f2_t dv = REG ? dvv[e] : g[i][e];
                     act_fwd_grad2<ACT>(zh[i][e], act, z, da[i][e]);
                     zh[i][e] = (z - mean) * rstd;
                     if (YOUT) yv[e] = zh[i][e] * (BLOCK ? gmv[e] : gm[i][e]) + yv[e];
-                    g[i][e] = dv * (BLOCK ? gmv[e] : gm[i][e]);
-                    s1v += g[i][e];
-                    s2v += g[i][e] * zh[i][e];
+                    const f2_t ge = dv * (BLOCK ? gmv[e] : gm[i][e]);
+                    if (!REG) g[i][e] = ge;
+                    s1v += ge;
+                    s2v += ge * zh[i][e];
                     ag[i][e] += dv * zh[i][e];
                     ab[i][e] += dv;
                 }
@@ -244,10 +249,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int i = 0; i < VPL; ++i) {
             const int vi = v0 + vstep * i;
             if (vi < nvec) {
-                f2_t o[4];
+                f2_t o[4], gg[4], gmv2[4];
+                if (REG) { cd[i].unpack(gg); ld8_f2<float>(red + vi * 8, gmv2); }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = rstd * (g[i][e] - c1 - zh[i][e] * c2);
+                    const f2_t ge = REG ? gg[e] * gmv2[e] : g[i][e];
+                    o[e] = rstd * (ge - c1 - zh[i][e] * c2);
                     if (ACT != ANTMMF_ACT_NONE) o[e] *= da[i][e];
                     if (dres) o[e] += rs[i][e];
                     if (DXSUM) ad[i][e] += o[e];
