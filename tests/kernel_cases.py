@@ -33,6 +33,14 @@ def check(name, got, want, rtol, atol_rel):
         idx = int(torch.argmax(err.flatten()))
         raise AssertionError(f"{name}: {int(bad.sum())}/{bad.numel()} out of tolerance, max abs err {float(err.max()):.4g} "
                              f"(ref scale {scale:.4g}) at flat index {idx}: got {float(got.flatten()[idx]):.6g} want {float(want.flatten()[idx]):.6g}")
+    # The absolute term above scales with the tensor's largest element, so on its own it says little about the SMALL elements.  Second
+    # criterion, blind to magnitude: the MEDIAN relative error over the non-zero reference elements -- an indexing / permutation error that only
+    # disturbs small entries, or garbage below the absolute tolerance, puts it near 1; rounding noise keeps it near the dtype's epsilon.
+    nz = want.abs() > 1e-6 * max(scale, 1e-30)
+    if int(nz.sum()) >= 16:
+        med = float((err[nz] / want[nz].abs()).median())
+        lim = max(4.0 * rtol, 20.0 * atol_rel, 1e-5)
+        assert med <= lim, f"{name}: median relative error {med:.4g} > {lim:.4g} over {int(nz.sum())} non-zero elements"
 
 
 def q(t):  # bf16 quantise, keep fp32 container
