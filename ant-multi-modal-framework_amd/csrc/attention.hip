@@ -489,6 +489,11 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int q0 = 32 * c + 16 * hh;
+                if (q0 >= a.Nq) {   // a 16-query tile of pure padding (257 queries: the last half chunk): p = dS = 0, no score work
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { p[hh][r] = 0.f; ds[hh][r] = 0.f; }
+                    continue;
+                }
                 f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < KM; ++j) sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Qs, q0 + l15, 4 * j + grp), kf[j], sa, 0, 0, 0);
