@@ -50,6 +50,7 @@ class ParamArena:
                 p._antmmf_bf16 = self.shadow[off:off + n].view(p.shape)
                 p._antmmf_arena, p._antmmf_offset = self, off   # lets a MoCo key tower mirror this layout (one-launch EMA)
                 p.grad = p._antmmf_main_grad
+                p.register_post_accumulate_grad_hook(self._late_grad_guard)
                 off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.sync_shadow()
 
@@ -109,8 +110,27 @@ class ParamArena:
         for g in self.groups:
             for p in g["params"]:
                 p._antmmf_uses = 0
+                p._antmmf_mixed = False
         self._ov = dict(group=group, dtype=reduce_dtype, handles=[], launched=set(), frozen=False, left=None)
         return True
+
+    def _late_grad_guard(self, p):
+        """torch's own AccumulateGrad just added to p.grad (a path outside the fused layers: plain torch ops, a tied weight).  If the
+        bucket of that parameter has already been handed to RCCL the contribution is lost on the other ranks -> refuse loudly."""
+        ov = getattr(self, "_ov", None)
+        if ov is not None and getattr(p, "_antmmf_bucket", None) in ov["launched"]:
+            raise RuntimeError("antmmf.hip.arena: a gradient reached a parameter after its bucket's all-reduce had started (a parameter used by a "
+                               "fused layer AND by an untracked op); call arena.note_untracked([p]) in the forward pass or disable overlap_grad_allreduce")
+
+    def note_untracked(self, params):
+        """Forward-pass notice from an autograd node that writes these parameters' gradients without reporting back (Linear, LayerNorm,
+        embeddings, patch embed): their buckets are reduced after the backward pass, whatever the fused layers report."""
+        ov = getattr(self, "_ov", None)
+        if ov is None or ov["frozen"]:
+            return
+        for p in params:
+            if p is not None and getattr(p, "_antmmf_arena", None) is self:
+                p._antmmf_mixed = True
 
     def note_forward(self, params):
         ov = getattr(self, "_ov", None)
@@ -130,7 +150,7 @@ class ParamArena:
             ov["left"] = []
             for b in self._buckets:
                 tracked = sum(1 for p in b["params"] if p._antmmf_uses > 0)
-                untracked = sum(1 for p in b["params"] if p._antmmf_uses == 0)
+                untracked = sum(1 for p in b["params"] if p._antmmf_uses == 0 or getattr(p, "_antmmf_mixed", False))
                 ov["left"].append(tracked if untracked == 0 else -1)  # -1: holds parameters outside the fused layers -> reduced at the end
         for p in params:
             if p is None or getattr(p, "_antmmf_arena", None) is not self or p._antmmf_uses <= 0:

@@ -164,6 +164,18 @@ def _bgrad(sink, b, dy2d):
     ops.colsum_(sink.buf(b), dy2d)
 
 
+def _note_untracked(*params):
+    """Generic ops write parameter gradients through GradSink without telling the arena when they are final: while an overlapped gradient
+    all-reduce is armed, their parameters' buckets must wait for the end of the backward pass (arena.note_untracked)."""
+    if not torch.is_grad_enabled():
+        return
+    for p in params:
+        arena = getattr(p, "_antmmf_arena", None) if p is not None else None
+        if arena is not None and getattr(arena, "_ov", None) is not None:
+            arena.note_untracked(params)
+            return
+
+
 # ------------------------------------------------------------------------------ generic ops
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
@@ -184,6 +196,7 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def layer_norm(x, weight, bias, eps):
+    _note_untracked(weight, bias)
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
@@ -225,6 +238,7 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, act=None, residual=None, weight_layout="oi"):
+    _note_untracked(weight, bias)
     return _Linear.apply(x, weight, bias, act, residual, weight_layout)
 
 
@@ -455,7 +469,8 @@ class _TransformerLayer(torch.autograd.Function):
         # fc2's bias gradient = column sums of the incoming gradient.  When that gradient is the dx of the NEXT layer's ln1 backward, that
         # kernel has already summed its columns (handed over on the tensor, valid only while the tensor is unmodified: _version check)
         handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0 and not os.environ.get("ANTMMF_DEBUG_NO_HANDOFF")) else None
-        if handed is not None and handed[1] == dy._version and handed[0].shape[0] == d and P["b2"] is not None and P["b2"].requires_grad:
+        if (handed is not None and handed[1:] == (dy._version, dy.data_ptr(), tuple(dy.shape)) and handed[0].shape[0] == d
+                and P["b2"] is not None and P["b2"].requires_grad):
             sink.buf(P["b2"]).add_(handed[0])
             COLSUM_HANDOFFS[0] += 1
         else:
@@ -533,7 +548,8 @@ class _TransformerLayer(torch.autograd.Function):
                 dx = ops.gemm(dqkv2, _packed_qkv_weight_t(P, spec), residual=dmid)
             dx = dx.view(B, N, d)
             if pre_ln:
-                dx._antmmf_colsum = (dx_colsum, dx._version)   # for the previous layer's fc2 bias gradient (see above)
+                # for the previous layer's fc2 bias gradient (see above): valid only for this very tensor, unmodified
+                dx._antmmf_colsum = (dx_colsum, dx._version, dx.data_ptr(), tuple(dx.shape))
         else:
             dx = None
         grads = [sink.result(p, p is not None and ctx.needs_input_grad[4 + i]) for i, p in enumerate(params)]
@@ -600,6 +616,7 @@ class _PatchEmbed(torch.autograd.Function):
 
 
 def patch_embed(image, weight, bias, cls, pos, patch, shift=0.0, scale=1.0):
+    _note_untracked(weight, bias, cls, pos)
     return _PatchEmbed.apply(image, weight, bias, cls, pos, patch, shift, scale)
 
 
@@ -638,4 +655,5 @@ class _Embed(torch.autograd.Function):
 
 
 def embed(ids, word, pos=None, type_table=None, zero_rows=None, pos_offset=0):
+    _note_untracked(word, pos, type_table)
     return _Embed.apply(ids, word, pos, type_table, zero_rows, pos_offset)

@@ -76,6 +76,9 @@ class GlobalRetrievalRecall(BaseMetric):
     def reset(self):
         for simi_level in self._simi_logit_key:
             self._ind[simi_level] = None
+        # the ground-truth lists belong to the set being evaluated (the reference keeps them, global_retrieval_recall.py:120-122, so a second,
+        # different set -- val then test -- would be scored against the first set's lists)
+        self.gt_t2v, self.gt_v2t = dict(), dict()
 
     def collect(self, sample_list, model_output, idx_t, idx_v, t2v=None, v2t=None, **kwargs):
         if t2v is not None and idx_t not in self.gt_t2v:

@@ -43,6 +43,40 @@ from antmmf.structures.sample import SampleList
 from antmmf.utils.distributed_utils import get_rank, get_world_size, is_main_process, reduce_dict, synchronize
 
 
+class EarlyStopping:
+    """Best-so-far bookkeeping of the monitored validation metric.  Attribute names are the reference's (antmmf/utils/early_stopping.py:8-102:
+    `best_monitored_value`, `best_monitored_iteration`, `activated`, `init_from_checkpoint`) because Checkpoint.save / _load read and restore
+    them by those names; the decision itself is taken in BaseTrainer._logistics on a value every rank agrees on."""
+
+    def __init__(self, monitored_metric="total_loss", patience=30000, minimize=True, should_stop=False):
+        self.monitored_metric, self.patience, self.minimize, self.should_stop = monitored_metric, patience, minimize, should_stop
+        self.best_monitored_value = math.inf if minimize else -math.inf
+        self.best_monitored_iteration = 0
+        self.activated = False
+
+    def improved(self, value):
+        return value < self.best_monitored_value if self.minimize else value > self.best_monitored_value
+
+    def update(self, iteration, value):
+        """-> (is a new best, training should stop)."""
+        if self.improved(value):
+            self.best_monitored_value, self.best_monitored_iteration = value, iteration
+            return True, False
+        if iteration - self.best_monitored_iteration > self.patience:
+            self.activated = True
+            return False, bool(self.should_stop)
+        return False, False
+
+    def init_from_checkpoint(self, ckpt):
+        if ckpt.get("best_iteration") is not None:
+            self.best_monitored_iteration = ckpt["best_iteration"]
+        if ckpt.get("best_metric_value") is not None:
+            self.best_monitored_value = ckpt["best_metric_value"]
+
+    def get_info(self):
+        return {"best iteration": self.best_monitored_iteration, f"best {self.monitored_metric}": self.best_monitored_value}
+
+
 @registry.register_trainer("base_trainer")
 class BaseTrainer:
     def __init__(self, config, train_batches=None):
@@ -77,7 +111,7 @@ class BaseTrainer:
         self.patience = tp.get("patience", 30000)
         self.monitored_metric = tp.get("monitored_metric", "total_loss")
         self.metric_minimize = bool(tp.get("metric_minimize", True))
-        self.best_monitored, self.best_iteration = None, 0
+        self.early_stopping = EarlyStopping(self.monitored_metric, self.patience, self.metric_minimize, self.should_early_stop)
         self.epoch_iterations = len(self.train_batches) if hasattr(self.train_batches, "__len__") else 0
         self.setup_lr_scheduler()
         self.load_extras()
@@ -195,8 +229,20 @@ class BaseTrainer:
                 break
         synchronize()
         if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
+            if self.early_stopping.activated and self.should_early_stop:
+                self.checkpoint.restore()   # <model>_final.pth holds the BEST weights after an early stop (reference early_stopping.py:79-83)
             self.checkpoint.finalize()
         return self.read_meters()
+
+    # the pre-round-3 attribute names, kept readable
+    @property
+    def best_monitored(self):
+        v = self.early_stopping.best_monitored_value
+        return None if math.isinf(v) else v
+
+    @property
+    def best_iteration(self):
+        return self.early_stopping.best_monitored_iteration
 
     def train_step(self, batch):
         """ONE iteration of the loop body: forward, meters, loss, backward (+ gradient all-reduce, clip, fused optimizer when the
@@ -226,6 +272,13 @@ class BaseTrainer:
                     sums[k] = sums.get(k, 0) + v.detach().float().mean()
         if was_training:
             self.model.train()
+        if sums and get_world_size() > 1 and not self.config.training_parameters.get("losses_are_global", True):
+            # per-rank validation shards: the mean over ranks is the value every rank reports (one packed all-reduce)
+            keys = sorted(sums)
+            packed = torch.stack([sums[k].reshape(()) for k in keys] + [torch.tensor(float(n), device=sums[keys[0]].device)])
+            dist.all_reduce(packed)
+            n = float(packed[-1])
+            sums = {k: packed[i] for i, k in enumerate(keys)}
         out = {k: float(v) / max(n, 1) for k, v in sums.items()}
         out["total_loss"] = sum(out.values())
         return out
@@ -244,13 +297,17 @@ class BaseTrainer:
         key = self.monitored_metric if self.monitored_metric in result else next((k for k in result if k.endswith(self.monitored_metric)), None)
         if key is None:
             return False
-        value = result[key]
-        better = self.best_monitored is None or (value < self.best_monitored if self.metric_minimize else value > self.best_monitored)
-        if better:
-            self.best_monitored, self.best_iteration = value, self.current_iteration
-            if self.checkpoint is not None and self.checkpoint.save_dir_enabled:
-                self.checkpoint.save(self.current_iteration, update_best=True)
-        return self.should_early_stop and (self.current_iteration - self.best_iteration) > self.patience
+        value = float(result[key])
+        if get_world_size() > 1:
+            # ONE value for every rank (rank 0's): a rank that saw a different validation shard must not leave the loop alone --
+            # the others would block in the next collective
+            t = torch.tensor([value], dtype=torch.float64, device=self.device)
+            dist.broadcast(t, src=0)
+            value = float(t)
+        better, stop = self.early_stopping.update(self.current_iteration, value)
+        if better and self.checkpoint is not None and self.checkpoint.save_dir_enabled:
+            self.checkpoint.save(self.current_iteration, update_best=True)
+        return stop
 
     def _forward_pass(self, batch, enable_amp=False):
         if not batch:

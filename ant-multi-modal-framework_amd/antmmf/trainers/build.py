@@ -1,7 +1,6 @@
 """build_trainer (reference: antmmf/trainers/build.py:12-26)."""
 from antmmf.common.registry import registry
 from antmmf.trainers import base_trainer, retrieval_trainer  # noqa: F401  (register "base_trainer" / "retrieval_trainer")
-from antmmf.trainers import base_trainer  # noqa: F401  (registers "base_trainer")
 
 
 def build_trainer(config, *args, **kwargs):

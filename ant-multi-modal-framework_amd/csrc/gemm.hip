@@ -1680,6 +1680,10 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
     act &= 0xff;
+    // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
+    // about what lands in aux); gate-holds-act' needs a gate
+    if (g.aux_grad && (act == ANTMMF_ACT_NONE || gate || !aux)) return ANTMMF_EINVAL;
+    if (g.gate_grad && !gate) return ANTMMF_EINVAL;
     g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha; g.ws = nullptr;
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
     static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- pairs/s of the contrastive image/video-text training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload l14|b16|vtp8|dmae12]
+    python bench.py --gpus N --steps K --warmup W [--workload l14|b16|vtp8|dmae12]      (N > 1: starts its own N ranks under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Default workload `l14` (the BASELINE metric): one step = forward + backward + optimizer over one synthetic batch already resident in
@@ -292,14 +292,74 @@ def make_trainer(a, device, world):
     return VtpTrainer(cfg)
 
 
+def _self_launch(a):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this file under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1, a free port) and hand its exit code back -- the reference's own launcher does the same with one Popen per local
+    rank (antmmf/utils/launch.py:220-282).  The ranks print the JSON line; this parent prints nothing."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this node exposes {have} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env["ANTMMF_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def choose_keep_ffn(a, is_m2, batch_size, device, world, probe_step):
+    """Activation policy: keep fc2's 4d-wide input for backward when HBM allows.  N = 1: the l14 step peaks at 244 GiB
+    reserved of 268 (measured, profiles/).  N > 1: RCCL's channel buffers and the bucket staging live OUTSIDE torch's allocator, so the
+    decision is made from a measurement on this very process -- one step in recompute mode (`probe_step`), the bytes the kept activation adds
+    on top of its peak (analytic), and what the device still has free next to torch's pool -- and agreed over all ranks (MIN)."""
+    from antmmf.hip import functional
+
+    total = torch.cuda.get_device_properties(device).total_memory
+    if a.recompute_ffn_norm:
+        return False, "recompute (--recompute-ffn-norm)"
+    if total < 250 * 2 ** 30 or (is_m2 and batch_size > 1024):
+        return False, "recompute (HBM)"
+    if world == 1:
+        return True, "kept"
+    functional.set_keep_ffn_norm(False)
+    torch.cuda.reset_peak_memory_stats()
+    probe_step()
+    torch.cuda.synchronize()
+    reserved = torch.cuda.max_memory_reserved()
+    free, _ = torch.cuda.mem_get_info()
+    outside = total - free - torch.cuda.memory_reserved()        # RCCL buffers, HIP runtime, code objects
+    if is_m2:
+        m = M2_WORKLOADS[a.workload]
+        tokens = batch_size * ((m["image_size"] // m["patch_size"]) ** 2 + 1 + m["max_text_len"])
+        extra = tokens * 4 * m["encoder_embed_dim"] * 2 * (m["encoder_layers"] + m["beit3_vl_layers"])
+    else:
+        w = VTP_WORKLOADS[a.workload]
+        extra = batch_size * (w["n_clips"] * 197 + w["seq"]) * 3072 * 2 * 12
+    margin = 6 * 2 ** 30
+    keep = reserved + extra + outside + margin <= total
+    flag = torch.tensor([1 if keep else 0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    keep = bool(flag.item())
+    note = (f"{'kept' if keep else 'recompute'} (probe: {reserved / 2 ** 30:.1f} GiB reserved in recompute mode + {extra / 2 ** 30:.1f} GiB kept activations + "
+            f"{outside / 2 ** 30:.1f} GiB outside torch's pool (RCCL, runtime) + {margin / 2 ** 30:.0f} GiB margin vs {total / 2 ** 30:.1f} GiB)")
+    return keep, note
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _self_launch(a)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed.run launch with --nproc-per-node {a.gpus}")
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -311,10 +371,6 @@ def main():
     assert _lib.backend() == 1, "bench.py must run on the gfx950 library"
     is_m2 = a.workload in M2_WORKLOADS
     batch_size = a.batch if a.batch is not None else (1024 if is_m2 else VTP_WORKLOADS[a.workload]["default_batch"])
-    # activation-memory policy: keep the 4d-wide normalised FFN activation when the device has the HBM for it
-    # fc2's input kept for backward instead of recomputed: the video workloads peak at ~90 GiB without it, the M2 ones fit up to 1024 pairs
-    keep_ffn = (not a.recompute_ffn_norm) and torch.cuda.get_device_properties(device).total_memory >= 250 * 2 ** 30 and (batch_size <= 1024 or not is_m2)
-    functional.set_keep_ffn_norm(keep_ffn)
     trainer = make_trainer(a, device, world)
     trainer.load()
     trainer.model.train()
@@ -330,7 +386,15 @@ def main():
         trainer.current_iteration += 1
         return trainer.train_step(batch)
 
-    loss0 = None
+    # activation-memory policy: fc2's 4d-wide input kept for backward instead of recomputed when the device has the HBM for it (the video
+    # workloads peak at ~90 GiB without it, the M2 ones fit up to 1024 pairs); at N > 1 decided from a probe step (RCCL's buffers count)
+    probe_loss = []
+    keep_ffn, keep_note = choose_keep_ffn(a, is_m2, batch_size, device, world, lambda: probe_loss.append(float(step().detach())))
+    functional.set_keep_ffn_norm(keep_ffn)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+
+    loss0 = probe_loss[0] if probe_loss else None   # (N > 1: the probe step was the first step of the run)
     for _ in range(a.warmup):
         loss = step()
         if loss0 is None:
@@ -403,7 +467,7 @@ def main():
                        "loss": round(final_loss, 5), "meters": {k: round(v, 5) for k, v in meters.items()},
                        "train_gflop_per_pair": round(gflop_pair, 1), "step_tflops_per_gpu": round(step_tflops, 1),
                        "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4),
-                       "loss_step0": None if loss0 is None else round(loss0, 5), "keep_ffn_norm": keep_ffn,
+                       "loss_step0": None if loss0 is None else round(loss0, 5), "keep_ffn_norm": keep_ffn, "ffn_activation_policy": keep_note,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_k64p_kernel / gemm_tn_k64_kernel (bf16 MFMA GEMM family, all layouts)", "achieved": round(achieved, 1),

@@ -121,6 +121,61 @@ def case_univl_stage1(dev, golden, tag="b4n1", n_clips=1, rtol=5e-2):
     return dict(loss=float(loss), ref_loss=ref_loss, worst_gnorm=worst[:3], directions=dirs)
 
 
+def case_univl_registry(dev, golden):
+    """the registry model `univl` built by build_model from a config, batch keys routed by prefix (group_inputs,
+    univl_model.py:36-51), loss equal to the reference's on the golden batch, and get_optimizer_parameters' four groups
+    {towers, new} x {decay, no decay} with the encoder lr decay (univl_video_ret.py:482-542) feeding the fused AdamW: after one step every
+    parameter has moved by (about) ITS group's learning rate -- AdamW's first update is lr * sign-like, so the group lr is visible per element."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from antmmf.models.build import build_model
+    from antmmf.optimizer import build_optimizer
+    from antmmf.structures.sample import SampleList
+
+    mcfg = Configuration(dict(TINY_CLIP_CFG, model="univl", encoder_lr_decay=0.1))
+    model = build_model(mcfg)
+    W.fill_module_(model.model)
+    model = model.to(dev).train()
+    g = golden("e2e_clip_arch.pt")
+    img, ids, mask = g["b4n1.image_data"].to(dev), g["b4n1.input_ids"].to(dev), g["b4n1.input_mask"].to(dev)
+    sl = SampleList(image_data=img, image_pad_mask=torch.zeros(4, img.shape[1], 32, 32, dtype=torch.bool, device=dev), image_n_clips=[1] * 4,
+                    image_num_frames=[1] * 4, caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids, dataset_type="train")
+    groups = model.group_inputs(sl)
+    assert set(groups["image"]) == {"image_data", "image_pad_mask", "image_n_clips", "image_num_frames"} and len(groups["caption"]) == 3
+    cfg = Configuration({"optimizer_attributes": {"type": "AdamW", "params": {"lr": 1e-3, "weight_decay": 0.0}}})
+    pg = model.get_optimizer_parameters(cfg)
+    assert [round(g_.get("lr", 1e-3), 8) for g_ in pg] == [1e-4, 1e-3, 1e-4, 1e-3] and [g_["weight_decay"] for g_ in pg] == [0.0, 0.0, 0.0, 0.0]
+    cfg_wd = Configuration({"optimizer_attributes": {"type": "AdamW", "params": {"lr": 1e-3, "weight_decay": 0.05}}})
+    assert [g_["weight_decay"] for g_ in model.get_optimizer_parameters(cfg_wd)] == [0.05, 0.05, 0.0, 0.0]
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert all(("bias" in names[id(p)] or "LayerNorm" in names[id(p)]) for g_ in (pg[2], pg[3]) for p in g_["params"])
+    assert all("img_encoder." in names[id(p)] or "text_encoder.e" in names[id(p)] for p in pg[0]["params"])
+    assert any("text_projection" in names[id(p)] for p in pg[1]["params"])  # not a tower prefix: trains at the full lr
+    assert sum(len(g_["params"]) for g_ in pg) == len(list(model.parameters()))
+    opt = build_optimizer(model, cfg, use_hip_arena=True)
+    assert len(opt.arena.groups) == len([g_ for g_ in pg if g_["params"]])
+    out = model(sl)
+    loss = out["losses"]["level1_similarity_loss"]
+    ref = float(g["b4n1.loss"])
+    assert abs(float(loss) - ref) <= 1e-3 * abs(ref), (float(loss), ref)
+    before = {id(p): p.detach().clone() for p in model.parameters()}
+    loss.backward()
+    opt.step()
+    moved = []
+    for g_ in pg:
+        lr = g_.get("lr", 1e-3)
+        for p in g_["params"]:
+            d = (p.detach() - before[id(p)]).abs()
+            nz = d[d > 0]
+            if nz.numel() < 8:
+                continue   # a parameter without gradient on this batch (e.g. unused position rows)
+            # first AdamW step, no weight decay: |delta| = lr |g| / (|g| + eps) <= lr, and = lr wherever |g| >> eps
+            assert float(d.max()) <= lr * 1.001 + 1e-12, (names[id(p)], float(d.max()), lr)
+            moved.append((float(nz.median()) / lr, names[id(p)]))
+    assert len(moved) >= 20 and sum(1 for m_, _ in moved if m_ > 0.5) >= 0.8 * len(moved), sorted(moved)[:5]
+    return dict(loss=float(loss), ref=ref, groups=[len(g_["params"]) for g_ in pg], moved=len(moved))
+
+
 def case_bert_layer_dropout(dev):
     """Fused BERT layer in training mode with attention / hidden dropout vs the oracle layer with the SAME masks (rebuilt on the
     host by the numpy twin of the counter-based hash): forward, input gradient, parameter gradients."""

@@ -246,3 +246,84 @@ def test_optimizer_step_refreshes_transposed_weight_copies_in_one_launch():
         ps[0].clamp_(-0.1, 0.1)                                    # a write the optimizer did not make
     t = F.compute_copy_t(ps[0])
     assert float(t.float().abs().max()) <= 0.1 + 1e-3 and torch.equal(t, F.compute_copy(ps[0]).t())
+
+
+@pytest.mark.parametrize("prefix", ["module.", ""])
+def test_cn_clip_load_pretrained_round_trip(tmp_path, prefix):
+    """8(f1): the CN-CLIP tower loaders (reference clip_visual_encoder.py:46-71, clip_text_encoder.py:194-227).  A released checkpoint is
+    {"state_dict": {"module.visual.<k>", "module.bert.<k>", "module.text_projection", "module.logit_scale", ...}}: the image tower keeps the
+    `visual.*` entries, the text tower the `bert.*` entries + `text_projection`; everything else is ignored.  Both spellings are accepted
+    here ("module."-prefixed as released, and bare -- the reference's own bare-key branch mangles `text_projection`, :213, so only the
+    prefixed form is pinned by it).  After the load every parameter equals the checkpoint tensor, the bf16 compute shadow follows (the
+    forward changes), and a wrong-shaped projection is skipped as the reference does (:222-227)."""
+    import model_cases as mc   # (puts prj/base_vtp on sys.path)
+    import roi_univl  # noqa: F401
+    from roi_univl.univl.model.clip_text_encoder import RobertBertEncoder
+    from roi_univl.univl.model.clip_visual_encoder import VitImageEncoder
+
+    vp = dict(mc.TINY_CLIP_CFG["image_encoder"]["params"])
+    tparams = dict(mc.TINY_CLIP_CFG["text_encoder"]["params"])
+    src_v, src_t = VitImageEncoder(**vp), RobertBertEncoder(**tparams)
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, v in src_v.visual.state_dict().items():
+        sd[prefix + "visual." + k] = torch.randn(v.shape, generator=g) * 0.05 if v.is_floating_point() else v.clone()
+    for k, v in src_t.module.state_dict().items():
+        sd[prefix + "bert." + k] = torch.randn(v.shape, generator=g) * 0.05 if v.is_floating_point() else v.clone()
+    sd[prefix + "text_projection"] = torch.randn(src_t.text_projection.shape, generator=g) * 0.05
+    sd[prefix + "logit_scale"] = torch.tensor(2.5)          # not a tower key: ignored by both loaders
+    path = str(tmp_path / "cn_clip.pt")
+    torch.save({"state_dict": sd, "epoch": 3}, path)
+
+    vis = VitImageEncoder(**dict(vp, pretrained=True, model_name=path))
+    for k, v in vis.visual.state_dict().items():
+        torch.testing.assert_close(v, sd[prefix + "visual." + k], rtol=0, atol=0, msg=k)
+    txt = RobertBertEncoder(**dict(tparams, pretrained=True, model_name=path))
+    for k, v in txt.module.state_dict().items():
+        torch.testing.assert_close(v, sd[prefix + "bert." + k], rtol=0, atol=0, msg=k)
+    torch.testing.assert_close(txt.text_projection.data, sd[prefix + "text_projection"], rtol=0, atol=0)
+
+    # a projection of another width is left alone (reference :222-227), a missing file is an error, not a download attempt
+    sd_bad = dict(sd)
+    sd_bad[prefix + "text_projection"] = torch.zeros(src_t.text_projection.shape[0], 7)
+    torch.save({"state_dict": sd_bad}, path)
+    keep = RobertBertEncoder(**dict(tparams, pretrained=True, model_name=path))
+    assert keep.text_projection.shape == src_t.text_projection.shape and float(keep.text_projection.abs().sum()) > 0
+    with pytest.raises(RuntimeError):
+        VitImageEncoder(**dict(vp, pretrained=True, model_name=str(tmp_path / "absent.pt")))
+
+    # the loaded weights are the ones the kernels compute with: forward of the loaded tower == forward of a tower filled by hand
+    ref = VitImageEncoder(**vp)
+    ref.visual.load_state_dict({k: sd[prefix + "visual." + k] for k in ref.visual.state_dict()})
+    img = torch.randn(2, 1, 3, 32, 32, generator=g)
+    m = torch.zeros(2, 1, 32, 32, dtype=torch.bool)
+    a, b = vis(img, m)["grid_feature"], ref(img, m)["grid_feature"]
+    torch.testing.assert_close(a.float(), b.float(), rtol=0, atol=0)
+
+
+def test_early_stop_state_is_persisted_and_best_weights_are_final(tmp_path):
+    """best.ckpt records the early-stopping state (`best_iteration`, `best_metric_value`; reference checkpoint.py:320-356 reads it
+    from trainer.early_stopping), a resumed run gets it back (init_from_checkpoint), and after an early stop `<model>_final.pth` holds the
+    BEST weights (checkpoint.restore() before finalize(), reference early_stopping.py:79-83).  The learning rate is negative-ish large so the
+    validation loss gets worse after the first evaluation."""
+    Trainer = _toy()
+    cfg = _cfg(tmp_path / "es", evaluation_interval=1, should_early_stop=True, patience=1, monitored_metric="total_loss", max_iterations=8,
+               snapshot_interval=100)
+    cfg.optimizer_attributes.params.lr = 5.0   # diverges: the first evaluation is the best one
+    batches = _batches() + _batches()
+    tr = Trainer(cfg, batches)
+    tr.load()
+    tr.load_task(batches, _batches()[:2])
+    tr.train()
+    assert tr.early_stopping.activated and tr.best_iteration >= 1 and tr.current_iteration == tr.best_iteration + 2, (tr.best_iteration, tr.current_iteration)
+    folder = tmp_path / "es" / "toy_task_toy_ckpt_7"
+    best = torch.load(folder / "toy_ckpt_best.ckpt" if (folder / "toy_ckpt_best.ckpt").is_file() else next(folder.glob("*best.ckpt")), weights_only=False)
+    assert best["best_iteration"] == tr.best_iteration and abs(best["best_metric_value"] - tr.best_monitored) < 1e-12
+    final = torch.load(next(folder.glob("*_final.pth")), weights_only=False)
+    for k, v in best["model"].items():
+        assert torch.equal(final[k], v), k      # the restored best weights, not the diverged last ones
+    # resume: patience keeps counting from the recorded best
+    cfg2 = _cfg(tmp_path / "es2", resume_file=str(next(folder.glob("*best.ckpt"))), evaluation_interval=1, should_early_stop=True, patience=1)
+    tr2 = Trainer(cfg2, batches)
+    tr2.load()
+    assert tr2.best_iteration == tr.best_iteration and abs(tr2.best_monitored - tr.best_monitored) < 1e-12

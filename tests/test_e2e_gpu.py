@@ -91,6 +91,67 @@ def test_dmae_wti_vs_reference(golden):
     print(mc.case_dmae_wti(DEV, golden))
 
 
+def test_univl_registry_model_four_param_groups_on_device(golden):
+    """SURVEY 8a R2 on the MI355X: build_model("univl") from a config -> Univl.group_inputs (batch keys by prefix) -> the reference loss on
+    the golden batch -> get_optimizer_parameters' four groups -> fused HipAdamW on the device (every parameter moves by its group's lr)."""
+    print(mc.case_univl_registry(DEV, golden))
+
+
+@pytest.mark.parametrize("workload", ["vtp8", "dmae12"])
+def test_video_workloads_full_size_step_properties(workload):
+    """BASELINE configs 3 / 4 AT SIZE (full ViT-B/16 + BERT-base towers, 224 x 224 frames, 8 clips + stage-2 cross encoder / 12 frames +
+    stage-3 WTI + NegNCE + TPM-CL, B = 8 videos) through the registry model and the product trainer: losses finite, the stage-1 MIL-NCE at
+    random init sits at its closed form ln(2B - 1) (uniform similarities; SURVEY 8c measured 2.70888 on the reference), the forward is
+    deterministic, a few AdamW steps on the same batch lower the loss."""
+    import math
+
+    import bench
+
+    class A:
+        pass
+
+    a = A()
+    a.workload, a.batch = workload, 8
+    trainer = bench.make_trainer(a, DEV, 1)
+    trainer.load()
+    trainer.model.train()
+    batch = bench.synthetic_vtp_batch(workload, 8, DEV, 4321)
+    with torch.no_grad():
+        o1 = trainer.model(batch)
+        o2 = trainer.model(batch)
+    for k in o1["losses"]:
+        assert math.isfinite(float(o1["losses"][k])), (k, float(o1["losses"][k]))
+        assert float(o1["losses"][k]) == float(o2["losses"][k]), f"{k}: forward must be deterministic"
+    l1 = float(o1["losses"]["level1_similarity_loss"])
+    assert abs(l1 - math.log(15.0)) < 0.35, l1
+    expect = {"vtp8": {"level1_similarity_loss", "level2_similarity_loss"}, "dmae12": {"level1_similarity_loss", "level3_similarity_loss"}}[workload]
+    assert expect <= set(o1["losses"]), set(o1["losses"])
+    first = None
+    for it in range(4):
+        trainer.current_iteration += 1
+        loss = trainer.train_step(batch)
+        first = float(loss) if first is None else first
+    assert math.isfinite(float(loss)) and float(loss) < first, (first, float(loss))
+    print(workload, {k: round(float(v), 4) for k, v in o1["losses"].items()}, "step losses", first, float(loss))
+
+
+@pytest.mark.parametrize("mode", ["overlap", "plain", "bf16"])
+def test_m2_step_two_rccl_ranks_equals_single_rank(mode):
+    """SURVEY 8e on RCCL itself: the whole tiny-M2 step on 2 ranks == the 1-rank step on the concatenated batch (tests/dp_rccl_case.py).
+    Needs two GPUs in the box; the driver's 1-GPU boxes skip it (the gloo + emulator twin in tests/test_host_logic.py always runs)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs in one box")
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ANTMMF_HIP_LIB", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29721 + ["overlap", "plain", "bf16"].index(mode)), os.path.join(mc.ROOT, "tests", "dp_rccl_case.py"), mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert "okdp world=2" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_bert_layer_dropout_vs_oracle_same_masks():
     print(mc.case_bert_layer_dropout(DEV))
 

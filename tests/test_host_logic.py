@@ -448,3 +448,36 @@ def test_m2_step_two_ranks_equals_single_rank(mode):
         diff = (two[0]["master"] - one["master"]).abs()
         bad = diff > (1e-5 + 1e-4 * one["master"].abs())
         assert int(bad.sum()) <= max(1, diff.numel() // 100000) and float(diff.max()) <= 2e-2, (int(bad.sum()), float(diff.max()))
+
+
+def test_bench_self_launches_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (how the driver may call it): bench.py starts N ranks of itself under
+    torch.distributed.run on 127.0.0.1 and returns that job's exit code; it refuses when the node has fewer GPUs."""
+    import subprocess
+
+    import bench
+
+    class A:
+        gpus = 4
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench._self_launch(A())
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench._self_launch(A())
+    assert "exposes 1 GPU" in str(e.value.code)
