@@ -58,6 +58,12 @@ _SIGNATURES = {
     "antmmf_wti_reduce_fwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "antmmf_wti_reduce_bwd": [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "antmmf_rank_rows": [P, L, I, I, P, P, P, P],
+    "antmmf_token_weight_fwd": [P, P, P, P, P, I, I, I, P],
+    "antmmf_token_weight_bwd": [P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "antmmf_pair_dots": [P, P, P, I, I, I, P],
+    "antmmf_pair_wsum": [P, P, P, I, I, I, P],
+    "antmmf_pair_outer": [P, P, P, I, I, I, P],
+    "antmmf_tis_keep": [P, F, P, I, I, P],
     "antmmf_negnce_fwd": [P, P, I, I, I, F, F, P, P, P, P, P],
     "antmmf_negnce_bwd": [P, P, P, P, I, I, I, F, F, P, I, P],
     "antmmf_resize_bicubic_u8": [P, L, P, I, I, I, I, I, I, P, P, P, P, I, P],

@@ -50,7 +50,7 @@ class ParamArena:
                 p._antmmf_bf16 = self.shadow[off:off + n].view(p.shape)
                 p._antmmf_arena, p._antmmf_offset = self, off   # lets a MoCo key tower mirror this layout (one-launch EMA)
                 p.grad = p._antmmf_main_grad
-                p.register_post_accumulate_grad_hook(self._late_grad_guard)
+                p.register_hook(lambda g, p=p: self._late_grad_guard(p, g))
                 off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.sync_shadow()
 
@@ -114,12 +114,14 @@ class ParamArena:
         self._ov = dict(group=group, dtype=reduce_dtype, handles=[], launched=set(), frozen=False, left=None)
         return True
 
-    def _late_grad_guard(self, p):
-        """torch's own AccumulateGrad just added to p.grad (a path outside the fused layers: plain torch ops, a tied weight).  If the
-        bucket of that parameter has already been handed to RCCL the contribution is lost on the other ranks -> refuse loudly."""
+    def _late_grad_guard(self, p, g):
+        """torch's own AccumulateGrad is about to add `g` to p.grad (a path outside the fused layers: plain torch ops, a tied weight; the
+        fused nodes hand autograd None for arena parameters, which arrives here as g = None and is not a gradient).  If the bucket of that
+        parameter has already been handed to RCCL the contribution would be lost on the other ranks -> refuse loudly."""
         ov = getattr(self, "_ov", None)
-        if ov is not None and getattr(p, "_antmmf_bucket", None) in ov["launched"]:
-            raise RuntimeError("antmmf.hip.arena: a gradient reached a parameter after its bucket's all-reduce had started (a parameter used by a "
+        if g is not None and ov is not None and getattr(p, "_antmmf_bucket", None) in ov["launched"]:
+            raise RuntimeError(f"antmmf.hip.arena: a gradient reached a parameter (shape {tuple(p.shape)}, arena offset {p._antmmf_offset}, uses left "
+                               f"{getattr(p, '_antmmf_uses', None)}) after its bucket's all-reduce had started (a parameter used by a "
                                "fused layer AND by an untracked op); call arena.note_untracked([p]) in the forward pass or disable overlap_grad_allreduce")
 
     def note_untracked(self, params):

@@ -513,6 +513,84 @@ def wti_reduce_bwd(S, A, T, B, V, tmask, vmask, f2f, z2_of, z1, tmax, dt2v, dv2t
     return dS, df2f
 
 
+# ------------------------------------------------------------------------------ DMAE stage-3 head: token weights, aligned-pair products
+_TW_SCRATCH = {}
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError(f"antmmf.hip: {name} must be a contiguous float32 tensor")
+    return t
+
+
+def token_weight_fwd(feat, w, bias, mask):
+    """softmax over the tokens of (feat . w + bias), masked tokens (mask < 0.5) excluded: feat [N, T, D] fp32 -> [N, T]."""
+    _dev_ok(feat, w, bias, mask); _f32c(feat, "feat"); _f32c(w, "w")
+    N, T, D = feat.shape
+    if mask is not None:
+        _f32c(mask, "mask")
+    out = torch.empty(N, T, dtype=torch.float32, device=feat.device)
+    _rc(_lib.load().antmmf_token_weight_fwd(_p(feat), _p(w), _p(bias), _p(mask), _p(out), N, T, D, _stream()), "antmmf_token_weight_fwd")
+    return out
+
+
+def token_weight_bwd(feat, w, p, dout, dw, dbias=None, want_dfeat=True):
+    """-> dfeat (or None); dw [D] / dbias [1] are accumulated in place."""
+    _dev_ok(feat, w, p, dout, dw, dbias)
+    for t, n in ((feat, "feat"), (w, "w"), (p, "p"), (dout, "dout"), (dw, "dw")):
+        _f32c(t, n)
+    N, T, D = feat.shape
+    scratch = _TW_SCRATCH.get(feat.device)
+    if scratch is None or scratch.numel() < 512 * (D + 1):
+        scratch = torch.empty(512 * 1025, dtype=torch.float32, device=feat.device)
+        _TW_SCRATCH[feat.device] = scratch
+    dfeat = torch.empty_like(feat) if want_dfeat else None
+    _rc(_lib.load().antmmf_token_weight_bwd(_p(feat), _p(w), _p(p), _p(dout), _p(dfeat), _p(dw), _p(dbias), _p(scratch), scratch.numel(), N, T, D,
+                                            _stream()), "antmmf_token_weight_bwd")
+    return dfeat
+
+
+def pair_dots(x, y):
+    """out[c, v] = x[c, :] . y[c, v, :]   (x [C, D], y [C, V, D] fp32)."""
+    _dev_ok(x, y); _f32c(x, "x"); _f32c(y, "y")
+    C, V, D = y.shape
+    if tuple(x.shape) != (C, D):
+        raise ValueError("pair_dots: x must be [C, D]")
+    out = torch.empty(C, V, dtype=torch.float32, device=y.device)
+    _rc(_lib.load().antmmf_pair_dots(_p(x), _p(y), _p(out), C, V, D, _stream()), "antmmf_pair_dots")
+    return out
+
+
+def pair_wsum(w, y):
+    """out[c, :] = sum_v w[c, v] y[c, v, :]."""
+    _dev_ok(w, y); _f32c(w, "w"); _f32c(y, "y")
+    C, V, D = y.shape
+    if tuple(w.shape) != (C, V):
+        raise ValueError("pair_wsum: w must be [C, V]")
+    out = torch.empty(C, D, dtype=torch.float32, device=y.device)
+    _rc(_lib.load().antmmf_pair_wsum(_p(w), _p(y), _p(out), C, V, D, _stream()), "antmmf_pair_wsum")
+    return out
+
+
+def pair_outer(w, x):
+    """out[c, v, :] = w[c, v] x[c, :]."""
+    _dev_ok(w, x); _f32c(w, "w"); _f32c(x, "x")
+    C, V = w.shape
+    D = x.shape[1]
+    out = torch.empty(C, V, D, dtype=torch.float32, device=x.device)
+    _rc(_lib.load().antmmf_pair_outer(_p(w), _p(x), _p(out), C, V, D, _stream()), "antmmf_pair_outer")
+    return out
+
+
+def tis_keep(w, thresh):
+    """keep mask [R, T] of TokenImportanceSelector: 0 for the tokens whose descending cumulative weight (inclusive) is < thresh."""
+    _dev_ok(w); _f32c(w, "w")
+    R, T = w.shape
+    keep = torch.empty_like(w)
+    _rc(_lib.load().antmmf_tis_keep(_p(w), float(thresh), _p(keep), R, T, _stream()), "antmmf_tis_keep")
+    return keep
+
+
 def rank_rows(S, gt_off, gt_idx):
     """rank [rows] int32: position (0 = first) of the best ground-truth column of every row of S [rows, cols] fp32;
     gt_off [rows + 1] / gt_idx int32 list the ground-truth columns of each row (CSR)."""

@@ -99,7 +99,9 @@ template <> __device__ __forceinline__ void st8_f2<bf16_t>(bf16_t* p, const f2_t
 // wave-wide (64-lane) sum, the same value in every lane.  Device: four DPP adds (xor 1, xor 2, half-row mirror, row mirror: every
 // lane of a 16-lane row holds the row sum) + four v_readlane -- no LDS round trips (the ds_bpermute butterfly is a chain of six
 // dependent LDS accesses per sum, which is what the row-wise kernels were waiting on).  The emulator keeps the shuffle butterfly.
-#if defined(ANTMMF_EMULATE) || defined(ANTMMF_SHFL_SUM)
+#if defined(ANTMMF_EMULATE)
+__device__ __forceinline__ float wave_sum(float v) { return emu_wave_sum(v); }   // tests/emu/hip_emu.h: the same butterfly sum in two barriers
+#elif defined(ANTMMF_SHFL_SUM)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -118,11 +120,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 #endif
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ float wave_max(float v) { return emu_wave_max(v); }
+#else
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+#endif
 
 // 16-B slot swizzle for [rows][64 bf16] (128-B row) LDS tiles: physical slot = slot ^ lds_swz(row).
 // Conflict-free for ds_read_b128 MFMA fragment reads (16 consecutive rows x one slot per 16-lane group).

@@ -1314,7 +1314,8 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                         for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rv[q][e]); v[2 * e + 1] += bf_hi(rv[q][e]); }
                     }
                     const u32x4_t ov = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                    K64_NT_STORE16(C + row * g.ldc + col, ov);
+                    if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(C + row * g.ldc + col) = ov;   // (store ablations: variant bits 11 / 12)
+                    else if (g.debug_nostore != 1) K64_NT_STORE16(C + row * g.ldc + col, ov);
                 }
             }
         }

@@ -9,8 +9,12 @@ Built:
     text rows -- the reference's [B_t, B_v, N_t, N_v] einsum tensor (96 GB at B_g = 8192) is never materialised;
   * CrossEn (:528-537) and NegNCE (:539-563) on fused row kernels.
   * TPM-CL, the partial-order margin losses (get_partial_similarity / _get_partial_output / wti_interaction_row, :280-523, with
-    tpmcl_utils.py's LinearXWeightPredictor and TokenImportanceSelector): a small head over 8 x 16 caption/video blocks, composed
-    from torch device ops (no custom kernel: per block it touches ~128 pairs x 30 tokens; the towers dominate the step).
+    tpmcl_utils.py's LinearXWeightPredictor and TokenImportanceSelector): a head over 8 x 16 caption/video blocks.  Round 3: (i) only the
+    blocks that hold a diagonal entry are evaluated -- the margin losses read torch.diag of the five [B_t, B_v] matrices (reference
+    :379-388) and a block's scores depend on nothing outside the block, so the other (B_t / 8)(B_v / 16) - B / 8 blocks never reach the
+    loss or any gradient (exact, 8 x less work at B = 128); (ii) what is evaluated runs on this build's kernels: token weights
+    (Linear(D, 1) + masked softmax), aligned-pair token products, the importance selection mask (antmmf.hip.tpmcl / csrc/tpmcl.hip) and
+    fp32-accurate small GEMMs on the MFMA pipe -- no torch / rocBLAS GEMM, softmax, einsum or sort is left.
 Not built: the attention-based predictor variant (xwp_type "attention"; the reference hard-codes "linear")."""
 from collections import OrderedDict
 
@@ -19,6 +23,7 @@ from torch import nn
 
 from antmmf.hip import contrastive
 from antmmf.hip import functional as HF
+from antmmf.hip import tpmcl
 from antmmf.modules.vision.backbone.clip.model import QuickGELU
 from antmmf.utils.distributed_utils import gather_tensor, get_world_size
 
@@ -117,17 +122,54 @@ class LinearXWeightPredictor(nn.Module):
     def forward(self, q, k):
         if not self._qk_same_embed_dim:
             q, k = self.q_proj(q), self.k_proj(k)
-        q = self.qk_proj(q.float().transpose(-2, -1)).transpose(-1, -2)
+        q = self._token_map(q)
         x = torch.cat([q, k.float()], dim=-1)
         rows = x.shape[0] * x.shape[1]
+        ln, fc_a, act, fc_b, sig = self.attn_proj
         if self.MFMA_MIN_ROWS is not None and rows >= self.MFMA_MIN_ROWS and x.shape[-1] % 64 == 0:
-            ln, fc_a, act, fc_b, sig = self.attn_proj
-            h = HF.linear(ln(x).to(torch.bfloat16), fc_a.weight)
-            w = sig(fc_b(act(h.float()))).squeeze(-1)
+            h = HF.linear(ln(x).to(torch.bfloat16), fc_a.weight).float()
         else:
-            w = self.attn_proj(x).squeeze(-1)
-        return w / w.sum(dim=1, keepdim=True)
+            h = tpmcl.linear_f32(ln(x), fc_a.weight)       # fp32-accurate on the MFMA pipe (hi / lo split)
+        return self._pair_tail(h)
 
+
+    def _token_map(self, q):
+        """qk_proj along the token axis: [n, F, D] -> [n, T, D] (a Linear(F, T) applied to the transposed tokens, tpmcl_utils.py:36)."""
+        n, F, D = q.shape
+        y = tpmcl.linear_f32(q.float().transpose(-2, -1).reshape(n * D, F), self.qk_proj.weight, self.qk_proj.bias)
+        return y.reshape(n, D, -1).transpose(-1, -2)
+
+    def _item_pieces(self, q_items, k_items):
+        """Per-ITEM pieces of the pair function (see forward_all_pairs): projected query tokens, their sums, and the two halves of the MLP's
+        first Linear applied per item."""
+        ln, fc_a = self.attn_proj[0], self.attn_proj[1]
+        D = self.embed_dim
+        qp = self._token_map(q_items)                                                   # [n_q, T, D]
+        kf = k_items.float()                                                            # [n_k, T, D]
+        gam, bet, W = ln.weight.float(), ln.bias.float(), fc_a.weight                    # [T, 2D], [T, 2D], [D/2, 2D]
+        A = tpmcl.linear_f32(qp * gam[None, :, :D], W[:, :D])                            # [n_q, T, D/2]
+        Bm = tpmcl.linear_f32(kf * gam[None, :, D:], W[:, D:])                           # [n_k, T, D/2]
+        c = tpmcl.linear_f32(gam, W)                                                     # [T, D/2]
+        d = tpmcl.linear_f32(bet, W)
+        return qp, kf, A, Bm, c, d
+
+    def _pair_tail(self, h):
+        """GELU, the D/2 -> 1 dot, sigmoid and the normalisation over the tokens: [..., T, D/2] -> [..., T]."""
+        _, _, act, fc_b, sig = self.attn_proj
+        w = sig((act(h) * fc_b.weight.float().reshape(-1)).sum(-1))
+        return w / w.sum(dim=-1, keepdim=True)
+
+    def forward_pairs(self, q_items, k_items, q_idx, k_idx):
+        """forward(q_items[q_idx[p]], k_items[k_idx[p]]) for the listed pairs only: -> [P, tokens] (same algebra as forward_all_pairs; what TPM-CL
+        needs are the pairs of the blocks that hold a diagonal entry)."""
+        qp, kf, A, Bm, c, d = self._item_pieces(q_items, k_items)
+        N = float(qp.shape[1] * 2 * self.embed_dim)
+        s1 = kf.sum(dim=(1, 2))[k_idx] + qp.sum(dim=(1, 2))[q_idx]                      # [P]
+        s2 = (kf * kf).sum(dim=(1, 2))[k_idx] + (qp * qp).sum(dim=(1, 2))[q_idx]
+        mu = s1 / N
+        r = torch.rsqrt((s2 / N - mu * mu).clamp_min(0.0) + self.attn_proj[0].eps)
+        h = r[:, None, None] * (Bm[k_idx] + A[q_idx]) - (r * mu)[:, None, None] * c + d   # [P, T, D/2]
+        return self._pair_tail(h)
 
     def forward_all_pairs(self, q_items, k_items):
         """forward(q, k) for EVERY (k item, q item) pair without materialising the pair batch: -> [n_k, n_q, tokens].
@@ -139,23 +181,14 @@ class LinearXWeightPredictor(nn.Module):
         What is left per pair is the elementwise tail (GELU, the D/2 -> 1 dot, sigmoid, normalisation over the tokens).  The reference
         (tpmcl_utils.py:35-50) evaluates the same function pair by pair on repeat / repeat_interleave copies; fp32 throughout, the result
         differs from the pair-batch evaluation by summation order only."""
-        ln, fc_a, act, fc_b, sig = self.attn_proj
-        D = self.embed_dim
-        qp = self.qk_proj(q_items.float().transpose(-2, -1)).transpose(-1, -2)          # [n_q, T, D]
-        kf = k_items.float()                                                            # [n_k, T, D]
-        N = float(qp.shape[1] * 2 * D)
+        qp, kf, A, Bm, c, d = self._item_pieces(q_items, k_items)
+        N = float(qp.shape[1] * 2 * self.embed_dim)
         s1 = kf.sum(dim=(1, 2))[:, None] + qp.sum(dim=(1, 2))[None, :]                   # [n_k, n_q]
         s2 = (kf * kf).sum(dim=(1, 2))[:, None] + (qp * qp).sum(dim=(1, 2))[None, :]
         mu = s1 / N
-        r = torch.rsqrt((s2 / N - mu * mu).clamp_min(0.0) + ln.eps)
-        gam, bet, W = ln.weight.float(), ln.bias.float(), fc_a.weight.float()            # [T, 2D], [T, 2D], [D/2, 2D]
-        A = torch.matmul(qp * gam[None, :, :D], W[:, :D].t())                            # [n_q, T, D/2]
-        Bm = torch.matmul(kf * gam[None, :, D:], W[:, D:].t())                           # [n_k, T, D/2]
-        c = torch.matmul(gam, W.t())                                                     # [T, D/2]
-        d = torch.matmul(bet, W.t())
+        r = torch.rsqrt((s2 / N - mu * mu).clamp_min(0.0) + self.attn_proj[0].eps)
         h = r[:, :, None, None] * (Bm[:, None] + A[None, :]) - (r * mu)[:, :, None, None] * c + d     # [n_k, n_q, T, D/2]
-        w = sig(fc_b(act(h))).squeeze(-1)                                                # [n_k, n_q, T]
-        return w / w.sum(dim=-1, keepdim=True)
+        return self._pair_tail(h)                                                        # [n_k, n_q, T]
 
 
 class TokenImportanceSelector(nn.Module):
@@ -166,10 +199,14 @@ class TokenImportanceSelector(nn.Module):
         super().__init__()
         self.register_buffer("thresh", thresh * torch.ones(1))
 
+    def keep_mask(self, attn_weight):
+        """[R, T] weights -> 0 / 1 keep policy (one wave per row on the device: the descending inclusive prefix sum of every token)."""
+        if not hasattr(self, "_thresh_f"):
+            self._thresh_f = float(self.thresh)      # a construction-time constant: read once (one host sync per model, not per step)
+        return tpmcl.tis_keep(attn_weight, self._thresh_f)
+
     def forward(self, x, attn_weight):
-        w_sorted, order = attn_weight.sort(dim=1, descending=True)
-        drop = torch.zeros_like(attn_weight).scatter(1, order, (w_sorted.cumsum(dim=1) < self.thresh).to(attn_weight.dtype))
-        keep = 1.0 - drop
+        keep = self.keep_mask(attn_weight)
         return x * keep.unsqueeze(-1).to(x.dtype), keep
 
 
@@ -234,8 +271,8 @@ class DmaeUtils(nn.Module):
             if isinstance(m, nn.Linear):
                 x = HF.linear(x.to(torch.bfloat16).contiguous(), m.weight, m.bias, act="relu").float()
         last = layers[-1]
-        z = torch.nn.functional.linear(x, last.weight.float(), last.bias.float()).squeeze(2)   # Linear(D, 1): a [*, D] x [D] reduction
-        return torch.softmax(z.masked_fill(mask.float() < 0.5, float("-inf")), dim=-1)
+        # Linear(D, 1) + masked softmax over the tokens: one kernel, the features are read once
+        return tpmcl.token_weights(x.contiguous(), last.weight, last.bias, mask.float().contiguous())
 
     def _get_wti_similarity(self, text_feat, video_feat, text_mask, video_mask, text_weight=None, video_weight=None, self_weight=False):
         return contrastive.wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight, video_weight,
@@ -313,7 +350,9 @@ class DmaeUtils(nn.Module):
             video_mask = video_mask.repeat_interleave(video_feat.shape[1] // video_mask.shape[1], dim=1)
         if text_mask.shape[1] != text_feat.shape[1]:
             text_mask = text_mask[:, :1]
-        logits = torch.einsum("ctd,cvd->ctv", text_feat, video_feat) * text_mask[:, :, None] * video_mask[:, None, :]
+        # 'ctd,cvd->ctv' on aligned pairs: one pass per text token (TPM-CL passes a single sentence / global token)
+        logits = torch.stack([tpmcl.pair_dots(text_feat[:, t_].contiguous(), video_feat) for t_ in range(text_feat.shape[1])], dim=1)
+        logits = logits * text_mask[:, :, None] * video_mask[:, None, :]
         t2v, v2t = logits.max(dim=-1).values, logits.max(dim=-2).values
         if "wti" in self.interaction:
             tw = self._masked_softmax(self.text_weight_fc, text_feat, text_mask)
@@ -345,12 +384,12 @@ class DmaeUtils(nn.Module):
         vis_j, vmask_j = visual_output.repeat_interleave(bt, 0), video_mask.repeat_interleave(bt, 0)
         word_w = self.v2t_linear_xwp(vis_i, words_i)            # word importance given the video   [bt*bv, Nw]
         frame_w = self.t2v_linear_xwp(sent_j, vis_j)            # frame importance given the caption [bt*bv, V]
-        glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)
+        glob = tpmcl.pair_wsum(word_w, words_i)
         glob = (glob / glob.norm(dim=-1, keepdim=True)).unsqueeze(1)
         out = dict.fromkeys(("t2vh", "t2vhh", "tg2vh", "tg2vhh", "tgh2vh"))
         if self.training and partial_type >= 2:
-            words_masked, _ = self.tis_selector(words_i.float(), word_w)
-            glob_partial = torch.einsum("abd,ab->ad", words_masked, word_w).unsqueeze(1)
+            # sum_t w_t (x_t keep_t) = sum_t (w_t keep_t) x_t: the masked words are never materialised
+            glob_partial = tpmcl.pair_wsum(word_w * self.tis_selector.keep_mask(word_w), words_i).unsqueeze(1)
             vis_masked, _ = self.tis_selector(vis_j.float(), frame_w)
             vis_partial, vmask_p, _ = self._agg_visual_feat(vis_masked, vmask_j, sim_header=self.sim_header)
             row = lambda a, b, ma, mb: self._loose_similarity_row(a, b, ma, mb, sim_header=self.sim_header)  # noqa: E731
@@ -361,53 +400,52 @@ class DmaeUtils(nn.Module):
             out["tgh2vh"] = row(glob_partial, vis_i, wmask_i, vmask_i).reshape(bt, bv)
         return out
 
+    @staticmethod
+    def _diagonal_blocks(Bt, Bv, bt, bv):
+        """The (caption block, video block) pairs of the bt x bv tiling that hold an entry (i, i): the only blocks the margin losses read
+        (they take torch.diag of the [B_t, B_v] matrices, reference :379-388), and a block's scores depend on nothing outside the block."""
+        return sorted({(i // bt, i // bv) for i in range(min(Bt, Bv))})
+
     def _get_partial_output_blocks(self, sequence_output, visual_output, attention_mask, video_mask, bt=8, bv=16, partial_type=4):
-        """ALL 8 x 16 caption x video blocks of _get_partial_output in one batched pass (the reference walks them in a Python double loop to bound
-        its memory; on 288 GB the B_t x B_v pairs of a step fit at once): every per-pair operator is evaluated over the concatenation of the
-        blocks' pair batches -- pair orderings inside a block as in the reference ("_i" caption-major, "_j" video-major) -- and the one
-        operator that couples the pairs of a block (the token-weight sums of wti_interaction_row) keeps its sums inside the blocks.
-        Returns the five [B_t, B_v] matrices.  Requires B_t % bt == 0 and B_v % bv == 0 (the loop handles ragged edges)."""
+        """The 8 x 16 caption x video blocks of _get_partial_output THAT HOLD A DIAGONAL ENTRY, in one batched pass (the reference walks all blocks
+        in a Python double loop): every per-pair operator is evaluated over the concatenation of those blocks' pair batches -- pair orderings
+        inside a block as in the reference ("_i" caption-major, "_j" video-major) -- and the one operator that couples the pairs of a block
+        (the token-weight sums of wti_interaction_row) keeps its sums inside the blocks.  Returns the five [B_t, B_v] matrices with the
+        evaluated blocks filled in and zeros elsewhere (never read: see _diagonal_blocks).  Requires B_t % bt == 0 and B_v % bv == 0 (the
+        loop handles ragged edges)."""
         sent, words = sequence_output
         Bt, Bv = sent.shape[0], visual_output.shape[0]
-        nbt, nbv = Bt // bt, Bv // bv
-        nb, dev = nbt * nbv, sent.device
-        # pair batches as broadcast views (backward = a reduction over the broadcast axes, no index_put): block n = a nbv + b covers captions
-        # a bt + i and videos b bv + j; caption-major pairs [a, b, i, j], video-major pairs [a, b, j, i]
-        def cap(x, video_major):
-            x = x.reshape(nbt, 1, 1, bt, *x.shape[1:]) if video_major else x.reshape(nbt, 1, bt, 1, *x.shape[1:])
-            full = (nbt, nbv, bv, bt) if video_major else (nbt, nbv, bt, bv)
-            return x.expand(*full, *x.shape[4:]).reshape(nb * bt * bv, *x.shape[4:])
-
-        def vid(x, video_major):
-            x = x.reshape(1, nbv, bv, 1, *x.shape[1:]) if video_major else x.reshape(1, nbv, 1, bv, *x.shape[1:])
-            full = (nbt, nbv, bv, bt) if video_major else (nbt, nbv, bt, bv)
-            return x.expand(*full, *x.shape[4:]).reshape(nb * bt * bv, *x.shape[4:])
-
-        sent_j, wmask_j = cap(sent, True), cap(attention_mask, True)
-        words_i, wmask_i = cap(words, False), cap(attention_mask, False)
-        vis_i, vmask_i = vid(visual_output, False), vid(video_mask, False)
-        vis_j, vmask_j = vid(visual_output, True), vid(video_mask, True)
+        dev = sent.device
+        blocks = self._diagonal_blocks(Bt, Bv, bt, bv)
+        nb = len(blocks)
+        cap_idx = (torch.tensor([a for a, _ in blocks], device=dev)[:, None] * bt + torch.arange(bt, device=dev)[None, :])   # [nb, bt]
+        vid_idx = (torch.tensor([b for _, b in blocks], device=dev)[:, None] * bv + torch.arange(bv, device=dev)[None, :])   # [nb, bv]
+        # pair index lists: caption-major p = (n, i, j), video-major p = (n, j, i)
+        ci_i = cap_idx[:, :, None].expand(nb, bt, bv).reshape(-1)
+        vi_i = vid_idx[:, None, :].expand(nb, bt, bv).reshape(-1)
+        ci_j = cap_idx[:, None, :].expand(nb, bv, bt).reshape(-1)
+        vi_j = vid_idx[:, :, None].expand(nb, bv, bt).reshape(-1)
+        sent_j, wmask_j = sent[ci_j], attention_mask[ci_j]
+        words_i, wmask_i = words[ci_i].float(), attention_mask[ci_i]
+        vis_i, vmask_i = visual_output[vi_i].float(), video_mask[vi_i]
+        vis_j, vmask_j = visual_output[vi_j].float(), video_mask[vi_j]
         if self.v2t_linear_xwp._qk_same_embed_dim and self.t2v_linear_xwp._qk_same_embed_dim and not self.config.get("l3_xwp_pair_batch", False):
-            # token-importance weights of all B_t x B_v pairs from per-caption / per-video pieces (LinearXWeightPredictor.forward_all_pairs),
-            # then laid out in the pair orders the rest of this function uses: caption-major [a, b, i, j] / video-major [a, b, j, i]
-            ww = self.v2t_linear_xwp.forward_all_pairs(visual_output, words)             # [B_t, B_v, Nw]   (k = words of caption i, q = video j)
-            fw = self.t2v_linear_xwp.forward_all_pairs(sent, visual_output)              # [B_v, B_t, V]    (k = frames of video j, q = caption i)
-            word_w = ww.reshape(nbt, bt, nbv, bv, -1).permute(0, 2, 1, 3, 4).reshape(nb * bt * bv, -1)
-            frame_w = fw.reshape(nbv, bv, nbt, bt, -1).permute(2, 0, 1, 3, 4).reshape(nb * bt * bv, -1)
+            # token-importance weights from per-caption / per-video pieces (LinearXWeightPredictor.forward_pairs): no pair batch for the predictors
+            word_w = self.v2t_linear_xwp.forward_pairs(visual_output, words, vi_i, ci_i)      # [P, Nw]  (k = words of caption i, q = video j)
+            frame_w = self.t2v_linear_xwp.forward_pairs(sent, visual_output, ci_j, vi_j)      # [P, V]   (k = frames of video j, q = caption i)
         else:
             word_w = self.v2t_linear_xwp(vis_i, words_i)
             frame_w = self.t2v_linear_xwp(sent_j, vis_j)
-        glob = torch.einsum("abd,ab->ad", words_i.float(), word_w)
+        glob = tpmcl.pair_wsum(word_w, words_i)
         glob = (glob / glob.norm(dim=-1, keepdim=True)).unsqueeze(1)
-        words_masked, _ = self.tis_selector(words_i.float(), word_w)
-        glob_partial = torch.einsum("abd,ab->ad", words_masked, word_w).unsqueeze(1)
-        vis_masked, _ = self.tis_selector(vis_j.float(), frame_w)
+        glob_partial = tpmcl.pair_wsum(word_w * self.tis_selector.keep_mask(word_w), words_i).unsqueeze(1)   # the masked words are never materialised
+        vis_masked = vis_j * self.tis_selector.keep_mask(frame_w).unsqueeze(-1)
         vis_partial, vmask_p, _ = self._agg_visual_feat(vis_masked, vmask_j, sim_header=self.sim_header)
         row = lambda x, y, mx, my: self._loose_similarity_row(x, y, mx, my, sim_header=self.sim_header, nblocks=nb)  # noqa: E731
 
-        def grid(x, video_major):   # [nb * bt * bv] scores -> [B_t, B_v]
-            blk = x.view(nb, bv, bt).transpose(1, 2) if video_major else x.view(nb, bt, bv)
-            return blk.reshape(nbt, nbv, bt, bv).permute(0, 2, 1, 3).reshape(Bt, Bv)
+        def grid(x, video_major):   # [nb * bt * bv] scores -> [B_t, B_v], zeros outside the evaluated blocks
+            M = torch.zeros(Bt, Bv, dtype=x.dtype, device=dev)
+            return M.index_put((ci_j, vi_j) if video_major else (ci_i, vi_i), x)
 
         return {"t2vhh": grid(row(sent_j, vis_partial, wmask_j, vmask_p), True), "t2vh": grid(row(sent_j, vis_i, wmask_j, vmask_i), False),
                 "tg2vh": grid(row(glob, vis_i, wmask_i, vmask_i), False), "tg2vhh": grid(row(glob, vis_partial, wmask_i, vmask_p), True),
@@ -429,12 +467,17 @@ class DmaeUtils(nn.Module):
             M = self._get_partial_output_blocks(sequence_output, visual_output, attention_mask, video_mask, 8, 16, partial_type)
             return self._partial_losses(M, partial_type)
         rows = {n: [] for n in names}
+        needed = set(self._diagonal_blocks(sent.shape[0], visual_output.shape[0], 8, 16))
         for t0 in range(0, sent.shape[0], 8):          # the reference's block sizes: 8 captions x 16 videos
             cols = {n: [] for n in names}
             blk = (sent[t0:t0 + 8], words[t0:t0 + 8])
             for v0 in range(0, visual_output.shape[0], 16):
-                o = self._get_partial_output(blk, visual_output[v0:v0 + 16], attention_mask[t0:t0 + 8], video_mask[v0:v0 + 16],
-                                             xwp_type="linear", partial_type=partial_type)
+                if (t0 // 8, v0 // 16) in needed:
+                    o = self._get_partial_output(blk, visual_output[v0:v0 + 16], attention_mask[t0:t0 + 8], video_mask[v0:v0 + 16],
+                                                 xwp_type="linear", partial_type=partial_type)
+                else:   # no diagonal entry: never read by the margin losses
+                    z = sent.new_zeros((blk[0].shape[0], visual_output[v0:v0 + 16].shape[0]), dtype=torch.float32)
+                    o = {n: z for n in names}
                 for n in names:
                     cols[n].append(o[n])
             for n in names:

@@ -231,6 +231,24 @@ int antmmf_wti_reduce_fwd(const float* S, int A, int T, int B, int V, const floa
 int antmmf_wti_reduce_bwd(const float* S, int A, int T, int B, int V, const float* tmask, const float* vmask, const float* f2f,
                           const int* z2_of, const int* z1, const int* tmax, const float* dt2v, const float* dv2t, void* dS,
                           float* df2f, int out_dtype, antmmf_stream_t stream);
+/* ---- DMAE stage-3 head, small fp32 row kernels (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:147-165,411-470; tpmcl_utils.py:101-121).
+ * token weights: out[n, t] = softmax over t of (feat[n, t, :] . w + bias[0]), tokens with mask[n, t] < 0.5 excluded (weight 0);
+ * replaces Linear(D, 1) + masked_fill + softmax.  feat [N, T, D], mask [N, T] (nullable), T <= 128. */
+int antmmf_token_weight_fwd(const float* feat, const float* w, const float* bias, const float* mask, float* out, int N, int T, int D,
+                            antmmf_stream_t stream);
+/* backward: dfeat [N, T, D] (nullable, fully written), dw [D] and dbias [1] (nullable) ACCUMULATED; p = the forward output; scratch: fp32
+ * workspace of >= 512 * (D + 1) floats for the per-workgroup partial sums (deterministic, no atomics).  D <= 1024. */
+int antmmf_token_weight_bwd(const float* feat, const float* w, const float* p, const float* dout, float* dfeat, float* dw, float* dbias,
+                            float* scratch, long scratch_floats, int N, int T, int D, antmmf_stream_t stream);
+/* aligned-pair token products (einsum 'ctd,cvd->ctv' with one text token; einsum 'abd,ab->ad'):
+ *   pair_dots  out[c, v]    = x[c, :] . y[c, v, :]          pair_wsum  out[c, :] = sum_v w[c, v] y[c, v, :]
+ *   pair_outer out[c, v, :] = w[c, v] x[c, :]               (each is the gradient of the others; V <= 128 for wsum / outer) */
+int antmmf_pair_dots(const float* x, const float* y, float* out, int C, int V, int D, antmmf_stream_t stream);
+int antmmf_pair_wsum(const float* w, const float* y, float* out, int C, int V, int D, antmmf_stream_t stream);
+int antmmf_pair_outer(const float* w, const float* x, float* out, int C, int V, int D, antmmf_stream_t stream);
+/* TokenImportanceSelector's keep mask (tpmcl_utils.py:101-121): keep[r, t] = 0 where the cumulative weight of the tokens in descending
+ * order, token t included, is < thresh; 1 elsewhere.  T <= 64. */
+int antmmf_tis_keep(const float* w, float thresh, float* keep, int R, int T, antmmf_stream_t stream);
 /* ---- retrieval evaluation (antmmf/modules/metrics/global_retrieval_recall.py:13-89): rank[i] = min over the ground-truth columns
  * gt_idx[gt_off[i] .. gt_off[i+1]) of #{ j : S[i][j] > S[i][g] } (0 = first).  S fp32 [rows, cols] with row stride ld. */
 int antmmf_rank_rows(const float* S, int64_t ld, int rows, int cols, const int* gt_off, const int* gt_idx, int* rank,

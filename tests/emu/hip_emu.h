@@ -117,6 +117,28 @@ static inline float __shfl(float v, int src, int = 64) {
     w->bar.arrive_and_wait();
     return r;
 }
+// wave-wide reductions in TWO barriers instead of a six-step shuffle butterfly (12 barriers of 64 OS threads each): every lane adds the 64 values
+// in butterfly order (pairs, then pairs of pairs, ...), so the result is the butterfly's bit for bit, the same in every lane
+static inline float emu_wave_sum(float v) {
+    auto* w = emu::tls.wave;
+    w->fbuf[emu::tls.lane] = v;
+    w->bar.arrive_and_wait();
+    float t[64];
+    for (int i = 0; i < 64; ++i) t[i] = w->fbuf[i];
+    w->bar.arrive_and_wait();
+    for (int n = 64; n > 1; n >>= 1)
+        for (int i = 0; i < n / 2; ++i) t[i] = t[i] + t[i + n / 2];
+    return t[0];
+}
+static inline float emu_wave_max(float v) {
+    auto* w = emu::tls.wave;
+    w->fbuf[emu::tls.lane] = v;
+    w->bar.arrive_and_wait();
+    float m = w->fbuf[0];
+    for (int i = 1; i < 64; ++i) m = m > w->fbuf[i] ? m : (w->fbuf[i] > m ? w->fbuf[i] : m);
+    w->bar.arrive_and_wait();
+    return m;
+}
 static inline float atomicAdd(float* p, float v) {
     auto* a = reinterpret_cast<std::atomic<float>*>(p);
     float old = a->load();

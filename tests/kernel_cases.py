@@ -511,6 +511,66 @@ def case_dmae_losses(contrastive, dev, B=9):
             check(f"dmae.{name}.grad", Sd.grad, S.grad, 2e-3, 1e-4)
 
 
+def case_tpmcl_ops(dev, C=37, V=13, T=30, D=96):
+    """The DMAE stage-3 head kernels (csrc/tpmcl.hip) through their autograd wrappers vs plain torch fp32 on the same inputs: token weights
+    (Linear(D, 1) + masked softmax; reference dmae_utils.py:147-165), aligned-pair dots / weighted sums (the two einsums of
+    wti_interaction_row and the global-feature prediction), the TokenImportanceSelector mask vs its sort / cumsum / scatter form
+    (tpmcl_utils.py:101-121), and linear_f32 (hi / lo split GEMM) forward and both gradients."""
+    from antmmf.hip import tpmcl
+
+    feat = rnd((C, T, D), 701, 1.0)
+    w, b = rnd((1, D), 702, 0.3), rnd((1,), 703, 0.1)
+    mask = (rnd((C, T), 704, 1.0) > -0.5).float()
+    mask[:, 0] = 1.0
+    dout = rnd((C, T), 705, 1.0)
+    fr, wr, br = (x.clone().requires_grad_(True) for x in (feat, w, b))
+    ref = torch.softmax((fr @ wr.t()).squeeze(-1).add(br).masked_fill(mask < 0.5, float("-inf")), dim=-1)
+    (ref * dout).sum().backward()
+    fd, wd, bd = (x.clone().to(dev).requires_grad_(True) for x in (feat, w, b))
+    got = tpmcl.token_weights(fd, wd, bd, mask.to(dev))
+    (got * dout.to(dev)).sum().backward()
+    check("tpm.token_weights", got, ref.detach(), 1e-5, 1e-6)
+    check("tpm.token_weights.dfeat", fd.grad, fr.grad, 1e-4, 1e-6)
+    check("tpm.token_weights.dw", wd.grad, wr.grad, 1e-4, 1e-5)
+    # (the bias gradient vanishes analytically -- a softmax does not see a shift of its logits: both sides hold rounding noise)
+    assert float(bd.grad.abs().max()) <= 1e-5 * float(wr.grad.abs().max()), (float(bd.grad), float(br.grad))
+    assert float(got[mask.to(dev) < 0.5].abs().max()) == 0.0
+
+    x, y, ww = rnd((C, D), 706, 1.0), rnd((C, V, D), 707, 1.0), rnd((C, V), 708, 1.0)
+    g1, g2 = rnd((C, V), 709, 1.0), rnd((C, D), 710, 1.0)
+    xr, yr, wwr = (t.clone().requires_grad_(True) for t in (x, y, ww))
+    dref = torch.einsum("cd,cvd->cv", xr, yr)
+    sref = torch.einsum("cv,cvd->cd", wwr, yr)
+    ((dref * g1).sum() + (sref * g2).sum()).backward()
+    xd, yd, wwd = (t.clone().to(dev).requires_grad_(True) for t in (x, y, ww))
+    dgot, sgot = tpmcl.pair_dots(xd, yd), tpmcl.pair_wsum(wwd, yd)
+    ((dgot * g1.to(dev)).sum() + (sgot * g2.to(dev)).sum()).backward()
+    check("tpm.pair_dots", dgot, dref.detach(), 1e-5, 1e-5)
+    check("tpm.pair_wsum", sgot, sref.detach(), 1e-5, 1e-5)
+    check("tpm.pair.dx", xd.grad, xr.grad, 1e-5, 1e-5)
+    check("tpm.pair.dy", yd.grad, yr.grad, 1e-5, 1e-5)
+    check("tpm.pair.dw", wwd.grad, wwr.grad, 1e-5, 1e-5)
+
+    for thresh in (0.6, 0.3, 0.95):
+        wts = torch.softmax(rnd((C, V), 711, 2.0), dim=-1)
+        ws, order = wts.sort(dim=1, descending=True)
+        keep_ref = 1.0 - torch.zeros_like(wts).scatter(1, order, (ws.cumsum(dim=1) < thresh).float())
+        keep = tpmcl.tis_keep(wts.to(dev), thresh)
+        assert torch.equal(keep.cpu(), keep_ref), (thresh, (keep.cpu() != keep_ref).sum())
+
+    X, Wm = rnd((3, 11, 40), 712, 1.0), rnd((24, 40), 713, 0.2)
+    bias = rnd((24,), 714, 0.1)
+    G = rnd((3, 11, 24), 715, 1.0)
+    Xr, Wr = X.clone().requires_grad_(True), Wm.clone().requires_grad_(True)
+    (torch.nn.functional.linear(Xr, Wr, bias) * G).sum().backward()
+    Xd, Wd = X.clone().to(dev).requires_grad_(True), Wm.clone().to(dev).requires_grad_(True)
+    out = tpmcl.linear_f32(Xd, Wd, bias.to(dev))
+    (out * G.to(dev)).sum().backward()
+    check("tpm.linear_f32", out, torch.nn.functional.linear(X, Wm, bias), 2e-5, 2e-5)   # hi / lo split: fp32-class accuracy out of bf16 MFMAs
+    check("tpm.linear_f32.dx", Xd.grad, Xr.grad, 2e-5, 2e-5)
+    check("tpm.linear_f32.dw", Wd.grad, Wr.grad, 2e-5, 2e-5)
+
+
 def case_retrieval_metrics(dev, golden):
     """GlobalRetrievalRecall's rank kernel + reductions vs the reference metric run (metric_recall.pt): square matrix with the
     diagonal as ground truth, and a 17 x 11 matrix with explicit (multi-)ground-truth lists in both directions."""

@@ -578,14 +578,14 @@ print("okdmae", float(l1), r1, float(l3), r3, rel[:2], dirs)
     return code
 
 
-def case_dmae_tpmcl(dev, golden):
+def case_dmae_tpmcl(dev, golden, ptypes=(2, 3, 4)):
     """DmaeUtils.get_partial_similarity (TPM-CL margin losses, types 2 / 3 / 4) on the device vs the reference run."""
     from antmmf.common.configuration import Configuration
 
     g = golden("ops_dmae_tpmcl.pt")
     mod = load_dmae_utils()
     res = {}
-    for ptype in (2, 3, 4):
+    for ptype in ptypes:
         du = mod.DmaeUtils(Configuration(dict(DMAE_CFG, l3_interaction="wti", l3_with_nfc=True, l3_sim_header="meanP", l3_partial_type=ptype,
                                               l3_max_frames=4, l3_max_words=12)))
         W.fill_module_(du)

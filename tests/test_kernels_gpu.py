@@ -175,6 +175,11 @@ def test_dmae_losses(ops):
     kc.case_dmae_losses(contrastive, DEV)
 
 
+def test_tpmcl_ops(ops):
+    kc.case_tpmcl_ops(DEV)
+    kc.case_tpmcl_ops(DEV, C=2048, V=13, T=30, D=768)   # the dmae12 bench's pair count and widths
+
+
 def test_retrieval_metrics(ops, golden):
     kc.case_retrieval_metrics(DEV, golden)
 

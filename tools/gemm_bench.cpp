@@ -1,8 +1,12 @@
 // gemm_bench.cpp -- within-process A/B of the NT GEMM kernel variants of libantmmf_hip.so on the ViT-L/14 step's shapes.
-// Build: hipcc -O2 tools/gemm_bench.cpp -o tools/gemm_bench -ldl      Run (GPU box): tools/gemm_bench [pairs=1024] [rounds=3]
-// Variants are selected with antmmf_debug_set_gemm_variant (0 = product default).  Prints one JSON line per (shape, variant):
+// Build: hipcc -O2 tools/gemm_bench.cpp -o tools/gemm_bench -ldl -lhipblaslt      Run (GPU box): tools/gemm_bench [pairs=1024] [rounds=3]
+// GEMM_BENCH_HIPBLASLT=1 adds, per NT shape, the vendor library on the SAME buffers, interleaved in the same rounds ("the honest
+// baseline to beat"): hipblasLtMatmul, bf16 in / bf16 out, fp32 compute, the same fused epilogue (bias vector; residual as beta = 1 on a
+// separate C), the best of the first 16 heuristic algorithms (each timed once, the winner re-timed with the others).
+// Variants are selected with antmmf_debug_set_gemm_variant (4 = the product default: BK = 64 persistent kernels; 0 = the round-1 BK = 32 ring).  Prints one JSON line per (shape, variant):
 // median TFLOP/s over interleaved rounds, and the max |difference| of the variant's output against variant 0 (same K order: expected 0).
 #include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstdint>
@@ -24,6 +28,7 @@ __global__ void maxdiff_f32(const float* a, const float* b, long n, unsigned* ou
     }
     atomicMax(out, m); atomicMax(outmag, mm);
 }
+#define LT(x) do { hipblasStatus_t s_ = (x); if (s_ != HIPBLAS_STATUS_SUCCESS) { printf("hipBLASLt error %d at %d\n", (int)s_, __LINE__); exit(1); } } while (0)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 __global__ void fill_bf16(uint16_t* p, long n, uint32_t seed, float scale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -72,12 +77,20 @@ int main(int argc, char** argv) {
     fill_bf16<<<4096, 256>>>(Rz, tokens * 4096, 3u, 1.0f);
     fill_f32<<<16, 256>>>(bias, 4096, 4u);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const bool with_lt = getenv("GEMM_BENCH_HIPBLASLT") != nullptr;
+    hipblasLtHandle_t lt = nullptr;
+    void* lt_ws = nullptr; const size_t lt_ws_bytes = 256u << 20;
+    uint16_t* biasb = nullptr;   // the library's bias vector in the output type (bf16) -- ours reads fp32
+    if (with_lt) { LT(hipblasLtCreate(&lt)); CK(hipMalloc(&lt_ws, lt_ws_bytes)); CK(hipMalloc(&biasb, 4096 * 2)); fill_bf16<<<16, 256>>>(biasb, 4096, 4u, 1.0f); }
     for (const Shape& s : shapes) {
         fill_bf16<<<4096, 256>>>(W, (long)s.J * (s.R + pad), 2u, 1.0f / sqrtf((float)s.R));
         CK(hipDeviceSynchronize());
+        // GEMM_BENCH_RES_LD0=1: ablation -- every row of the residual tile reads the SAME 512 bytes (leading dimension 0: cache-resident): what is
+        // left of the residual epilogue's cost is its instruction path, what disappears is the HBM burst / latency of the residual tile
+        static const bool res_ld0 = getenv("GEMM_BENCH_RES_LD0") != nullptr;
         auto run = [&](int v, uint16_t* out) {
             setv(v);
-            return gemm(A, W, out, (int)tokens, s.J, s.R, s.R + pad, s.R + pad, s.J, 0, 0, 1, 1.0f, s.bias ? bias : nullptr, 0, s.res ? Rz : nullptr, s.J, nullptr, 0, nullptr, 0, 0, 1, 0);
+            return gemm(A, W, out, (int)tokens, s.J, s.R, s.R + pad, s.R + pad, s.J, 0, 0, 1, 1.0f, s.bias ? bias : nullptr, 0, s.res ? Rz : nullptr, res_ld0 ? 0 : s.J, nullptr, 0, nullptr, 0, 0, 1, 0);
         };
         std::vector<std::vector<double>> ms(variants.size());
         std::vector<float> diff(variants.size(), 0.f);
@@ -102,6 +115,67 @@ int main(int argc, char** argv) {
                 float t; CK(hipEventElapsedTime(&t, e0, e1));
                 ms[vi].push_back(t / iters);
             }
+        if (with_lt) {
+            // row-major C[T, J] = A[T, R] W[J, R]^T  ==  column-major C^T (J x T, ld J) = op_T(W buffer: R x J, ld R) * (A buffer: R x T, ld R)
+            hipblasLtMatmulDesc_t md; hipblasLtMatrixLayout_t la, lb, lc; hipblasLtMatmulPreference_t pref;
+            LT(hipblasLtMatmulDescCreate(&md, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+            hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+            LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)));
+            LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)));
+            if (s.bias) {
+                hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS; hipDataType bt = HIP_R_16BF; const void* bp = biasb;
+                LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+                LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+                LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)));
+            }
+            LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, s.R, s.J, s.R + pad));
+            LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, s.R, tokens, s.R + pad));
+            LT(hipblasLtMatrixLayoutCreate(&lc, HIP_R_16BF, s.J, tokens, s.J));
+            LT(hipblasLtMatmulPreferenceCreate(&pref));
+            uint64_t wsb = lt_ws_bytes;
+            LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)));
+            hipblasLtMatmulHeuristicResult_t heur[16]; int nh = 0;
+            LT(hipblasLtMatmulAlgoGetHeuristic(lt, md, la, lb, lc, lc, pref, 16, heur, &nh));
+            const float one = 1.0f, beta = s.res ? 1.0f : 0.0f;
+            auto run_lt = [&](int a) { return hipblasLtMatmul(lt, md, &one, W, la, A, lb, &beta, s.res ? Rz : C1, lc, C1, lc, &heur[a].algo, lt_ws, lt_ws_bytes, 0); };
+            const int own_v = 4;   // the product's kernels, whatever GEMM_BENCH_VARIANTS lists
+            int best_a = -1; double best_ms = 1e30;
+            for (int a = 0; a < nh; ++a) {
+                if (run_lt(a) != HIPBLAS_STATUS_SUCCESS) continue;
+                CK(hipEventRecord(e0, 0));
+                for (int it = 0; it < 4; ++it) run_lt(a);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                if (t / 4 < best_ms) { best_ms = t / 4; best_a = a; }
+            }
+            if (best_a >= 0) {
+                // interleaved with the product kernel (variant 0), same rounds, same iteration count
+                std::vector<double> mlt, mown;
+                for (int r = 0; r < rounds; ++r) {
+                    const int iters = 8;
+                    run(own_v, C1);
+                    CK(hipEventRecord(e0, 0)); for (int it = 0; it < iters; ++it) run(own_v, C1); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    float t; CK(hipEventElapsedTime(&t, e0, e1)); mown.push_back(t / iters);
+                    run_lt(best_a);
+                    CK(hipEventRecord(e0, 0)); for (int it = 0; it < iters; ++it) run_lt(best_a); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&t, e0, e1)); mlt.push_back(t / iters);
+                }
+                std::sort(mlt.begin(), mlt.end()); std::sort(mown.begin(), mown.end());
+                // numerical agreement of the two libraries on the same operands (bf16 outputs; the bias vectors differ only by bf16 rounding)
+                run(own_v, C0); run_lt(best_a);
+                CK(hipMemset(dmax, 0, 4));
+                maxdiff<<<2048, 256>>>(C0, C1, tokens * s.J, dmax);
+                unsigned u; CK(hipMemcpy(&u, dmax, 4, hipMemcpyDeviceToHost));
+                const double fl = 2.0 * tokens * s.J * s.R;
+                printf("{\"shape\": \"%s\", \"I\": %ld, \"J\": %d, \"R\": %d, \"epi\": %d, \"hipblaslt_algos_tried\": %d, \"hipblaslt_ms_med\": %.4f, \"hipblaslt_tf_med\": %.1f, "
+                       "\"own_ms_med\": %.4f, \"own_tf_med\": %.1f, \"own_over_hipblaslt\": %.3f, \"maxdiff_own_vs_hipblaslt\": %g}\n",
+                       s.tag, tokens, s.J, s.R, s.bias | (s.res << 1), nh, mlt[mlt.size() / 2], fl / mlt[mlt.size() / 2] * 1e-9, mown[mown.size() / 2],
+                       fl / mown[mown.size() / 2] * 1e-9, mlt[mlt.size() / 2] / mown[mown.size() / 2], *reinterpret_cast<float*>(&u));
+                fflush(stdout);
+            } else printf("{\"shape\": \"%s\", \"hipblaslt\": \"no algorithm\"}\n", s.tag);
+            hipblasLtMatmulPreferenceDestroy(pref); hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(lb); hipblasLtMatrixLayoutDestroy(lc);
+            hipblasLtMatmulDescDestroy(md);
+        }
         for (size_t vi = 0; vi < variants.size(); ++vi) {
             std::sort(ms[vi].begin(), ms[vi].end());
             const double med = ms[vi][ms[vi].size() / 2], best = ms[vi][0];
@@ -140,6 +214,51 @@ int main(int argc, char** argv) {
                     float t; CK(hipEventElapsedTime(&t, e0, e1));
                     ms[vi].push_back(t / iters);
                 }
+            if (with_lt) {
+                // dW (row-major [n_out, k_in] fp32, accumulated) == column-major (k_in x n_out) = Xc (k_in x T) * Yc^T (Yc: n_out x T)
+                hipblasLtMatmulDesc_t md; hipblasLtMatrixLayout_t la, lb, lc; hipblasLtMatmulPreference_t pref;
+                LT(hipblasLtMatmulDescCreate(&md, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+                hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+                LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSA, &opN, sizeof(opN)));
+                LT(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSB, &opT, sizeof(opT)));
+                LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, w.k_in, tokens, w.k_in));
+                LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, w.n_out, tokens, w.n_out));
+                LT(hipblasLtMatrixLayoutCreate(&lc, HIP_R_32F, w.k_in, w.n_out, w.k_in));
+                LT(hipblasLtMatmulPreferenceCreate(&pref));
+                uint64_t wsb2 = lt_ws_bytes;
+                LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb2, sizeof(wsb2)));
+                hipblasLtMatmulHeuristicResult_t heur[16]; int nh = 0;
+                hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(lt, md, la, lb, lc, lc, pref, 16, heur, &nh);
+                const float one = 1.0f;
+                auto run_lt = [&](int a) { return hipblasLtMatmul(lt, md, &one, A, la, Rz, lb, &one, dW1, lc, dW1, lc, &heur[a].algo, lt_ws, lt_ws_bytes, 0); };
+                int best_a = -1; double best_ms = 1e30;
+                for (int a = 0; hs == HIPBLAS_STATUS_SUCCESS && a < nh; ++a) {
+                    if (run_lt(a) != HIPBLAS_STATUS_SUCCESS) continue;
+                    CK(hipEventRecord(e0, 0)); for (int it = 0; it < 4; ++it) run_lt(a); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    float t; CK(hipEventElapsedTime(&t, e0, e1));
+                    if (t / 4 < best_ms) { best_ms = t / 4; best_a = a; }
+                }
+                if (best_a >= 0) {
+                    std::vector<double> mlt, mown;
+                    for (int r = 0; r < rounds; ++r) {
+                        const int iters = 8; float t;
+                        runw(tv.back(), dW1);
+                        CK(hipEventRecord(e0, 0)); for (int it = 0; it < iters; ++it) runw(tv.back(), dW1); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&t, e0, e1)); mown.push_back(t / iters);
+                        run_lt(best_a);
+                        CK(hipEventRecord(e0, 0)); for (int it = 0; it < iters; ++it) run_lt(best_a); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                        CK(hipEventElapsedTime(&t, e0, e1)); mlt.push_back(t / iters);
+                    }
+                    std::sort(mlt.begin(), mlt.end()); std::sort(mown.begin(), mown.end());
+                    const double fl = 2.0 * tokens * w.n_out * w.k_in;
+                    printf("{\"shape\": \"%s\", \"tokens\": %ld, \"n_out\": %d, \"k_in\": %d, \"hipblaslt_algos_tried\": %d, \"hipblaslt_ms_med\": %.4f, \"hipblaslt_tf_med\": %.1f, \"own_variant\": %d, "
+                           "\"own_ms_med\": %.4f, \"own_tf_med\": %.1f, \"own_over_hipblaslt\": %.3f}\n", w.tag, tokens, w.n_out, w.k_in, nh, mlt[mlt.size() / 2],
+                           fl / mlt[mlt.size() / 2] * 1e-9, tv.back(), mown[mown.size() / 2], fl / mown[mown.size() / 2] * 1e-9, mlt[mlt.size() / 2] / mown[mown.size() / 2]);
+                    fflush(stdout);
+                } else printf("{\"shape\": \"%s\", \"hipblaslt\": \"no algorithm (status %d, %d candidates)\"}\n", w.tag, (int)hs, nh);
+                hipblasLtMatmulPreferenceDestroy(pref); hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(lb); hipblasLtMatrixLayoutDestroy(lc);
+                hipblasLtMatmulDescDestroy(md);
+            }
             for (size_t vi = 0; vi < tv.size(); ++vi) {
                 std::sort(ms[vi].begin(), ms[vi].end());
                 const double med = ms[vi][ms[vi].size() / 2], fl = 2.0 * tokens * w.n_out * w.k_in;
