@@ -12,6 +12,8 @@ Lightning plumbing are outside the step path.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -82,6 +84,21 @@ def init_weights(module):
         module.bias.data.zero_()
 
 
+def get_pretrained_tokenizer(tokenizer_type, from_pretrained):
+    """reference :121-127 (`eval(tokenizer_type).from_pretrained(path)`), as a table: GLMChineseTokenizer = sp.model directory of the released
+    checkpoints; BertTokenizer = a vocab.txt (the config.py default).  No rank-0-first barrier: nothing is downloaded."""
+    if tokenizer_type == "GLMChineseTokenizer":
+        from vlmo.tokenizer.tokenization_glm import GLMChineseTokenizer
+
+        return GLMChineseTokenizer.from_pretrained(from_pretrained)
+    if tokenizer_type == "BertTokenizer":
+        from antmmf.datasets.tokenization import BertWordPieceTokenizer
+
+        path = os.path.join(from_pretrained, "vocab.txt") if os.path.isdir(from_pretrained) else from_pretrained
+        return BertWordPieceTokenizer(path, do_lower_case="uncased" in os.path.basename(os.path.normpath(from_pretrained)))
+    raise NotImplementedError(f"get_pretrained_tokenizer: {tokenizer_type!r} (GLMChineseTokenizer | BertTokenizer)")
+
+
 class VLMo(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -100,7 +117,9 @@ class VLMo(nn.Module):
         self.out_features = config["out_embed_dim"]
         self.patch_size = config["patch_size"]
         self.num_frames = config.get("num_frames", 1)
-        self.text_tokenizer = None  # tokenisation is outside the step path
+        # host-side tokenizer (reference :167-168): built only when the config names one -- the training step takes ids
+        self.tokenizer_type = config.get("tokenizer_type", None)
+        self.text_tokenizer = get_pretrained_tokenizer(self.tokenizer_type, config["tokenizer"]) if (self.tokenizer_type and config.get("tokenizer")) else None
         self.backbone = BEiT3(args)
         self.use_vl = config["beit3_vl_layers"] > 0
         if self.use_vl:

@@ -1,0 +1,128 @@
+"""Caption processors + BERT word-piece tokenizer against vectors produced by the reference's own processor classes on
+transformers' BertTokenizer (tests/golden/make_golden_text.py).  Bit-exact ids are the bar."""
+import json
+import os
+import random
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _golden():
+    with open(os.path.join(GOLD, "text_processors.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def _params(params, vocabs):
+    p = json.loads(json.dumps(params))
+    tc = p["tokenizer_config"]
+    tc["type"] = os.path.join(GOLD, "vocabs", vocabs[tc["type"]])   # pretrained: false -> `type` is the vocabulary path (datasets/build.py)
+    return p
+
+
+G = _golden()
+
+
+@pytest.mark.parametrize("case", G["cases"], ids=[c["name"] for c in G["cases"]])
+def test_processor_rows_equal_reference(case):
+    import antmmf.datasets.processors  # noqa: F401  (registers)
+    from antmmf.common.registry import registry
+
+    name = {"MaskedBertTokenizer": "masked_bert_tokenizer", "MaskedTokenProcessor": "masked_token"}[case["cls"]]
+    proc = registry.get_processor_class(name)(_params(case["params"], G["vocabs"]))
+    if case["seed"] is not None:
+        random.seed(case["seed"]); torch.manual_seed(case["seed"])
+    for item, want in zip(case["items"], case["expect"]):
+        if "raises" in want:
+            with pytest.raises(AssertionError):
+                proc(dict(item))
+            continue
+        got = proc(dict(item)) if case["probability"] is None else proc(dict(item), probability=case["probability"])
+        for k in ("input_ids", "input_mask", "segment_ids", "lm_label_ids"):
+            assert got[k].dtype == torch.long and got[k].tolist() == want[k], (case["name"], item, k)
+        assert got["tokens"] == want["tokens"] and got["source_len"] == want["source_len"]
+        for k in ("cls_id", "sep_id"):
+            if k in want:
+                assert got[k] == want[k]
+        if case["cls"] == "MaskedBertTokenizer":
+            assert got["text"] == want["tokens"] and got["lm_label_ids"] is got["lm_label_ids"]
+        if "is_correct" in item:
+            assert int(got["is_correct"]) == item["is_correct"]
+
+
+def test_batch_equals_rows_and_processor_wrapper():
+    from antmmf.datasets.processors import Processor
+
+    case = G["cases"][0]
+    cfg = {"type": "masked_bert_tokenizer", "params": _params(case["params"], G["vocabs"])}
+    cfg["params"]["preprocessor"] = {"type": "simple_sentence", "params": {}}   # as in the *_vtp ymls (built, not used by this processor)
+    proc = Processor(cfg)
+    texts = [it["text"] for it in case["items"]]
+    b = proc.batch(texts)
+    assert b["input_ids"].shape == (len(texts), 30)
+    assert b["input_ids"].tolist() == [w["input_ids"] for w in case["expect"]]
+    assert b["input_mask"].tolist() == [w["input_mask"] for w in case["expect"]]
+    assert proc.preprocessor({"text": "The dog's bone, isn't it?"})["text"] == ["the", "dog", "'", "s", "bone", "isn", "'", "t", "it"]   # value produced by the reference's tokenize()
+    assert proc.get_vocab_size() == 29514   # the reference test vocabulary repeats 1008 mojibake lines: unique tokens, as len(BertTokenizer) reports
+
+
+def test_build_tokenizer_resolution(tmp_path, monkeypatch):
+    from antmmf.datasets.build import build_tokenizer
+
+    d = tmp_path / "bert-base-uncased"
+    d.mkdir()
+    (d / "vocab.txt").write_text(open(os.path.join(GOLD, "vocabs", G["vocabs"]["uncased"]), encoding="utf-8").read(), encoding="utf-8")
+    monkeypatch.setenv("PYTORCH_TRANSFORMERS_CACHE", str(tmp_path))
+    tok = build_tokenizer({"type": "bert-base-uncased", "params": {"model_type": "bert", "do_lower_case": True}})
+    assert tok.convert_tokens_to_ids(tok.tokenize("Hello WORLD")) == [7592, 2088] and tok.cls_token_id == 101 and tok.sep_token_id == 102
+    assert build_tokenizer({"type": "bert-base-uncased"}).do_lower_case is True
+    with pytest.raises(FileNotFoundError):
+        build_tokenizer({"type": "bert-base-chinese"})
+    with pytest.raises(NotImplementedError):
+        build_tokenizer({"type": "roberta-base", "params": {"model_type": "roberta"}})
+
+
+def test_tokenizer_matches_transformers_when_installed():
+    """Live fuzz against the third-party implementation the reference resolves to (skipped where transformers is absent)."""
+    tr = pytest.importorskip("transformers")
+    from antmmf.datasets.tokenization import BertWordPieceTokenizer
+
+    rng = random.Random(11)
+    pools = [(32, 126), (0xC0, 0x24F), (0x4E00, 0x4E80), (0x2000, 0x206F), (0x300, 0x36F), (0, 31), (0x370, 0x3FF), (0xFF00, 0xFFEF), (0xF900, 0xFA2F), (0xE000, 0xE010)]
+    for key, lower in (("uncased", True), ("chinese", False)):
+        path = os.path.join(GOLD, "vocabs", G["vocabs"][key])
+        hf, me = tr.BertTokenizer(path, do_lower_case=lower), BertWordPieceTokenizer(path, do_lower_case=lower)
+        words = list(me.vocab)
+        for _ in range(1500):
+            parts = []
+            for _ in range(rng.randint(1, 8)):
+                lo, hi = rng.choice(pools)
+                parts.append(rng.choice([rng.choice(words).replace("##", ""), "".join(chr(rng.randint(lo, hi)) for _ in range(rng.randint(1, 6))), rng.choice(me.all_special_tokens)]))
+            text = rng.choice([" ", ""]).join(parts)
+            assert me.tokenize(text) == hf.tokenize(text), repr(text)
+
+
+def test_m2_glm_tokenizer_equals_reference():
+    """prj/M2_Encoder/m2_encoder.py:39-45: tokenizer(texts, padding="max_length", truncation=True, max_length=L) -- rows produced by the
+    reference's GLMChineseTokenizer (tests/golden/make_golden_text.py::main_glm)."""
+    pytest.importorskip("sentencepiece")
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "ant-multi-modal-framework_amd", "prj", "M2_Encoder"))
+    from vlmo.modules.vlmo_module import get_pretrained_tokenizer
+
+    with open(os.path.join(GOLD, "m2_tokenizer.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    tok = get_pretrained_tokenizer("GLMChineseTokenizer", os.path.join(GOLD, "m2_tokenizer"))
+    assert len(tok) == g["size"]
+    assert dict(cls=tok.cls_token_id, eos=tok.eos_token_id, pad=tok.pad_token_id, mask=tok.mask_token_id, unk=tok.unk_token_id) == g["ids"]
+    for text, want in zip(g["texts"], g["pieces"]):
+        assert tok.tokenize(text) == want, repr(text)
+    for case in g["cases"]:
+        enc = tok(g["texts"], padding="max_length", truncation=True, max_length=case["max_length"], return_special_tokens_mask=True)
+        assert enc["input_ids"] == case["input_ids"] and enc["attention_mask"] == case["attention_mask"], case["max_length"]
+    one = tok(g["texts"][0], padding="max_length", truncation=True, max_length=52, return_tensors="pt")
+    assert one["input_ids"].tolist() == g["cases"][1]["input_ids"][0]
