@@ -122,3 +122,38 @@ def resize_bicubic_u8(images, out_h, out_w, out_f32=True, device=None):
     plan = ResizePlan([(int(t.shape[0]), int(t.shape[1])) for t in images], C, out_h, out_w, device)
     src = torch.cat([t.reshape(-1).to(device, non_blocking=True) for t in images])
     return resize_packed_u8(src, plan, out_f32)
+
+
+# ------------------------------------------------------------------------------ video frames (bilinear, float32, fused normalise + pad)
+def frames_bilinear_norm(frames, out_h, out_w, mean=None, std=None, out=None, div255=-1, layout="nchw"):
+    """All frames of one video: uint8 `frames` ([n, C, h, w], or [n, h, w, C] with layout="nhwc": only the strides differ) ->
+    float32 [n, C, out_h, out_w] = GroupNormalize(bilinear_resize(frames.float())) (csrc/frames.hip; reference
+    image_processors.py:520-547 + image_ops.py:72-108,127-223).  `out`: optional float32 view to write into (last dim contiguous) --
+    e.g. the [n, C, :out_h, :out_w] corner of the zero-initialised padded batch canvas, which makes the collate padding free.
+    mean / std None: resize only.  div255 -1: the reference's `max > 1` test, evaluated on the device."""
+    if frames.dtype != torch.uint8 or frames.dim() != 4:
+        raise ValueError("frames_bilinear_norm: frames must be a uint8 [n, C, h, w] (or [n, h, w, C]) tensor")
+    if (frames.device.type == "cuda") != (_lib.backend() == 1):
+        raise RuntimeError("frames_bilinear_norm: device does not match the loaded library (gfx950 library <-> cuda tensors; no CPU fallback)")
+    if layout == "nhwc":
+        n, h, w, C = frames.shape
+        sn, sh, sw, sc = frames.stride()
+    else:
+        n, C, h, w = frames.shape
+        sn, sc, sh, sw = frames.stride()
+    dev = frames.device
+    if out is None:
+        out = torch.empty(n, C, out_h, out_w, dtype=torch.float32, device=dev)
+    if out.dtype != torch.float32 or tuple(out.shape) != (n, C, out_h, out_w) or out.stride(3) != 1 or out.device != dev:
+        raise ValueError("frames_bilinear_norm: out must be a float32 [n, C, out_h, out_w] view with contiguous columns on the frames' device")
+    mean_t = std_t = scratch = None
+    if mean is not None:
+        mean_t = torch.as_tensor(mean, dtype=torch.float32).reshape(-1).to(dev)
+        std_t = torch.as_tensor(std, dtype=torch.float32).reshape(-1).to(dev)
+        if mean_t.numel() != C or std_t.numel() != C:
+            raise ValueError("frames_bilinear_norm: mean / std need one value per channel")
+        if div255 < 0:
+            scratch = torch.zeros(1, dtype=torch.int32, device=dev)
+    _rc(_lib.load().antmmf_frames_bilinear_norm(_p(frames), n, C, h, w, sn, sc, sh, sw, _p(out), out_h, out_w, out.stride(0), out.stride(1), out.stride(2),
+                                               _p(mean_t), _p(std_t), int(div255), _p(scratch), _stream()), "antmmf_frames_bilinear_norm")
+    return out

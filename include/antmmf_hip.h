@@ -276,6 +276,19 @@ int antmmf_resize_bicubic_u8(const void* src, int64_t src_bytes, const int64_t* 
                              int channels, int out_h, int out_w, const int32_t* coeffs, const int32_t* bounds, void* tmp, void* out,
                              int out_f32, antmmf_stream_t stream);
 
+/* ---- input pipeline: the video-frame transform in front of the visual tower, for all frames of one video at once:
+ * uint8 -> float32 (CustomTransforms.__call__, antmmf/datasets/processors/image_processors.py:520-547) -> bilinear resize to
+ * (out_h, out_w) (ImageLongsideScaleAndPad, antmmf/utils/image_ops.py:127-223 = torchvision F.resize on a tensor =
+ * interpolate(mode="bilinear", align_corners=False)) -> GroupNormalize (image_ops.py:72-108: / 255 if the resized maximum is > 1,
+ * - mean[c], / std[c]) -> written into a (zero-initialised) padded canvas, the collate step of NestedTensor.from_tensor_list
+ * (antmmf/structures/nested_tensor.py:51-63).  src: uint8 frames with BYTE strides (sn, sc, sh, sw) of [frame, channel, row, column]
+ * ([n, C, h, w] and the decoder's [n, h, w, C] are both strides).  out: float32, element (f, c, y, x) at out[f on + c oc + y oh + x].
+ * mean / std: device float[C], or both NULL (resize only: plain float32 frames).  div255: 1 / 0 fixed; -1 = evaluate the reference's
+ * "resized.max() > 1" on the device into max_scratch (device int; one extra read-only pass, no host round trip). */
+int antmmf_frames_bilinear_norm(const void* src, int n, int channels, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                float* out, int out_h, int out_w, int64_t on, int64_t oc, int64_t oh, const float* mean, const float* std,
+                                int div255, int* max_scratch, antmmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

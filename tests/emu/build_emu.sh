@@ -11,6 +11,6 @@ exec 9>"$ROOT/tests/emu/build/.build.lock"
 flock 9
 if [ -f "$OUT" ] && [ -z "$(find "$SRC" "$ROOT/tests/emu/hip_emu.h" -newer "$OUT" \( -name '*.hip' -o -name '*.h' \) -print -quit)" ]; then exit 0; fi
 "$CXX" -std=c++20 -O1 -pthread -fPIC -shared -DANTMMF_EMULATE -Wno-unused-value -I"$ROOT/tests/emu" -I"$SRC" -x c++ \
-  "$SRC/abi.hip" "$SRC/layernorm.hip" "$SRC/elementwise.hip" "$SRC/gemm.hip" "$SRC/attention.hip" "$SRC/loss.hip" "$SRC/tpmcl.hip" "$SRC/resize.hip" \
+  "$SRC/abi.hip" "$SRC/layernorm.hip" "$SRC/elementwise.hip" "$SRC/gemm.hip" "$SRC/attention.hip" "$SRC/loss.hip" "$SRC/tpmcl.hip" "$SRC/resize.hip" "$SRC/frames.hip" \
   -o "$OUT.tmp.$$"
 mv -f "$OUT.tmp.$$" "$OUT"

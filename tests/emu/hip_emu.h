@@ -145,6 +145,18 @@ static inline float atomicAdd(float* p, float v) {
     while (!a->compare_exchange_weak(old, old + v)) {}
     return old;
 }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline int atomicMax(int* p, int v) {
+    auto* a = reinterpret_cast<std::atomic<int>*>(p);
+    int old = a->load();
+    while (old < v && !a->compare_exchange_weak(old, v)) {}
+    return old;
+}
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float emu_expf(float x) { return std::exp(x); }

@@ -1,0 +1,105 @@
+"""Shared cases for the video-frame transform (CPU lane emulator and MI355X): product path vs oracle/frames.py (float32: 1e-6 relative)."""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import frames as oframes  # noqa: E402  (tests only)
+
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]   # the *_vtp ymls (detr statistics)
+
+
+def _close(got, want, what):
+    got, want = got.cpu(), want.cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    tol = 1e-6 * max(1.0, want.abs().max().item()) * 4
+    assert err <= tol, (what, err, tol)
+    return err
+
+
+def _frames(n, h, w, seed, c=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (n, c, h, w), dtype=torch.uint8, generator=g)
+
+
+def case_processor(dev, shapes=((2, 48, 64, 96), (3, 64, 48, 96), (1, 33, 57, 64), (2, 50, 50, 40), (1, 7, 5, 32), (2, 30, 40, 30))):
+    """`custom_transforms` [ImageLongsideScaleAndPad, GroupNormalize] as configured by the ymls, up- and down-scaling, odd sizes."""
+    import antmmf.datasets.processors  # noqa: F401
+    from antmmf.datasets.processors import Processor
+
+    worst = 0.0
+    for i, (n, h, w, max_size) in enumerate(shapes):
+        cfg = {"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+            {"type": "ImageLongsideScaleAndPad", "params": {"max_size": max_size, "random_scale": False, "pad": False}},
+            {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}}
+        proc = Processor(cfg)
+        fr = _frames(n, h, w, 100 + i)
+        got = proc(fr.to(dev))
+        want = oframes.frame_processor(fr, max_size, MEAN, STD)
+        worst = max(worst, _close(got, want, (n, h, w, max_size)))
+        assert proc({"image": fr.to(dev)})["image"].shape == want.shape
+    # the two transforms alone: resize only (float frames out), and NHWC strides (the decoder's layout) through the same entry point
+    from antmmf.hip.image import frames_bilinear_norm
+    from antmmf.utils.image_ops import ImageLongsideScaleAndPad
+
+    fr = _frames(2, 40, 56, 7)
+    worst = max(worst, _close(ImageLongsideScaleAndPad(80)(fr.to(dev)), oframes.scale_frames(fr, 80), "scale only"))
+    nhwc = fr.permute(0, 2, 3, 1).contiguous().to(dev)
+    oh, ow = oframes.resize_size(40, 56, 80)
+    worst = max(worst, _close(frames_bilinear_norm(nhwc, oh, ow, mean=MEAN, std=STD, layout="nhwc"), oframes.frame_processor(fr, 80, MEAN, STD), "nhwc"))
+    padded = ImageLongsideScaleAndPad(80, pad=True)(fr.to(dev)).cpu()
+    assert padded.shape == (2, 3, 80, 80) and float(padded[:, :, oh:, :].abs().max()) == 0.0
+    return f"max abs err {worst:.2e}"
+
+
+def case_dark_clip_keeps_reference_semantics(dev):
+    """GroupNormalize divides by 255 only when the resized maximum exceeds 1 (image_ops.py:103-104): an all-dark clip (values 0 / 1) is NOT rescaled."""
+    import antmmf.datasets.processors  # noqa: F401
+    from antmmf.datasets.processors import Processor
+
+    proc = Processor({"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+        {"type": "ImageLongsideScaleAndPad", "params": {"max_size": 32}}, {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}})
+    dark = (_frames(2, 20, 24, 3) % 2).to(torch.uint8)
+    _close(proc(dark.to(dev)), oframes.frame_processor(dark, 32, MEAN, STD), "dark")
+    bright = dark.clone(); bright[0, 0, 3, 3] = 200
+    _close(proc(bright.to(dev)), oframes.frame_processor(bright, 32, MEAN, STD), "bright")
+    return "ok"
+
+
+def case_collate(dev):
+    """A ragged batch of videos -> padded image_data + image_pad_mask, random_scale drawn in the reference's order."""
+    import antmmf.datasets.processors  # noqa: F401
+    from antmmf.datasets.processors import Processor
+    from antmmf.datasets.processors.image_processors import collate_video_frames
+
+    cfg = {"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+        {"type": "ImageLongsideScaleAndPad", "params": {"max_size": 288, "random_scale": True, "pad": False}},
+        {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}}
+    proc = Processor(cfg)
+    vids = [_frames(4, h, w, 40 + i) for i, (h, w) in enumerate(((36, 64), (64, 36), (48, 48)))]
+    random.seed(21)
+    data, mask = collate_video_frames([v.to(dev) for v in vids], proc.processor, n_clips=2, num_frm=2)
+    random.seed(21)
+    want_d, want_m = oframes.collate([oframes.frame_processor(v, 288, MEAN, STD, random_scale=True) for v in vids])
+    _close(data, want_d, "collate data")
+    assert torch.equal(mask.cpu(), want_m)
+    return tuple(data.shape)
+
+
+def case_full_size(dev, n=12, h=360, w=640, max_size=448):
+    """One 12-frame 640x360 video at the test-time size of the ymls (max_size 448): oracle on two frames, properties on all."""
+    from antmmf.hip.image import frames_bilinear_norm
+
+    fr = _frames(n, h, w, 5)
+    oh, ow = oframes.resize_size(h, w, max_size)
+    got = frames_bilinear_norm(fr.to(dev), oh, ow, mean=MEAN, std=STD)
+    _close(got[:2], oframes.frame_processor(fr[:2], max_size, MEAN, STD), "full size")
+    flat = torch.full((1, 3, h, w), 128, dtype=torch.uint8)
+    const = frames_bilinear_norm(flat.to(dev), oh, ow, mean=MEAN, std=STD).cpu()   # a constant frame stays constant
+    for c in range(3):
+        assert float((const[0, c] - (128 / 255 - MEAN[c]) / STD[c]).abs().max()) < 1e-5
+    return (oh, ow)
