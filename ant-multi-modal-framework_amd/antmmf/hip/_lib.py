@@ -67,6 +67,12 @@ _SIGNATURES = {
     "antmmf_negnce_fwd": [P, P, I, I, I, F, F, P, P, P, P, P],
     "antmmf_negnce_bwd": [P, P, P, P, I, I, I, F, F, P, I, P],
     "antmmf_resize_bicubic_u8": [P, L, P, I, I, I, I, I, I, P, P, P, P, I, P],
+    "antmmf_ffn_prepare_w2": [P, P, P, P, P, P, P, I, I, P],
+    "antmmf_ffn_fc1_fwd": [P, P, P, P, P, P, I, I, I, L, L, L, I, F, P, L, P],
+    "antmmf_ffn_fc2_fwd": [P, P, P, P, P, P, P, I, I, I, L, L, L, L, P],
+    "antmmf_ffn_bwd_rows": [P, P, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, P],
+    "antmmf_ffn_fc2_dgrad": [P, P, P, P, P, P, P, I, I, I, L, L, L, L, P, L, P],
+    "antmmf_ffn_wgrad_post": [P, P, P, P, P, P, P, P, P, I, I, P],
     "antmmf_frames_bilinear_norm": [P, I, I, I, I, L, L, L, L, P, I, I, L, L, L, P, P, I, P, P],
 }
 

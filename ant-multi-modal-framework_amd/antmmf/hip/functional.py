@@ -349,6 +349,29 @@ def set_keep_ffn_norm(flag):
     KEEP_FFN_NORM = bool(flag)
 
 
+# Sub-LN fold (M2 layers under the KEEP_FFN_NORM activation policy): gelu -> ffn_layernorm live in the epilogues of fc1 / fc2 and of fc2's dgrad
+# (ops.ffn_*, csrc/gemm.hip "Sub-LN fold"); the two 4d-wide LayerNorm passes per layer disappear.  Same activation memory as the kept policy
+# (z = gelu(u) and gelu'(u) instead of u and LN(z)).  OFF by default: measured on MI355X at the bench size (tools/ffn_fold_bench.py,
+# profiles/r3_ffn_fold_bench_image.jsonl) the removed passes (1.05 + 1.43 ms per image layer) come back one for one as exposed epilogue time of the
+# persistent GEMM kernel (fc1 + 0.92, dgrad + 0.96, fc2 + 0.11, row pass 0.46): its HBM-bound epilogues do not overlap the MFMA loop, so moving bytes
+# from a streaming kernel into them buys nothing (step 1314 vs 1313 pairs/s).  ANTMMF_FFN_FOLD=1 / set_ffn_fold(True) turns it on (parity-tested).
+FFN_FOLD = os.environ.get("ANTMMF_FFN_FOLD", "0") == "1"
+
+
+def set_ffn_fold(flag):
+    global FFN_FOLD
+    FFN_FOLD = bool(flag)
+
+
+def _folded_w2(P):
+    """(W2 diag(gamma) bf16, its transpose, c = its row sums, b2f = b2 + W2 beta) -- rebuilt once per optimizer step (two small launches per layer)."""
+    def build():
+        w2g, c, b2f = ops.ffn_prepare_w2(f32(P["w2"]), f32(P["ffn_w"]), f32(P["ffn_b"]), f32(P["b2"]))
+        return w2g, ops.transpose_bf16(w2g), c, b2f
+
+    return _cached_on(P["w2"], "_antmmf_ffn_fold", build)
+
+
 class _TransformerLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, key_bias, spec, seed, *params):
@@ -395,7 +418,12 @@ class _TransformerLayer(torch.autograd.Function):
             h2, m2_, r2 = ops.layernorm_fwd(mid, f32(P["ln1_w"]), f32(P["ln1_b"]), spec.eps)
             st2 = (m2_, r2)
         st_f = None
-        if spec.kind == "m2":
+        fold = spec.kind == "m2" and FFN_FOLD and KEEP_FFN_NORM and P["b1"] is not None and P["b2"] is not None and d <= 2048
+        if fold:
+            # fc1's epilogue: z = gelu(u), gelu'(u) and the row statistics of z; fc2 consumes z against W2 diag(gamma) and applies (mu, rstd) in ITS epilogue
+            g_n, u, stats = ops.ffn_fc1_fwd(h2, compute_copy(P["w1"]), f32(P["b1"]), spec.act, spec.eps)   # (u holds gelu'(u) on this path)
+            st_f = (stats, None)
+        elif spec.kind == "m2":
             # fc1 -> [gelu -> ffn_layernorm] fused: gelu(u) never goes to HBM
             u = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]))
             g_n, mf, rf = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, act=spec.act)
@@ -406,7 +434,10 @@ class _TransformerLayer(torch.autograd.Function):
             u = torch.empty(T, P["w1"].shape[0], dtype=BF, device=dev)
             g_n = ops.gemm(h2, compute_copy(P["w1"]), bias=f32(P["b1"]), act=spec.act, aux=u, aux_grad=KEEP_FFN_NORM)
         res = mid if pre_ln else h2
-        if p_hid > 0:
+        if fold:
+            w2g, _, c_w2g, b2f = _folded_w2(P)
+            y = ops.ffn_fc2_fwd(g_n, w2g, c_w2g, b2f, stats, res)
+        elif p_hid > 0:
             y = ops.dropout_add(ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"])), p_hid, seed + 2, residual=res)
         else:
             y = ops.gemm(g_n, compute_copy(P["w2"]), bias=f32(P["b2"]), residual=res)
@@ -423,10 +454,13 @@ class _TransformerLayer(torch.autograd.Function):
             saved += list(st) if st is not None else [None, None]
         saved.append(s2)
         saved.append(kept_gn)
+        y3 = y.view(B, N, d)
+        saved.append(y3 if fold else None)   # the fold's backward takes one of the LayerNorm's row means from the layer output (an output may be saved)
         ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.shape, ctx.nsaved, ctx.drop = spec, (B, N, d), len(saved), (p_att, p_hid, seed)
         ctx.u_is_grad = bool(KEEP_FFN_NORM and spec.kind != "m2")
-        return y.view(B, N, d)
+        ctx.fold = fold
+        return y3
 
     @staticmethod
     def backward(ctx, dy):
@@ -436,7 +470,7 @@ class _TransformerLayer(torch.autograd.Function):
         sv = ctx.saved_tensors
         x2, qkv, o, lse, mid, u, key_bias = sv[:7]
         (m1, r1, mi, ri, m2_, r2, mf, rf, my, ry) = sv[7:17]
-        s2, kept_gn = sv[17], sv[18]
+        s2, kept_gn, y_out = sv[17], sv[18], sv[19]
         params = sv[ctx.nsaved:]
         P = dict(zip(SLOTS, params))
         sink = GradSink()
@@ -457,7 +491,9 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             dgw, dgb = lnw("ln2")
             ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb)
-        if kept_gn is not None:
+        if ctx.fold:
+            g_n = None
+        elif kept_gn is not None:
             g_n = kept_gn
         elif spec.kind == "m2":
             g_n, _, _ = ops.layernorm_fwd(u, f32(P["ffn_w"]), f32(P["ffn_b"]), spec.eps, want_stats=False, act=spec.act)
@@ -465,18 +501,44 @@ class _TransformerLayer(torch.autograd.Function):
             g_n = ops.act_fwd(u, spec.act)
         # hidden dropout: the dense output's gradient is the masked / rescaled ds2; the residual branch keeps ds2 itself
         dy_w2 = ops.dropout_add(ds2.contiguous(), p_hid, seed + 2) if p_hid > 0 else ds2
-        _wgrad(sink, P["w2"], dy_w2, g_n)
+        if not ctx.fold:
+            _wgrad(sink, P["w2"], dy_w2, g_n)
         # fc2's bias gradient = column sums of the incoming gradient.  When that gradient is the dx of the NEXT layer's ln1 backward, that
         # kernel has already summed its columns (handed over on the tensor, valid only while the tensor is unmodified: _version check)
         handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0 and not os.environ.get("ANTMMF_DEBUG_NO_HANDOFF")) else None
-        if (handed is not None and handed[1:] == (dy._version, dy.data_ptr(), tuple(dy.shape)) and handed[0].shape[0] == d
-                and P["b2"] is not None and P["b2"].requires_grad):
+        handed_ok = handed is not None and handed[1:] == (dy._version, dy.data_ptr(), tuple(dy.shape)) and handed[0].shape[0] == d
+        if ctx.fold:
+            # ---- sub-LN fold: one row pass over d-wide tensors (the LayerNorm's two row means, rstd-scaled dy for fc2's wgrad, the column sums the
+            # LayerNorm parameters need), then everything 4d-wide happens in GEMM epilogues
+            z, dact, stats = kept_gn, u, mf
+            w2g, w2gt, c_w2g, b2f = _folded_w2(P)
+            s_col = torch.zeros(d, dtype=torch.float32, device=dy2.device)
+            cs_col = None if handed_ok else torch.zeros(d, dtype=torch.float32, device=dy2.device)
+            rowv4, dys = ops.ffn_bwd_rows(ds2, y_out.view(T, d), mid, b2f, c_w2g, stats, z.shape[1], s_col, cs_col)
+            cs = handed[0] if handed_ok else cs_col
+            if handed_ok:
+                COLSUM_HANDOFFS[0] += 1
+            if P["b2"].requires_grad:
+                sink.buf(P["b2"]).add_(cs)      # b2f = b2 + W2 beta: d b2 = column sums of dy
+            b1_fused = True
+            du = ops.ffn_fc2_dgrad(ds2, w2gt, z, dact, rowv4, sink.buf(P["b1"]) if P["b1"].requires_grad else None)
+            if P["w2"].requires_grad or P["ffn_w"].requires_grad or P["ffn_b"].requires_grad:
+                Gm = torch.zeros(d, z.shape[1], dtype=torch.float32, device=dy2.device)
+                ops.gemm_wgrad_(Gm, dys, z)
+                dW2 = sink.buf(P["w2"]) if P["w2"].requires_grad else torch.empty_like(Gm)
+                ops.ffn_wgrad_post_(dW2, Gm, f32(P["w2"]), f32(P["ffn_w"]), f32(P["ffn_b"]), s_col, cs,
+                                    sink.buf(P["ffn_w"]) if P["ffn_w"].requires_grad else None, sink.buf(P["ffn_b"]) if P["ffn_b"].requires_grad else None)
+                del Gm
+            del dys, z, dact
+        elif (handed_ok and P["b2"] is not None and P["b2"].requires_grad):
             sink.buf(P["b2"]).add_(handed[0])
             COLSUM_HANDOFFS[0] += 1
         else:
             _bgrad(sink, P["b2"], dy_w2)
         del g_n
-        if spec.kind == "m2":
+        if ctx.fold:
+            pass
+        elif spec.kind == "m2":
             dgn = dgrad(ds2, P["w2"])
             dgw, dgb = lnw("ffn")
             # through LN and gelu at once; the fc1 bias gradient (column sums of du) falls out of the same pass

@@ -350,6 +350,114 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     return dW
 
 
+# ------------------------------------------------------------------------------ M2 feed-forward with the sub-LayerNorm folded into its GEMMs
+_FFN_WS = {}
+
+
+def _ffn_ws(dev, nbytes):
+    ws = _FFN_WS.get(dev)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max((nbytes + 3) // 4, 1 << 22), dtype=torch.float32, device=dev)
+        _FFN_WS[dev] = ws
+    return ws
+
+
+def _bf2d(t, name):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
+        raise ValueError(f"ffn: {name} must be a 2-D bf16 tensor with unit inner stride")
+    return t
+
+
+def _trace_begin():
+    if GEMM_TRACE is not None and _lib.backend() == 1:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+    return None
+
+
+def _trace_end(ev, I, J, R, tag):
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * I * J * R, "nt", (I, J, R, tag)))
+
+
+def ffn_prepare_w2(W2, gamma, beta, b2):
+    """fp32 master W2 [n_out, n_ff], ffn_layernorm (gamma, beta), fc2 bias -> (W2g bf16 = W2 diag(gamma), c = row sums of the rounded W2g, b2f = b2 + W2 beta)."""
+    _dev_ok(W2, gamma, beta, b2); _f32(W2, "W2"); _f32(gamma, "gamma"); _f32(beta, "beta"); _f32(b2, "b2"); _c(W2, "W2")
+    n_out, n_ff = W2.shape
+    w2g = torch.empty(n_out, n_ff, dtype=torch.bfloat16, device=W2.device)
+    c = torch.empty(n_out, dtype=torch.float32, device=W2.device)
+    b2f = torch.empty(n_out, dtype=torch.float32, device=W2.device)
+    _rc(_lib.load().antmmf_ffn_prepare_w2(_p(W2), _p(gamma), _p(beta), _p(b2), _p(w2g), _p(c), _p(b2f), n_out, n_ff, _stream()), "antmmf_ffn_prepare_w2")
+    return w2g, c, b2f
+
+
+def ffn_fc1_fwd(x, W1, b1, act, eps):
+    """-> (z = act(x W1^T + b1), dact = act'(.), stats [tokens, 2] = (mean, rstd) of the rounded rows of z)."""
+    _dev_ok(x, W1, b1); _bf2d(x, "x"); _bf2d(W1, "W1"); _f32(b1, "b1")
+    tokens, n_in = x.shape
+    n_ff = W1.shape[0]
+    z = torch.empty(tokens, n_ff, dtype=torch.bfloat16, device=x.device)
+    dact = torch.empty_like(z)
+    stats = torch.empty(tokens, 2, dtype=torch.float32, device=x.device)
+    ws = _ffn_ws(x.device, (n_ff // 64) * tokens * 8)
+    ev = _trace_begin()
+    _rc(_lib.load().antmmf_ffn_fc1_fwd(_p(x), _p(W1), _p(b1), _p(z), _p(dact), _p(stats), tokens, n_ff, n_in, x.stride(0), W1.stride(0), z.stride(0),
+                                       ACT_IDS[act], float(eps), _p(ws), ws.numel() * 4, _stream()), "antmmf_ffn_fc1_fwd")
+    _trace_end(ev, tokens, n_ff, n_in, "ffn1")
+    return z, dact, stats
+
+
+def ffn_fc2_fwd(z, w2g, c, b2f, stats, res):
+    _dev_ok(z, w2g, c, b2f, stats, res); _bf2d(z, "z"); _bf2d(w2g, "w2g"); _bf2d(res, "res"); _f32(c, "c"); _f32(b2f, "b2f"); _f32(stats, "stats")
+    tokens, n_ff = z.shape
+    n_out = w2g.shape[0]
+    y = torch.empty(tokens, n_out, dtype=torch.bfloat16, device=z.device)
+    ev = _trace_begin()
+    _rc(_lib.load().antmmf_ffn_fc2_fwd(_p(z), _p(w2g), _p(c), _p(b2f), _p(stats), _p(res), _p(y), tokens, n_out, n_ff, z.stride(0), w2g.stride(0), res.stride(0),
+                                       y.stride(0), _stream()), "antmmf_ffn_fc2_fwd")
+    _trace_end(ev, tokens, n_out, n_ff, "ffn2")
+    return y
+
+
+def ffn_bwd_rows(dy, y, res, b2f, c, stats, n_ff, s_col, cs_col=None):
+    """-> (rowv4 [tokens, 4] = (mu, rstd, m1, m2), dys = bf16(rstd dy)); accumulates s_col (and cs_col when given)."""
+    _dev_ok(dy, y, res, b2f, c, stats, s_col, cs_col); _bf2d(dy, "dy"); _bf2d(y, "y"); _bf2d(res, "res"); _f32(s_col, "s_col"); _f32(cs_col, "cs_col")
+    tokens, n_out = dy.shape
+    rowv4 = torch.empty(tokens, 4, dtype=torch.float32, device=dy.device)
+    dys = torch.empty(tokens, n_out, dtype=torch.bfloat16, device=dy.device)
+    _rc(_lib.load().antmmf_ffn_bwd_rows(_p(dy), _p(y), _p(res), _p(b2f), _p(c), _p(stats), _p(rowv4), _p(dys), _p(s_col), _p(cs_col), tokens, n_out, int(n_ff),
+                                        dy.stride(0), y.stride(0), res.stride(0), dys.stride(0), _stream()), "antmmf_ffn_bwd_rows")
+    return rowv4, dys
+
+
+def ffn_fc2_dgrad(dy, w2gt, z, dact, rowv4, db1=None):
+    """du = act'(u) * LayerNorm-backward(dy W2g) -- the gradient at fc1's pre-activation; db1 += column sums of du."""
+    _dev_ok(dy, w2gt, z, dact, rowv4, db1); _bf2d(dy, "dy"); _bf2d(w2gt, "w2gt"); _bf2d(z, "z"); _bf2d(dact, "dact"); _f32(db1, "db1")
+    tokens, n_out = dy.shape
+    n_ff = w2gt.shape[0]
+    if z.stride(0) != dact.stride(0):
+        raise ValueError("ffn_fc2_dgrad: z and dact must share their row stride")
+    du = torch.empty(tokens, n_ff, dtype=torch.bfloat16, device=dy.device)
+    ws = _ffn_ws(dy.device, (tokens // 128 + 1) * n_ff * 4)
+    ev = _trace_begin()
+    _rc(_lib.load().antmmf_ffn_fc2_dgrad(_p(dy), _p(w2gt), _p(z), _p(dact), _p(rowv4), _p(du), _p(db1), tokens, n_ff, n_out, dy.stride(0), w2gt.stride(0),
+                                         z.stride(0), du.stride(0), _p(ws), ws.numel() * 4, _stream()), "antmmf_ffn_fc2_dgrad")
+    _trace_end(ev, tokens, n_ff, n_out, "ffn3")
+    return du
+
+
+def ffn_wgrad_post_(dW2, Gm, W2, gamma, beta, s_col, cs_col, dgamma=None, dbeta=None):
+    _dev_ok(dW2, Gm, W2, gamma, beta, s_col, cs_col, dgamma, dbeta)
+    for t, n in ((dW2, "dW2"), (Gm, "Gm"), (W2, "W2")):
+        _f32(t, n); _c(t, n)
+    n_out, n_ff = W2.shape
+    _rc(_lib.load().antmmf_ffn_wgrad_post(_p(Gm), _p(W2), _p(gamma), _p(beta), _p(s_col), _p(cs_col), _p(dW2), _p(dgamma), _p(dbeta), n_out, n_ff, _stream()),
+        "antmmf_ffn_wgrad_post")
+    return dW2
+
+
 # ------------------------------------------------------------------------------ attention
 def _tok_ld(t, name):
     if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1) or t.dtype != torch.bfloat16:

@@ -120,6 +120,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 #endif
+// partial wave sums used by the GEMM epilogues of the sub-LN fold: over the 16 lanes of a DPP row (every lane of the row receives it), and over the four
+// lanes {l, l ^ 16, l ^ 32, l ^ 48} (one lane per row; v_permlane16_swap / v_permlane32_swap of gfx950: no LDS crossbar, no lgkmcnt)
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ float row16_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+__device__ __forceinline__ float rows4_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+#else
+__device__ __forceinline__ float row16_sum(float v) {
+    v = ANTMMF_DPP_ADD(v, 0xB1);
+    v = ANTMMF_DPP_ADD(v, 0x4E);
+    v = ANTMMF_DPP_ADD(v, 0x141);
+    v = ANTMMF_DPP_ADD(v, 0x140);
+    return v;
+}
+typedef __attribute__((ext_vector_type(2))) unsigned int antmmf_u2_t;
+__device__ __forceinline__ float rows4_sum(float v) {
+    const antmmf_u2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const antmmf_u2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+#endif
 #ifdef ANTMMF_EMULATE
 __device__ __forceinline__ float wave_max(float v) { return emu_wave_max(v); }
 #else

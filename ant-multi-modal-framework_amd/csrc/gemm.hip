@@ -48,6 +48,15 @@ struct GemmArgs {
     int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
     int aux_grad, gate_grad;  // ANTMMF_ACT_AUX_GRAD: aux receives act'(pre-activation) instead of the pre-activation; ANTMMF_ACT_GATE_GRAD: gate holds act' already
     int debug_nostore;  // ablations (antmmf_debug_set_gemm_variant bit 11 / 12): the staged epilogue skips its global stores / stores without the nt hint
+    // ---- sub-LN fold (antmmf_ffn_* at the end of this file): the M2 feed-forward's gelu -> LayerNorm(4d) pair lives in the epilogues of its GEMMs
+    //   1  fc1:   z = act(acc + bias) -> C,  act'(acc + bias) -> aux,  per-row (sum z, sum z^2) of the ROUNDED z -> part   (k64p; other kernels: a row pass follows)
+    //   2  fc2:   C = rstd_i acc - rstd_i mu_i colv_j + bias_j + residual_ij                 rowv = [I][2] (mu, rstd);  Q = W2 gamma,  colv_j = sum_k Q[j][k]
+    //   3  dgrad: C = gate_ij (A_i acc + B_i - G_i residual_ij),  A = rstd, B = -rstd m1 + mu rstd^2 m2, G = rstd^2 m2     rowv = [I][4] (mu, rstd, m1, m2),
+    //             residual = z (fc1's output), gate = act'; per-column sums of C over the tile's rows -> part (k64p)
+    int ffn_mode;
+    const float* rowv;
+    const float* colv;
+    float* part;   // mode 1: [J / 64][I] float2 (column block major);  mode 3: [I / 128][J]
 };
 
 
@@ -106,6 +115,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             const int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
             if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
             float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
+            if (g.ffn_mode) {   // sub-LN fold, element-wise form (the statistics / column sums of these shapes come from their own small passes)
+                bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long)i * g.ldc + j;
+                if (g.ffn_mode == 1) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
+                    const float u[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+                    float z[4], d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) act_fwd_grad<-1>(u[e], g.act, z[e], d[e]);
+                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
+                    *reinterpret_cast<uint2*>(g.aux + (long)i * g.ldaux + j) = make_uint2(pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]));
+                } else if (g.ffn_mode == 2) {
+                    const float2 st = *reinterpret_cast<const float2*>(g.rowv + 2 * (long)i);
+                    const float4 c = *reinterpret_cast<const float4*>(g.colv + j), b = *reinterpret_cast<const float4*>(g.bias + j);
+                    const uint2 r = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                    const float rs = st.y, rm = -st.y * st.x;
+                    const float o0 = (rs * v[0] + rm * c.x + b.x) + bf_lo(r.x), o1 = (rs * v[1] + rm * c.y + b.y) + bf_hi(r.x);
+                    const float o2 = (rs * v[2] + rm * c.z + b.z) + bf_lo(r.y), o3 = (rs * v[3] + rm * c.w + b.w) + bf_hi(r.y);
+                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+                } else {
+                    const float4 st = *reinterpret_cast<const float4*>(g.rowv + 4 * (long)i);
+                    const float A = st.y, G = st.y * st.y * st.w, Bc = -st.y * st.z + st.x * G;
+                    const uint2 z = *reinterpret_cast<const uint2*>(g.residual + (long)i * g.ldr + j);
+                    const uint2 d = *reinterpret_cast<const uint2*>(g.gate + (long)i * g.ldgate + j);
+                    const float o0 = bf_lo(d.x) * ((A * v[0] + Bc) - G * bf_lo(z.x)), o1 = bf_hi(d.x) * ((A * v[1] + Bc) - G * bf_hi(z.x));
+                    const float o2 = bf_lo(d.y) * ((A * v[2] + Bc) - G * bf_lo(z.y)), o3 = bf_hi(d.y) * ((A * v[3] + Bc) - G * bf_hi(z.y));
+                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+                }
+                continue;
+            }
             if (g.bias) {
                 const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -978,7 +1016,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                    ONEBAR = FLAGS & K64F_ONEBAR;
     // residual / generic epilogues run from registers (permuted Q rows + lane swap, 16-B accesses of 64-B row segments: the residual is read
     // coalesced); plain / bias epilogues stage through the 32 KiB of LDS above the ring (128-B row segments)
-    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4 || EPI == 8;   // EPI 8: out = acc * gate (the dgrad through an activation whose derivative was stored)
+    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4 || EPI == 8 || EPI >= 16;   // EPI 8: out = acc * gate (the dgrad through an activation whose derivative was stored); 16 / 32 / 64: the sub-LN fold (GemmArgs::ffn_mode 1 / 2 / 3)
     const int lane = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
@@ -1232,9 +1270,42 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
         } else {
             // ---- epilogue straight from the accumulators.  lane (l15, grp) holds out[i = it 16 + l15][j = jt 16 + 4 PB(grp) + r],
             // PB = {0, 2, 1, 3}; after the swap it holds 8 consecutive columns of fragment 2 p + (lane >> 5) at (grp & 1) * 8.
-            constexpr bool GENERIC = EPI == 4, GATEMUL = EPI == 8, BIAS = (EPI & 1) && !GATEMUL, RES = (EPI & 2) && !GATEMUL;
+            constexpr bool FFN1 = EPI == 16, FFN2 = EPI == 32, FFN3 = EPI == 64;
+            constexpr bool GENERIC = EPI == 4, GATEMUL = EPI == 8, BIAS = ((EPI & 1) && EPI < 8) || FFN1, RES = ((EPI & 2) && EPI < 8) || FFN2;
             const int pbg = ((grp & 1) << 1) | (grp >> 1);
             const int jw = j0 + wj * 64, iw = i0 + wi * 128 + l15;
+            if (FFN2) {
+                // fc2 with the sub-LN folded in, on the fragment layout: acc <- rstd_i acc - rstd_i mu_i c_j + b_j; the residual epilogue below does the rest
+                float rs[TI], rm[TI];
+#pragma unroll
+                for (int it = 0; it < TI; ++it) {
+                    const float2 st = *reinterpret_cast<const float2*>(g.rowv + 2 * (long)(iw + it * 16));
+                    rs[it] = st.y; rm[it] = -st.y * st.x;
+                }
+#pragma unroll
+                for (int jt = 0; jt < TJ; ++jt) {
+                    const float4 c = *reinterpret_cast<const float4*>(g.colv + jw + jt * 16 + pbg * 4);
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + jw + jt * 16 + pbg * 4);
+#pragma unroll
+                    for (int it = 0; it < TI; ++it) {
+                        acc[it][jt][0] = rs[it] * acc[it][jt][0] + (rm[it] * c.x + b.x); acc[it][jt][1] = rs[it] * acc[it][jt][1] + (rm[it] * c.y + b.y);
+                        acc[it][jt][2] = rs[it] * acc[it][jt][2] + (rm[it] * c.z + b.z); acc[it][jt][3] = rs[it] * acc[it][jt][3] + (rm[it] * c.w + b.w);
+                    }
+                }
+                SCHED_FENCE();   // the 16 residual vectors below must not be requested while the row / column vectors above are live
+            }
+            if (FFN3) {
+                // acc <- A_i acc + B_i  (the part of the LayerNorm backward that needs no tile operand)
+#pragma unroll
+                for (int it = 0; it < TI; ++it) {
+                    const float4 st = *reinterpret_cast<const float4*>(g.rowv + 4 * (long)(iw + it * 16));
+                    const float A = st.y, Bc = -st.y * st.z + st.x * (st.y * st.y * st.w);
+#pragma unroll
+                    for (int jt = 0; jt < TJ; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[it][jt][r] = A * acc[it][jt][r] + Bc;
+                }
+            }
             if (BIAS && !GENERIC) {
 #pragma unroll
                 for (int jt = 0; jt < TJ; ++jt) {
@@ -1248,6 +1319,97 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             // all 16 residual vectors of the wave's tile are requested up front (64 VGPRs: the K loop's fragment registers are free here): ONE
             // exposed L2 / HBM latency per output tile instead of one per half -- at R = 1024 (16 K-tiles per tile) each cost ~10 % of the tile
             // (the generic epilogue keeps two halves of 8: with gate / aux operands live as well, 16 vectors spill)
+            if (FFN1) {
+                // fc1 of the folded feed-forward: z = act(u) and act'(u) stored, row sums of the rounded z kept per lane and closed over the four lanes of a row
+                float s1[TI], s2[TI];
+#pragma unroll
+                for (int it = 0; it < TI; ++it) { s1[it] = 0.f; s2[it] = 0.f; }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int it = q >> 1, p2 = q & 1, a = 2 * p2, b = 2 * p2 + 1;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const k64_u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][a][r]), __float_as_uint(acc[it][b][r]), false, false);
+                        v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    f2_t zz[4], dd[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) act_fwd_grad2<-1>((f2_t){v[2 * e], v[2 * e + 1]}, g.act, zz[e], dd[e]);
+                    const u32x4_t zv = {pack_bf2(zz[0].x, zz[0].y), pack_bf2(zz[1].x, zz[1].y), pack_bf2(zz[2].x, zz[2].y), pack_bf2(zz[3].x, zz[3].y)};
+                    const u32x4_t dv = {pack_bf2(dd[0].x, dd[0].y), pack_bf2(dd[1].x, dd[1].y), pack_bf2(dd[2].x, dd[2].y), pack_bf2(dd[3].x, dd[3].y)};
+                    f2_t t1 = f2_splat(0.f), t2 = f2_splat(0.f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const f2_t zr = f2_bf(zv[e]); t1 += zr; t2 += zr * zr; }
+                    s1[it] += t1.x + t1.y; s2[it] += t2.x + t2.y;
+                    const long row = iw + it * 16;
+                    const int col = cj + 32 * p2;
+                    K64_NT_STORE16(C + row * g.ldc + col, zv);
+                    K64_NT_STORE16(g.aux + row * g.ldaux + col, dv);
+                }
+#pragma unroll
+                for (int it = 0; it < TI; ++it) { s1[it] = rows4_sum(s1[it]); s2[it] = rows4_sum(s2[it]); }
+                if (grp == 0) {
+                    float* pp = g.part + 2 * ((long)(jw >> 6) * g.I + iw);
+#pragma unroll
+                    for (int it = 0; it < TI; ++it) *reinterpret_cast<float2*>(pp + 2 * (it * 16)) = make_float2(s1[it], s2[it]);
+                }
+            } else if (FFN3) {
+                // dgrad through the sub-LN and the activation: du = act' (acc' - G_i z);  column sums of du (the fc1 bias gradient) per 128-row block
+                float G[TI];
+#pragma unroll
+                for (int it = 0; it < TI; ++it) {
+                    const float4 st = *reinterpret_cast<const float4*>(g.rowv + 4 * (long)(iw + it * 16));
+                    G[it] = st.y * st.y * st.w;
+                }
+                f2_t cs[2][4];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[p2][e] = f2_splat(0.f);
+                // (quarters of the wave's tile: 4 + 4 operand vectors in flight -- halves of 8 + 8 spill next to the 128 accumulators)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    u32x4_t zv[4], dv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int it = h * 2 + (q >> 1), p2 = q & 1;
+                        zv[q] = *reinterpret_cast<const u32x4_t*>(g.residual + (long)(iw + it * 16) * g.ldr + cj + 32 * p2);
+                        dv[q] = *reinterpret_cast<const u32x4_t*>(g.gate + (long)(iw + it * 16) * g.ldgate + cj + 32 * p2);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int it = h * 2 + (q >> 1), p2 = q & 1, a = 2 * p2, b = 2 * p2 + 1;
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const k64_u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][a][r]), __float_as_uint(acc[it][b][r]), false, false);
+                            v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                        }
+                        u32x4_t ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f2_t du = f2_bf(dv[q][e]) * ((f2_t){v[2 * e], v[2 * e + 1]} - G[it] * f2_bf(zv[q][e]));
+                            ov[e] = pack_bf2(du.x, du.y);
+                            cs[p2][e] += f2_bf(ov[e]);   // the gradient the wgrad sees: the rounded value
+                        }
+                        K64_NT_STORE16(C + (long)(iw + it * 16) * g.ldc + cj + 32 * p2, ov);
+                    }
+                    SCHED_FENCE();
+                }
+                float* pp = g.part + (long)((i0 + wi * 128) >> 7) * g.J + cj;
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    float c8[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { c8[2 * e] = row16_sum(cs[p2][e].x); c8[2 * e + 1] = row16_sum(cs[p2][e].y); }
+                    if (l15 == 0) {
+                        *reinterpret_cast<float4*>(pp + 32 * p2) = make_float4(c8[0], c8[1], c8[2], c8[3]);
+                        *reinterpret_cast<float4*>(pp + 32 * p2 + 4) = make_float4(c8[4], c8[5], c8[6], c8[7]);
+                    }
+                }
+            } else {
             constexpr int NH = GENERIC ? 2 : 1, NV = 16 / NH;
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
@@ -1317,6 +1479,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                     if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(C + row * g.ldc + col) = ov;   // (store ablations: variant bits 11 / 12)
                     else if (g.debug_nostore != 1) K64_NT_STORE16(C + row * g.ldc + col, ov);
                 }
+            }
             }
         }
         if (!more) {
@@ -1680,6 +1843,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
+    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
     act &= 0xff;
     // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
     // about what lands in aux); gate-holds-act' needs a gate
@@ -1829,6 +1993,285 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     } else if (p_rmajor && q_rmajor && (R & 63) == 0 && (I & 127) == 0 && (J & 127) == 0) {
         hipLaunchKernelGGL((gemm_tn_dma_kernel<2, 2, 4, 4>), grid, block, lds, stream, g);
     } else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, stream, g);
+    return antmmf_check_launch();
+}
+
+// =====================================================================================================================================
+// Sub-LN fold: the M2 feed-forward  y = fc2(LayerNorm_4d(gelu(fc1(x)))) + residual  (reference prj/M2_Encoder/vlmo/torchscale/component/
+// feedforward_network.py:117-128: fc1 -> activation_fn -> ffn_layernorm -> fc2) without the two 4d-wide LayerNorm passes.  With z = gelu(u),
+// (mu_i, r_i) the row statistics of z, W2g = W2 diag(gamma), c_j = sum_k W2g[j][k], b2f = b2 + W2 beta:
+//   forward   fc1's epilogue stores z and gelu'(u) and the row sums of z;  y_ij = r_i (z W2g^T)_ij - r_i mu_i c_j + b2f_j + res_ij  (fc2's epilogue)
+//   backward  t = dy W2g (dgrad) ;  dz_ik = r_i (t_ik - m1_i - zhat_ik m2_i),  m1 = mean_k t = dy . c / F,  m2 = mean_k t zhat = dy . (y - b2f - res) / F
+//             -- both row dot products over d-wide tensors the step keeps anyway (a row pass over 3 d-wide tensors instead of 3 4d-wide ones) --
+//             du = gelu'(u) dz in the dgrad's epilogue, with the fc1 bias gradient (column sums of du) from the same tiles;
+//             dW2_jk = gamma_k (Gm_jk - s_j) + beta_k cs_j,  Gm = (r dy)^T z,  s_j = sum_i r_i mu_i dy_ij,  cs = column sums of dy;
+//             dgamma_k = sum_j W2_jk (Gm_jk - s_j),  dbeta_k = sum_j W2_jk cs_j.
+// The 4d-wide tensors are touched by GEMM epilogues only.
+static int gemm_ffn_launch(GemmArgs& g, hipStream_t stream) {
+    const long tiles256 = (long)((g.I + 255) / 256) * ((g.J + 255) / 256);
+    static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");
+    const bool aligned = !(g.I & 255) && !(g.J & 255) && !(g.R & 63) && g.R >= 128 && !(g.ldc & 7) && !(g.ldp & 7) && !(g.ldq & 7) &&
+                         (!g.residual || !(g.ldr & 7)) && (!g.aux || !(g.ldaux & 7)) && (!g.gate || !(g.ldgate & 7));
+    const bool k64p = aligned && g.part && (force ? force[0] == 'k' : tiles256 >= 512);
+    if (!k64p) {
+        g.part = nullptr;
+        const long tiles = (long)((g.I + 127) / 128) * ((g.J + 127) / 128);
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
+        hipLaunchKernelGGL((gemm_kernel<false, false>), dim3((unsigned)tiles, 1, 1), dim3(256), 65536, stream, g);
+        return 0;
+    }
+    static const char* pwgs_env = getenv("ANTMMF_GEMM_PERSIST_WGS");
+    const unsigned pwgs = pwgs_env ? (unsigned)atoi(pwgs_env) : 256u;
+    const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);
+    const unsigned gridp = pwgs < t8 ? pwgs : t8;
+    ++g_k64_launches;
+#define FFN_LAUNCH(E_, F_)                                                                                                        \
+    do {                                                                                                                          \
+        static bool oncep = false;                                                                                                \
+        if (!oncep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64p_kernel<E_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); oncep = true; } \
+        hipLaunchKernelGGL((gemm_nt_k64p_kernel<E_, F_>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);              \
+    } while (0)
+    if (g.ffn_mode == 1) FFN_LAUNCH(16, K64F_ONEBAR | K64F_PRIO);
+    else if (g.ffn_mode == 2) FFN_LAUNCH(32, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
+    else FFN_LAUNCH(64, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
+#undef FFN_LAUNCH
+    return 1;
+}
+
+static void gemm_ffn_args(GemmArgs& g, const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc) {
+    g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.C = C; g.bias = nullptr; g.residual = nullptr; g.aux = nullptr; g.gate = nullptr;
+    g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = 0; g.ldaux = 0; g.ldgate = 0;
+    g.I = I; g.J = J; g.R = R; g.act = ANTMMF_ACT_NONE; g.c_dtype = ANTMMF_BF16; g.accumulate = 0; g.ksteps_per_split = (R + 63) / 64; g.alpha = 1.0f;
+    g.ws = nullptr; g.raster = 1; g.aux_grad = 0; g.gate_grad = 0; g.debug_nostore = 0;
+    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
+}
+static bool ffn_shape_ok(int I, int J, int R, long ldp, long ldq, long ldc) {
+    return I > 0 && J > 0 && R > 0 && !(J & 7) && !(R & 7) && !(ldp & 7) && !(ldq & 7) && !(ldc & 7);
+}
+
+// (sum z, sum z^2) partials per 64-column block -> (mean, rstd) per row
+__global__ __launch_bounds__(256) void ffn_stats_reduce_kernel(const float* __restrict__ part, int nblk, int I, int F, float eps, float* __restrict__ stats) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float2 p = *reinterpret_cast<const float2*>(part + 2 * ((long)b * I + i));
+        s1 += p.x; s2 += p.y;
+    }
+    const float mu = s1 / (float)F;
+    float var = s2 / (float)F - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    *reinterpret_cast<float2*>(stats + 2 * (long)i) = make_float2(mu, rsqrtf(var + eps));
+}
+// the same statistics straight from a stored z (shapes that do not run on the persistent kernel): one wave per row, two-pass
+__global__ __launch_bounds__(256) void ffn_row_stats_kernel(const bf16_t* __restrict__ Z, long ldz, int I, int F, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= I) return;
+    const bf16_t* z = Z + i * ldz;
+    float s1 = 0.f;
+    for (int k = lane * 8; k < F; k += 512) { float v[8]; ld8<bf16_t>(z + k, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += v[e]; }
+    const float mu = wave_sum(s1) / (float)F;
+    float s2 = 0.f;
+    for (int k = lane * 8; k < F; k += 512) { float v[8]; ld8<bf16_t>(z + k, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 += (v[e] - mu) * (v[e] - mu); }
+    const float var = wave_sum(s2) / (float)F;
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * i) = make_float2(mu, rsqrtf(var + eps));
+}
+// out[c] += sum over the partial rows (split over gridDim.y, closed with one atomic per column and slice)
+__global__ __launch_bounds__(256) void ffn_colpart_reduce_kernel(const float* __restrict__ part, int nparts, int J, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= J) return;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += part[(long)p * J + c];
+    if (p1 > p0) atomicAdd(out + c, s);
+}
+
+extern "C" int antmmf_colsum(const void* x, float* out, long rows, int cols, long ld, int dtype, hipStream_t s);
+
+extern "C" int antmmf_ffn_fc1_fwd(const void* X, const void* W1, const float* b1, void* Z, void* DACT, float* stats, int tokens, int n_ff, int n_in,
+                                  long ldx, long ldw, long ldz, int act, float eps, float* workspace, long workspace_bytes, hipStream_t stream) {
+    if (!X || !W1 || !b1 || !Z || !DACT || !stats || !ffn_shape_ok(tokens, n_ff, n_in, ldx, ldw, ldz) || act == ANTMMF_ACT_NONE) return ANTMMF_EINVAL;
+    GemmArgs g;
+    gemm_ffn_args(g, X, W1, Z, tokens, n_ff, n_in, ldx, ldw, ldz);
+    g.bias = b1; g.aux = (bf16_t*)DACT; g.ldaux = ldz; g.act = act; g.ffn_mode = 1;
+    const int nblk = n_ff / 64;
+    if (workspace && !(n_ff & 63) && workspace_bytes >= (long)nblk * tokens * 8) g.part = workspace;
+    if (gemm_ffn_launch(g, stream)) hipLaunchKernelGGL(ffn_stats_reduce_kernel, dim3((tokens + 255) / 256), dim3(256), 0, stream, workspace, nblk, tokens, n_ff, eps, stats);
+    else hipLaunchKernelGGL(ffn_row_stats_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, (const bf16_t*)Z, ldz, tokens, n_ff, eps, stats);
+    return antmmf_check_launch();
+}
+
+extern "C" int antmmf_ffn_fc2_fwd(const void* Z, const void* W2g, const float* colsum_w2g, const float* b2f, const float* stats, const void* RES, void* Y,
+                                  int tokens, int n_out, int n_ff, long ldz, long ldw, long ldres, long ldy, hipStream_t stream) {
+    if (!Z || !W2g || !colsum_w2g || !b2f || !stats || !RES || !Y || !ffn_shape_ok(tokens, n_out, n_ff, ldz, ldw, ldy) || (ldres & 7)) return ANTMMF_EINVAL;
+    GemmArgs g;
+    gemm_ffn_args(g, Z, W2g, Y, tokens, n_out, n_ff, ldz, ldw, ldy);
+    g.bias = b2f; g.residual = (const bf16_t*)RES; g.ldr = ldres; g.rowv = stats; g.colv = colsum_w2g; g.ffn_mode = 2;
+    float dummy;   // the persistent kernel is chosen by g.part != NULL; mode 2 writes no partials
+    g.part = &dummy;
+    gemm_ffn_launch(g, stream);
+    return antmmf_check_launch();
+}
+
+extern "C" int antmmf_ffn_fc2_dgrad(const void* dY, const void* W2gT, const void* Z, const void* DACT, const float* rowv4, void* dU, float* db1,
+                                    int tokens, int n_ff, int n_out, long lddy, long ldw, long ldz, long lddu, float* workspace, long workspace_bytes,
+                                    hipStream_t stream) {
+    if (!dY || !W2gT || !Z || !DACT || !rowv4 || !dU || !ffn_shape_ok(tokens, n_ff, n_out, lddy, ldw, lddu) || (ldz & 7)) return ANTMMF_EINVAL;
+    GemmArgs g;
+    gemm_ffn_args(g, dY, W2gT, dU, tokens, n_ff, n_out, lddy, ldw, lddu);
+    g.residual = (const bf16_t*)Z; g.ldr = ldz; g.gate = (const bf16_t*)DACT; g.ldgate = ldz; g.rowv = rowv4; g.ffn_mode = 3;
+    const int nparts = tokens / 128;
+    if (workspace && !(tokens & 127) && workspace_bytes >= (long)nparts * n_ff * 4) g.part = workspace;
+    if (gemm_ffn_launch(g, stream)) {
+        if (db1) hipLaunchKernelGGL(ffn_colpart_reduce_kernel, dim3((n_ff + 255) / 256, 16), dim3(256), 0, stream, workspace, nparts, n_ff, db1);
+    } else if (db1) {
+        const int rc = antmmf_colsum(dU, db1, tokens, n_ff, lddu, ANTMMF_BF16, stream);
+        if (rc) return rc;
+    }
+    return antmmf_check_launch();
+}
+
+// Backward row pass over the d-wide tensors: rowv4[i] = (mu, rstd, m1, m2), dYs = bf16(rstd_i dy), s_col[j] += sum_i rstd_i mu_i dy_ij, cs_col[j] += sum_i dy_ij.
+// One wave per row (n_out <= 2048: up to four 16-B chunks per lane), persistent over rows; the column sums are closed per workgroup (LDS) + one atomic per column.
+template <int NCH>
+__global__ __launch_bounds__(256) void ffn_bwd_rows_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ Y, const bf16_t* __restrict__ RES,
+                                                           const float* __restrict__ b2f, const float* __restrict__ cw, const float* __restrict__ stats,
+                                                           float* __restrict__ rowv4, bf16_t* __restrict__ dYs, float* __restrict__ s_col, float* __restrict__ cs_col,
+                                                           int tokens, int n_out, float inv_f, long lddy, long ldy, long ldres, long lddys) {
+    ANTMMF_DYN_LDS(float, red);   // [4 waves][2][n_out]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float cb[NCH][8], cc[NCH][8], as_[NCH][8], ac[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { as_[c][e] = 0.f; ac[c][e] = 0.f; cb[c][e] = 0.f; cc[c][e] = 0.f; }
+        if (k < n_out) { ld8<float>(b2f + k, cb[c]); ld8<float>(cw + k, cc[c]); }
+    }
+    for (long i = (long)blockIdx.x * 4 + wave; i < tokens; i += (long)gridDim.x * 4) {
+        float dy[NCH][8];
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 512 + lane * 8;
+            if (k < n_out) {
+                float y[8], r[8];
+                ld8<bf16_t>(dY + i * lddy + k, dy[c]); ld8<bf16_t>(Y + i * ldy + k, y); ld8<bf16_t>(RES + i * ldres + k, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d1 += dy[c][e] * cc[c][e]; d2 += dy[c][e] * ((y[e] - r[e]) - cb[c][e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dy[c][e] = 0.f;
+            }
+        }
+        d1 = wave_sum(d1) * inv_f; d2 = wave_sum(d2) * inv_f;
+        const float2 st = *reinterpret_cast<const float2*>(stats + 2 * i);
+        if (lane == 0) *reinterpret_cast<float4*>(rowv4 + 4 * i) = make_float4(st.x, st.y, d1, d2);
+        const float rm = st.y * st.x;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 512 + lane * 8;
+            if (k < n_out) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = st.y * dy[c][e]; as_[c][e] += rm * dy[c][e]; ac[c][e] += dy[c][e]; }
+                st8<bf16_t>(dYs + i * lddys + k, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 512 + lane * 8;
+        if (k < n_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * n_out + k + e] = as_[c][e]; red[(wave * 2 + 1) * n_out + k + e] = ac[c][e]; }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_out; k += 256) {
+        atomicAdd(s_col + k, (red[0 * n_out + k] + red[2 * n_out + k]) + (red[4 * n_out + k] + red[6 * n_out + k]));
+        if (cs_col) atomicAdd(cs_col + k, (red[1 * n_out + k] + red[3 * n_out + k]) + (red[5 * n_out + k] + red[7 * n_out + k]));
+    }
+}
+
+extern "C" int antmmf_ffn_bwd_rows(const void* dY, const void* Y, const void* RES, const float* b2f, const float* colsum_w2g, const float* stats,
+                                   float* rowv4, void* dYs, float* s_col, float* cs_col, int tokens, int n_out, int n_ff,
+                                   long lddy, long ldy, long ldres, long lddys, hipStream_t stream) {
+    if (!dY || !Y || !RES || !b2f || !colsum_w2g || !stats || !rowv4 || !dYs || !s_col || tokens <= 0 || n_out <= 0 || (n_out & 7) || n_out > 2048 || n_ff <= 0 ||
+        (lddy & 7) || (ldy & 7) || (ldres & 7) || (lddys & 7)) return ANTMMF_EINVAL;
+    int wgs = (tokens + 3) / 4;
+    if (wgs > 1024) wgs = 1024;
+    const size_t lds = (size_t)8 * n_out * sizeof(float);
+    const float inv_f = 1.0f / (float)n_ff;
+#define ROWS_LAUNCH(N)                                                                                                                          \
+    do {                                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_rows_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(ffn_bwd_rows_kernel<N>, dim3(wgs), dim3(256), lds, stream, (const bf16_t*)dY, (const bf16_t*)Y, (const bf16_t*)RES, b2f, colsum_w2g, \
+                           stats, rowv4, (bf16_t*)dYs, s_col, cs_col, tokens, n_out, inv_f, lddy, ldy, ldres, lddys);                           \
+    } while (0)
+    const int nch = (n_out + 511) / 512;
+    if (nch == 1) ROWS_LAUNCH(1); else if (nch == 2) ROWS_LAUNCH(2); else if (nch == 3) ROWS_LAUNCH(3); else ROWS_LAUNCH(4);
+#undef ROWS_LAUNCH
+    return antmmf_check_launch();
+}
+
+// dW2[j][k] += gamma_k (Gm[j][k] - s_j) + beta_k cs_j;  dgamma_k += sum_j W2[j][k] (Gm[j][k] - s_j);  dbeta_k += sum_j W2[j][k] cs_j.
+// Workgroup = 16 rows j x 256 columns k (thread = one column): coalesced rows, the column sums of the slab go out as one atomic per column.
+__global__ __launch_bounds__(256) void ffn_wgrad_post_kernel(const float* __restrict__ Gm, const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ s, const float* __restrict__ cs,
+                                                             float* __restrict__ dW2, float* __restrict__ dgamma, float* __restrict__ dbeta, int n_out, int n_ff) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ff) return;
+    const int j0 = blockIdx.y * 16, j1 = j0 + 16 < n_out ? j0 + 16 : n_out;
+    const float ga = gamma[k], be = beta[k];
+    float dg = 0.f, db = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const long o = (long)j * n_ff + k;
+        const float h = Gm[o] - s[j], w = W2[o], c = cs[j];
+        dW2[o] += ga * h + be * c;
+        dg += w * h; db += w * c;
+    }
+    if (dgamma) atomicAdd(dgamma + k, dg);
+    if (dbeta) atomicAdd(dbeta + k, db);
+}
+extern "C" int antmmf_ffn_wgrad_post(const float* Gm, const float* W2, const float* gamma, const float* beta, const float* s, const float* cs, float* dW2,
+                                     float* dgamma, float* dbeta, int n_out, int n_ff, hipStream_t stream) {
+    if (!Gm || !W2 || !gamma || !beta || !s || !cs || !dW2 || n_out <= 0 || n_ff <= 0) return ANTMMF_EINVAL;
+    hipLaunchKernelGGL(ffn_wgrad_post_kernel, dim3((n_ff + 255) / 256, (n_out + 15) / 16), dim3(256), 0, stream, Gm, W2, gamma, beta, s, cs, dW2, dgamma, dbeta, n_out, n_ff);
+    return antmmf_check_launch();
+}
+
+// Once per optimizer step and layer: W2g[j][k] = bf16(W2[j][k] gamma_k),  c_j = sum_k W2g[j][k] (of the ROUNDED operand the GEMM multiplies),
+// b2f_j = b2_j + sum_k beta_k W2[j][k].  One workgroup per output row j.
+__global__ __launch_bounds__(256) void ffn_prepare_w2_kernel(const float* __restrict__ W2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ b2, bf16_t* __restrict__ W2g, float* __restrict__ c, float* __restrict__ b2f, int n_ff) {
+    __shared__ float red[2][4];
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sc = 0.f, sb = 0.f;
+    for (int k = threadIdx.x; k < n_ff; k += 256) {
+        const float w = W2[(long)j * n_ff + k];
+        const bf16_t q = f2bf(w * gamma[k]);
+        W2g[(long)j * n_ff + k] = q;
+        sc += bf2f(q); sb += beta[k] * w;
+    }
+    sc = wave_sum(sc); sb = wave_sum(sb);
+    if (lane == 0) { red[0][wave] = sc; red[1][wave] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c[j] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        b2f[j] = (b2 ? b2[j] : 0.f) + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+extern "C" int antmmf_ffn_prepare_w2(const float* W2, const float* gamma, const float* beta, const float* b2, void* W2g, float* c, float* b2f, int n_out, int n_ff,
+                                     hipStream_t stream) {
+    if (!W2 || !gamma || !beta || !W2g || !c || !b2f || n_out <= 0 || n_ff <= 0) return ANTMMF_EINVAL;
+    hipLaunchKernelGGL(ffn_prepare_w2_kernel, dim3(n_out), dim3(256), 0, stream, W2, gamma, beta, b2, (bf16_t*)W2g, c, b2f, n_ff);
     return antmmf_check_launch();
 }
 

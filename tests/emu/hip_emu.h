@@ -33,6 +33,8 @@ struct dim3 {
 struct uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+static inline float2 make_float2(float a, float b) { return {a, b}; }
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return {a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return {a, b, c, d}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }

@@ -110,6 +110,70 @@ def case_act_layernorm(ops, dev, dtype, rows=9, cols=512, act="gelu"):
     check(f"actln.{act}.dbeta", dbet, br.grad, 1e-4, 1e-4)
 
 
+# ------------------------------------------------------------------------------ M2 feed-forward with the sub-LayerNorm folded into its GEMMs
+def case_ffn_fold(ops, dev, tokens=40, d=64, ff=192, eps=1e-5, seed=300, res_scale=1.0, act="gelu"):
+    """fc1 -> gelu -> ffn_layernorm -> fc2 (+ residual) and its whole backward through antmmf_ffn_* vs fp32 autograd on the same bf16-rounded
+    operands (reference feedforward_network.py:117-128).  Small shapes take the element-wise epilogues + the row / column passes; 256-aligned
+    ones under ANTMMF_GEMM_FORCE_TILE=k the persistent kernel's epilogues with their per-tile partial sums."""
+    fn = {"gelu": oops.gelu_erf, "quick_gelu": oops.quick_gelu}[act]
+    x = q(rnd((tokens, d), seed, 1.0))
+    W1 = rnd((ff, d), seed + 1, d ** -0.5)
+    b1 = 0.2 * rnd((ff,), seed + 2)
+    gam = 1 + 0.2 * rnd((ff,), seed + 3)
+    bet = 0.1 * rnd((ff,), seed + 4)
+    W2 = rnd((d, ff), seed + 5, ff ** -0.5)
+    b2 = 0.1 * rnd((d,), seed + 6)
+    res = q(rnd((tokens, d), seed + 7, res_scale))
+    dy = q(rnd((tokens, d), seed + 8, 1.0))
+    # fp32 reference on the operands the kernels see (bf16 weights for the GEMMs, fp32 LayerNorm parameters)
+    xr = x.clone().requires_grad_(True)
+    W1r, b1r = q(W1).requires_grad_(True), b1.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    W2r, b2r = W2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    ur = xr @ W1r.t() + b1r
+    ur.retain_grad()
+    zr = fn(ur)
+    yr = oops.layer_norm(zr, gr, br, eps) @ W2r.t() + b2r + res
+    yr.backward(dy)
+
+    to = lambda t, dt=torch.float32: t.to(dev, dt)
+    w2g, c, b2f = ops.ffn_prepare_w2(to(W2), to(gam), to(bet), to(b2))
+    check("ffn.w2g", w2g, W2 * gam[None, :], 1e-2, 1e-2)
+    check("ffn.c", c, w2g.float().cpu().sum(1), 1e-5, 1e-5)
+    check("ffn.b2f", b2f, b2 + W2 @ bet, 1e-5, 1e-5)
+    z, dact, stats = ops.ffn_fc1_fwd(to(x, BF), to(q(W1), BF), to(b1), act, eps)
+    check("ffn.z", z, zr, 2e-2, 1e-2)
+    zq = z.float().cpu()
+    mu_ref, var_ref = zq.mean(1), zq.var(1, unbiased=False)
+    check("ffn.mu", stats[:, 0], mu_ref, 1e-4, 1e-4)
+    check("ffn.rstd", stats[:, 1], (var_ref + eps).rsqrt(), 1e-4, 1e-4)
+    ug = ur.detach().clone().requires_grad_(True)
+    fn(ug).sum().backward()
+    check("ffn.dact", dact, ug.grad, 2e-2, 1e-2)
+    y = ops.ffn_fc2_fwd(z, w2g, c, b2f, stats, to(res, BF))
+    check("ffn.y", y, yr, 2e-2, 1e-2)
+    # backward
+    s_col, cs_col = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    rowv4, dys = ops.ffn_bwd_rows(to(dy, BF), y, to(res, BF), b2f, c, stats, ff, s_col, cs_col)
+    check("ffn.cs", cs_col, dy.sum(0), 1e-4, 1e-4)
+    t_ref = dy @ w2g.float().cpu()                               # gamma (.) dn
+    zhat = (zq - mu_ref[:, None]) * (var_ref[:, None] + eps).rsqrt()
+    check("ffn.m1", rowv4[:, 2], t_ref.mean(1), 1e-3, 1e-3)
+    check("ffn.m2", rowv4[:, 3], (t_ref * zhat).mean(1), 5e-2, 5e-2)   # from y - b2f - res in bf16: exact up to the rounding of y
+    db1 = torch.zeros(ff, device=dev)
+    du = ops.ffn_fc2_dgrad(to(dy, BF), ops.transpose_bf16(w2g), z, dact, rowv4, db1)
+    check("ffn.du", du, ur.grad, 3e-2, 2e-2)
+    check("ffn.db1", db1, du.float().cpu().sum(0), 1e-3, 1e-3 * max(1.0, tokens ** 0.5))
+    check("ffn.db1.ref", db1, b1r.grad, 3e-2, 3e-2 * max(1.0, tokens ** 0.5) / 4)
+    Gm = torch.zeros(d, ff, device=dev)
+    ops.gemm_wgrad_(Gm, dys, z)
+    dW2, dgam, dbet = torch.zeros(d, ff, device=dev), torch.zeros(ff, device=dev), torch.zeros(ff, device=dev)
+    ops.ffn_wgrad_post_(dW2, Gm, to(W2), to(gam), to(bet), s_col, cs_col, dgam, dbet)
+    check("ffn.dW2", dW2, W2r.grad, 3e-2, 2e-2)
+    check("ffn.dgamma", dgam, gr.grad, 3e-2, 3e-2)
+    check("ffn.dbeta", dbet, br.grad, 2e-2, 2e-2)
+
+
 # ------------------------------------------------------------------------------ activations / l2norm / colsum / movers
 def case_activations(ops, dev):
     for act, fn in (("gelu", oops.gelu_erf), ("quick_gelu", oops.quick_gelu), ("relu", torch.relu)):

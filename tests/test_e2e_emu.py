@@ -140,3 +140,18 @@ def test_dmae_seqtransf_vs_reference(golden):
 @SLOW
 def test_m2_itc_step_vs_oracle():
     print(mc.case_m2_itc_vs_oracle(torch.device("cpu")))
+
+
+@SLOW
+def test_m2_sub_ln_fold(golden):
+    """The optional sub-LN fold of the M2 layers (gelu -> ffn_layernorm inside the GEMM epilogues; functional.set_ffn_fold): reference goldens for the
+    towers at the usual gates."""
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    functional.set_ffn_fold(True)
+    try:
+        print(mc.case_m2_towers(torch.device("cpu"), golden))
+    finally:
+        functional.set_ffn_fold(False)
+        functional.set_keep_ffn_norm(False)

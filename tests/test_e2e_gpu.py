@@ -196,11 +196,39 @@ def test_m2_itc_step_vs_oracle_keep_ffn_norm():
         functional.set_keep_ffn_norm(False)
 
 
+def test_m2_towers_vs_reference_sub_ln_fold(golden):
+    """The M2 towers with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) against the same reference goldens and gates: logits, every parameter's gradient direction."""
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    functional.set_ffn_fold(True)
+    try:
+        print(mc.case_m2_towers(DEV, golden))
+    finally:
+        functional.set_ffn_fold(False)
+        functional.set_keep_ffn_norm(False)
+
+
 @pytest.mark.parametrize("kind,d,heads,N,pad", [("m2", 1024, 16, 257, 0), ("m2", 1024, 16, 77, 30), ("clip", 768, 12, 197, 0), ("m2", 768, 12, 197, 0)])
 def test_transformer_layer_real_width_vs_oracle(kind, d, heads, N, pad):
     """One fused layer at the real widths of BASELINE.json's configs (ViT-L/14 image / text towers, ViT-B/16) vs the fp32 oracle:
     output, input gradient and every parameter gradient (cosine >= 0.999, norm within 2 %)."""
     print(mc.case_layer_real_width(DEV, kind=kind, d=d, heads=heads, N=N, B=2, pad_tail=pad))
+
+
+@pytest.mark.parametrize("N,B,pad", [(257, 2, 0), (77, 3, 30), (256, 32, 0)])
+def test_m2_layer_real_width_sub_ln_fold(N, B, pad):
+    """The M2 layer at ViT-L/14 width with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) vs the fp32 oracle at the same gates (cosine >= 0.999, norm
+    within 2 %); 32 x 256 tokens puts fc1 and the dgrad on the persistent kernel's epilogues (512 tiles)."""
+    from antmmf.hip import functional
+
+    functional.set_keep_ffn_norm(True)
+    functional.set_ffn_fold(True)
+    try:
+        print(mc.case_layer_real_width(DEV, kind="m2", d=1024, heads=16, N=N, B=B, pad_tail=pad))
+    finally:
+        functional.set_ffn_fold(False)
+        functional.set_keep_ffn_norm(False)
 
 
 def test_smoke_entry():

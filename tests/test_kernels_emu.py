@@ -61,6 +61,30 @@ def test_act_layernorm(ops):
     kc.case_layernorm(ops, DEV, torch.float32, rows=7, cols=4096)
 
 
+def test_ffn_fold_elementwise(ops):
+    """Sub-LN fold through the generic kernel's epilogues + the row-statistics / column-sum passes (shapes the persistent kernel does not take)."""
+    kc.case_ffn_fold(ops, DEV, tokens=40, d=64, ff=192)
+    kc.case_ffn_fold(ops, DEV, tokens=9, d=128, ff=512, res_scale=4.0, seed=340)
+    kc.case_ffn_fold(ops, DEV, tokens=17, d=64, ff=128, act="quick_gelu", seed=380)
+
+
+def test_ffn_fold_persistent_kernel():
+    """The same operator on the BK = 64 persistent kernel's register-level epilogues (row partials of fc1, row-affine fc2, LayerNorm-backward dgrad with the
+    bias-gradient partials): 256-aligned shapes, an 8-workgroup grid so that workgroups walk several tiles."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
+            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '8';"
+            "import ctypes; import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cpu');"
+            "kc.case_ffn_fold(ops, dev, tokens=512, d=256, ff=512, seed=420);"
+            "lib = ctypes.CDLL(os.environ['ANTMMF_HIP_LIB']); lib.antmmf_debug_gemm_k64_launches.restype = ctypes.c_long;"
+            "assert lib.antmmf_debug_gemm_k64_launches() >= 3, lib.antmmf_debug_gemm_k64_launches(); print('okffn')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert "okffn" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_activations(ops):
     kc.case_activations(ops, DEV)
 

@@ -42,6 +42,36 @@ def test_act_layernorm(ops):
         kc.case_act_layernorm(ops, DEV, dtype, rows=77, cols=512, act="quick_gelu")
 
 
+def test_ffn_fold(ops):
+    """Sub-LN fold: element-wise epilogues + row / column passes (unaligned shapes), then ViT-L/14 widths where all three GEMMs run on the persistent
+    kernel (>= 512 tiles each: fc1 / dgrad 128 x 16, fc2 128 x 4) with their per-tile partial sums."""
+    kc.case_ffn_fold(ops, DEV, tokens=40, d=64, ff=192)
+    kc.case_ffn_fold(ops, DEV, tokens=515, d=768, ff=3072, res_scale=4.0, seed=340)
+    kc.case_ffn_fold(ops, DEV, tokens=77, d=128, ff=512, act="quick_gelu", seed=380)
+    import ctypes
+    from antmmf.hip import _lib
+
+    lib = ctypes.CDLL(_lib.DEFAULT_LIB)
+    lib.antmmf_debug_gemm_k64_launches.restype = ctypes.c_long
+    before = lib.antmmf_debug_gemm_k64_launches()
+    kc.case_ffn_fold(ops, DEV, tokens=32768, d=1024, ff=4096, seed=500)
+    assert lib.antmmf_debug_gemm_k64_launches() - before >= 4   # fc1, fc2, dgrad (+ the wgrad)
+
+
+def test_ffn_fold_forced_persistent():
+    """The same operator with every GEMM forced onto the persistent kernel at a size where workgroups walk several tiles of a short grid."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k'; os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '24';"
+            "import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cuda:0');"
+            "kc.case_ffn_fold(ops, dev, tokens=2048, d=1024, ff=4096, seed=520); kc.case_ffn_fold(ops, dev, tokens=768, d=768, ff=3072, seed=540); print('okffn')"
+            % (os.path.join(root, "tests"), os.path.join(root, "ant-multi-modal-framework_amd"), root))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "okffn" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_activations(ops):
     kc.case_activations(ops, DEV)
 
