@@ -17,3 +17,6 @@ class TextEncoder(ModuleRegistry):
 class VisualEncoder(ModuleRegistry):
     def __init__(self, config, *args, **kwargs):
         super().__init__(config["type"], *args, **kwargs, **_params(config))
+
+
+from . import text_encoder  # noqa: E402,F401  (registers PretrainedTransformerEncoder)

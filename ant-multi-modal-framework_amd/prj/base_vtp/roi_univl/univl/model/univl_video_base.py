@@ -2,7 +2,7 @@
 prj/base_vtp/roi_univl/univl/model/univl_video_base.py:14-166,272-299) and the stage-2 cross-modal merged attention
 (prepare_cross_text / prepare_cross_visual / get_cross_output, reference :168-271): [text tokens ; clip tokens ; SEP] through
 the text tower's own BERT layers (fused HIP layers with the -10000 key mask), pooled = cls @ text_projection.
-In scope: arch_type "clip"."""
+arch_type "clip" (in-repo CLIP ViT + BERT) or "univl" (PretrainedTransformerEncoder: HF-BERT weight layout on the fused BERT, pooler heads, img_fc)."""
 import torch
 from torch import nn
 
@@ -18,8 +18,8 @@ class UnivlVideoBase(nn.Module):
         self.with_cross_encoder = kwargs.get("with_cross_encoder", None)
         if self.with_cross_encoder is None:
             self.with_cross_encoder = self.config.with_cross_encoder
-        if self.arch_type != "clip":
-            raise NotImplementedError("HIP path: arch_type 'clip' (in-repo ViT + BERT); the HF-AutoModel 'univl' arch is out of scope")
+        if self.arch_type not in ("clip", "univl"):
+            raise NotImplementedError(f"arch_type {self.arch_type!r}: 'clip' (in-repo ViT + BERT towers) or 'univl' (PretrainedTransformerEncoder text tower)")
         self.build()
 
     def build(self):
@@ -29,9 +29,16 @@ class UnivlVideoBase(nn.Module):
         if self.img_encoder.out_dim != self.config.hidden_size:
             self.img_proj = nn.Parameter(torch.empty((self.img_encoder.out_dim, self.config.hidden_size)))
             nn.init.normal_(self.img_proj, std=self.img_encoder.out_dim ** -0.5)
+        if self.arch_type == "univl":   # reference :37-45: an MLP on the clip feature, registered on the image encoder
+            h = self.config.hidden_size
+            self.img_encoder.add_module("img_fc", nn.Sequential(nn.Linear(h, h), nn.ReLU(), nn.Linear(h, h)))
         # the cross encoder shares the text tower's embeddings / layers (reference :47-48)
         self.cross_embeddings = self.text_encoder.embeddings
         self.cross_encoder = self.text_encoder.encoder
+        if self.with_cross_encoder is True and self.arch_type == "univl":
+            import copy
+
+            self.cross_pooler = copy.deepcopy(self.text_encoder.pooler)   # its own parameters (reference :51-54)
 
     def forward_img_encoder(self, image_data, image_pad_mask, image_n_clips, image_num_frames, img_encoder=None, **kwargs):
         img_encoder = img_encoder or self.img_encoder
@@ -48,13 +55,22 @@ class UnivlVideoBase(nn.Module):
         clip_feature = (feat.float() * keep).sum(dim=(1, 3)) / keep.sum(dim=(1, 3))
         clip_tokens = clip_feature.view(bsz, n_clips, c)
         clip_mask = torch.zeros((bsz, n_clips), device=clip_tokens.device, dtype=torch.bool)
+        if "img_fc" in img_encoder._modules:
+            fc = img_encoder.img_fc
+            hid = HF.linear(clip_feature.to(torch.bfloat16).contiguous(), fc[0].weight, fc[0].bias, act="relu")
+            clip_feature = HF.linear(hid, fc[2].weight, fc[2].bias)
         clip_feature = HF.l2_normalize(clip_feature.to(feat.dtype).contiguous())
         return dict(visual_embed=clip_tokens, visual_mask=clip_mask, visual_grid_shape=grid_feature.shape[-2:],
                     clip_feature=clip_feature)
 
     def forward_text_encoder(self, input_ids, input_mask, txt_encoder=None):
         text_encoder = txt_encoder or self.text_encoder
-        sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask)
+        if self.arch_type == "univl":
+            # (the reference also asks for the attention maps in training to derive `words_importance`, which only the pretraining head's masking reads:
+            # on the fused path the maps never reach HBM and the entry stays None)
+            sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=torch.zeros_like(input_ids))[:2]
+        else:
+            sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask)
         pooled_output = HF.l2_normalize(pooled_output.contiguous())
         return dict(sequence_output=sequence_output, pooled_output=pooled_output, input_mask=input_mask, words_importance=None)
 
@@ -97,7 +113,9 @@ class UnivlVideoBase(nn.Module):
         key_bias = (1.0 - mask.float()) * -10000.0
         sequence_output = self.cross_encoder(embed, key_bias.contiguous(), head_mask=None)[0]
         cls = sequence_output[:, 0, :].contiguous()
-        if self.text_encoder.text_projection is not None:
+        if self.arch_type == "univl":
+            pooled_output = self.cross_pooler(sequence_output)
+        elif self.text_encoder.text_projection is not None:
             pooled_output = HF.linear(cls, self.text_encoder.text_projection, weight_layout="io")
         else:
             pooled_output = cls
