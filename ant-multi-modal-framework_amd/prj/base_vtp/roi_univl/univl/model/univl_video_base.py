@@ -114,7 +114,7 @@ class UnivlVideoBase(nn.Module):
         sequence_output = self.cross_encoder(embed, key_bias.contiguous(), head_mask=None)[0]
         cls = sequence_output[:, 0, :].contiguous()
         if self.arch_type == "univl":
-            pooled_output = self.cross_pooler(sequence_output)
+            pooled_output = self.cross_pooler(sequence_output).to(sequence_output.dtype)   # (the pooler's tanh runs in fp32; the similarity MLP takes the activation dtype)
         elif self.text_encoder.text_projection is not None:
             pooled_output = HF.linear(cls, self.text_encoder.text_projection, weight_layout="io")
         else:
