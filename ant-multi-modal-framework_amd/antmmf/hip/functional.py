@@ -142,13 +142,9 @@ class GradSink:
         return self._fresh.get(id(p))
 
 
-def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False, bias=None):
-    """dW += dy^T x  (W stored [out, in]);  for W stored [in, out] (CLIP `proj`) dW += x^T dy.  `bias`: the Linear's bias parameter -- its gradient (column sums
-    of dy) is taken by the same call (inside the wgrad kernel where the shape allows: no pass over dy), so callers that pass it do not call _bgrad."""
-    want_b = bias is not None and bias.requires_grad
+def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
+    """dW += dy^T x  (W stored [out, in]);  for W stored [in, out] (CLIP `proj`) dW += x^T dy."""
     if W is None or not W.requires_grad:
-        if want_b:
-            ops.colsum_(sink.buf(bias), dy2d)
         return
     out = sink.buf(W)
     tiles = ((out.shape[0] + 127) // 128) * ((out.shape[1] + 127) // 128)
@@ -158,10 +154,8 @@ def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False, bias=None):
         split = min(8, max(1, 512 // tiles), tokens // 2048)
     if w_is_in_out:
         ops.gemm_wgrad_(out, x2d, dy2d, split)
-        if want_b:
-            ops.colsum_(sink.buf(bias), dy2d)
     else:
-        ops.gemm_wgrad_(out, dy2d, x2d, split, db=sink.buf(bias) if want_b else None)
+        ops.gemm_wgrad_(out, dy2d, x2d, split)
 
 
 def _bgrad(sink, b, dy2d):
@@ -234,7 +228,8 @@ class _Linear(torch.autograd.Function):
             dy2 = dy2.contiguous()
         sink = GradSink()
         du = ops.act_bwd(dy2, aux, ctx.act) if ctx.act else dy2
-        _wgrad(sink, weight, du, x2, w_is_in_out=ctx.io, bias=bias)
+        _wgrad(sink, weight, du, x2, w_is_in_out=ctx.io)
+        _bgrad(sink, bias, du)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dgrad(du, weight, "io" if ctx.io else "oi").view(ctx.shp)
@@ -567,7 +562,9 @@ class _TransformerLayer(torch.autograd.Function):
             da = dgrad(du, P["w1"], residual=ds2)  # bert: a feeds the MLP and the residual
             dmid, h2 = ops.layernorm_bwd_renorm(da, mid, m2_, r2, f32(P["ln1_w"]), f32(P["ln1_b"]), dgw, dgb, dxsum=bo_sum)
             del da
-        _wgrad(sink, P["w1"], du, h2, bias=None if b1_fused else P["b1"])
+        _wgrad(sink, P["w1"], du, h2)
+        if not b1_fused:
+            _bgrad(sink, P["b1"], du)
         del h2
         del du
 
@@ -580,7 +577,9 @@ class _TransformerLayer(torch.autograd.Function):
             do, o_n = ops.layernorm_bwd_renorm(do, o2, mi, ri, f32(P["inner_w"]), f32(P["inner_b"]), dgw, dgb)
         else:
             o_n = o2
-        _wgrad(sink, P["wo"], dy_wo, o_n, bias=None if bo_fused else P["bo"])
+        _wgrad(sink, P["wo"], dy_wo, o_n)
+        if not bo_fused:
+            _bgrad(sink, P["bo"], dy_wo)
         del o_n
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
@@ -598,11 +597,13 @@ class _TransformerLayer(torch.autograd.Function):
         else:
             h = x2
         if spec.packed_qkv:
-            _wgrad(sink, P["wqkv"], dqkv2, h, bias=P["bqkv"])   # the q / k / v bias gradients ride on the wgrad (no column-sum pass over dqkv)
+            _wgrad(sink, P["wqkv"], dqkv2, h)
+            _bgrad(sink, P["bqkv"], dqkv2)
         else:
             for i, nm in enumerate("qkv"):
                 sl = dqkv2[:, i * d:(i + 1) * d]
-                _wgrad(sink, P["w" + nm], sl, h, bias=P["b" + nm])   # the bias gradient rides on the wgrad (no column-sum pass over dqkv)
+                _wgrad(sink, P["w" + nm], sl, h)
+                _bgrad(sink, P["b" + nm], sl)
         del h
         if ctx.needs_input_grad[0]:
             if not pre_ln:

@@ -321,13 +321,10 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
 _WGRAD_WS = {}
 
 
-def gemm_wgrad_(dW, dY, X, split_k_hint=1, db=None):
+def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     """dW[n_out, k_in] += dY[tokens, n_out]^T X[tokens, k_in]   (fp32 accumulate in place; bf16 token-major operands,
-    row-strided views allowed).  A per-device fp32 workspace for the token-split partial sums is kept and reused.
-    db: optional fp32 [n_out], += the column sums of dY (the bias gradient) -- inside the wgrad kernel where its shape allows, no pass over dY."""
-    _dev_ok(dW, dY, X, db); _f32(dW, "dW"); _f32(db, "db")
-    if db is not None and (db.dim() != 1 or db.shape[0] != dY.shape[1] or not db.is_contiguous()):
-        raise ValueError("gemm_wgrad_: db must be a contiguous fp32 [n_out] vector")
+    row-strided views allowed).  A per-device fp32 workspace for the token-split partial sums is kept and reused."""
+    _dev_ok(dW, dY, X); _f32(dW, "dW")
     for t, n in ((dY, "dY"), (X, "X")):
         if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
             raise ValueError(f"gemm_wgrad_: {n} must be a 2-D bf16 tensor with unit inner stride")
@@ -345,12 +342,8 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1, db=None):
     if GEMM_TRACE is not None and _lib.backend() == 1:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if db is None:
-        _rc(_lib.load().antmmf_gemm_wgrad_bf16(_p(dY), _p(X), _p(dW), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
-                                               int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
-    else:
-        _rc(_lib.load().antmmf_gemm_wgrad_bias_bf16(_p(dY), _p(X), _p(dW), _p(db), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
-                                                    int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bias_bf16")
+    _rc(_lib.load().antmmf_gemm_wgrad_bf16(_p(dY), _p(X), _p(dW), tokens, n_out, k_in, dY.stride(0), X.stride(0), dW.stride(0),
+                                           int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16")
     if ev is not None:
         ev[1].record()
         GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_out * k_in, "tn", (n_out, k_in, tokens, "wgrad")))

@@ -57,7 +57,6 @@ struct GemmArgs {
     const float* rowv;
     const float* colv;
     float* part;   // mode 1: [J / 64][I] float2 (column block major);  mode 3: [I / 128][J]
-    float* bias_grad;   // wgrad (gemm_tn_k64_kernel, J >= 1024): bias_grad[i] += sum_r P[r][i] (the column sums of dY) from the fragments the K loop holds anyway
 };
 
 
@@ -1755,14 +1754,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
     const bool late = wave >= 4;
     uint32_t so = 0;
     bool first = true;   // first K-tile: K-tile 1 is complete, the refills that target it are skipped
-    // Bias gradient (column sums of dY = the P operand) riding on the wgrad: a lane's dY fragment pb[f] holds 8 tokens of ONE output feature (n_out index l15), so
-    // their sum is eight fp32 adds into one register -- no pass over dY, no MFMA, one VGPR (an MFMA against a ones fragment was tried first: + 8 VGPRs tipped the
-    // 256-register kernel into spilling its accumulators).  A K-tile holds 16 (fragment it, 32-token half) units per row half wi; the 4 wj waves x tiles_j
-    // column-tile workgroups that see the same dY rows and tokens share them: worker u = 4 (tile % tiles_j) + wj takes unit u (it = u >> 1, half = u & 1), u < 16.
-    const int bu = (tile % tiles_j) * 4 + wj;
-    const bool bias_on = g.bias_grad != nullptr && bu < 16;
-    const int b_it = bu >> 1, b_ph = ((bu & 1) << 1) | (b_it >> 2), b_f = b_it & 3;
-    float bsum = 0.f;
     // WT: 0 steady, 1 = K-tile nk - 2, 2 = K-tile nk - 1
 #define TK_PIECES(PH, WT)                                                                                                           \
     do {                                                                                                                            \
@@ -1797,12 +1788,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
         _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                                               \
             _Pragma("unroll") for (int jt = 0; jt < TJ; ++jt)                                                                       \
                 acc[4 * (PH & 1) + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[f], acc[4 * (PH & 1) + f][jt], 0, 0, 0); \
-        if (bias_on && b_ph == PH) {                                                                                                \
-            union { bf16x8_t f; uint4 u; } cv_;                                                                                     \
-            cv_.f = b_f == 0 ? pb[0] : (b_f == 1 ? pb[1] : (b_f == 2 ? pb[2] : pb[3]));                                             \
-            bsum += ((bf_lo(cv_.u.x) + bf_hi(cv_.u.x)) + (bf_lo(cv_.u.y) + bf_hi(cv_.u.y))) +                                       \
-                    ((bf_lo(cv_.u.z) + bf_hi(cv_.u.z)) + (bf_lo(cv_.u.w) + bf_hi(cv_.u.w)));                                        \
-        }                                                                                                                           \
         if (PRIO) K64_SETPRIO(0);                                                                                                   \
         SCHED_FENCE();                                                                                                              \
         if (late) { TK_WAIT(PH, WT); K64_BARRIER(); }                                                                               \
@@ -1818,10 +1803,6 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
 #undef TK_WAIT
 #undef TK_PIECES
     wg_barrier_lds_only();  // every wave is past its last MFMA block and nothing is in flight: the stages are free
-    if (g.bias_grad != nullptr) {   // (wave-uniform; every lane takes part in the cross-row sum)
-        const float bt = rows4_sum(bsum);   // the four 8-token groups of the 32-token half
-        if (bias_on && grp == 0) atomicAdd(g.bias_grad + i0 + wi * (16 * TI) + b_it * 16 + l15, bt);
-    }
     if (g.ws) {
         store_partial_f32_staged<TI, TJ>(g.ws + (long)split * g.I * g.J + (long)i0 * g.J + j0, g.J, acc, wi, wj, lane, smem + wave * 16384);
         return;
@@ -1840,8 +1821,7 @@ extern "C" long antmmf_debug_gemm_k64_launches() { return g_k64_launches; }
 static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                      int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                      const void* residual, long ldr, void* aux, long ldaux, const void* gate, long ldgate,
-                     int accumulate, int split_k, float* workspace, long workspace_bytes, hipStream_t stream, float* bias_grad = nullptr, bool* bias_fused = nullptr) {
-    if (bias_fused) *bias_fused = false;
+                     int accumulate, int split_k, float* workspace, long workspace_bytes, hipStream_t stream) {
     if (!P || !Q || !C || I < 0 || J < 0 || R <= 0) return ANTMMF_EINVAL;
     if (I == 0 || J == 0) return ANTMMF_OK;
     if ((J & 3) || (ldc & 3)) return ANTMMF_EINVAL;
@@ -1863,7 +1843,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
-    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr; g.bias_grad = nullptr;
+    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
     act &= 0xff;
     // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
     // about what lands in aux); gate-holds-act' needs a gate
@@ -1992,7 +1972,6 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             g.ksteps_per_split = k64_steps;
             const bool ws64 = k64_zs > 1 && workspace && workspace_bytes >= (long)k64_zs * I * J * 4;
             g.ws = ws64 ? workspace : nullptr;
-            if (bias_grad && J >= 1024) { g.bias_grad = bias_grad; if (bias_fused) *bias_fused = true; }   // >= 4 column tiles share the 16 bias units of a K-tile
             static bool once64 = false;
             if (!once64) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_k64_kernel<K64F_PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once64 = true; }
             ++g_k64_launches;
@@ -2065,7 +2044,7 @@ static void gemm_ffn_args(GemmArgs& g, const void* P, const void* Q, void* C, in
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = 0; g.ldaux = 0; g.ldgate = 0;
     g.I = I; g.J = J; g.R = R; g.act = ANTMMF_ACT_NONE; g.c_dtype = ANTMMF_BF16; g.accumulate = 0; g.ksteps_per_split = (R + 63) / 64; g.alpha = 1.0f;
     g.ws = nullptr; g.raster = 1; g.aux_grad = 0; g.gate_grad = 0; g.debug_nostore = 0;
-    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr; g.bias_grad = nullptr;
+    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
 }
 static bool ffn_shape_ok(int I, int J, int R, long ldp, long ldq, long ldc) {
     return I > 0 && J > 0 && R > 0 && !(J & 7) && !(R & 7) && !(ldp & 7) && !(ldq & 7) && !(ldc & 7);
@@ -2306,19 +2285,6 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
 
 // dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in]  (fp32 accumulate), with a caller-owned fp32 workspace for the token-split
 // partial sums (the kernel picks the split; workspace_bytes >= 32 * n_out * k_in * 4 always suffices; NULL -> fp32 atomics).
-// The same with the bias gradient db[n_out] += column sums of dY.  On the BK = 64 wgrad kernel (k_in >= 1024) it rides on the GEMM: the dY fragments are in registers anyway, a wave adds
-// one of them up per 64-token K-tile (eight fp32 adds per lane), no pass over dY; other shapes take the column-sum kernel.
-extern "C" int antmmf_colsum(const void* x, float* out, long rows, int cols, long ld, int dtype, hipStream_t s);
-extern "C" int antmmf_gemm_wgrad_bias_bf16(const void* dY, const void* X, float* dW, float* db, long tokens, int n_out, int k_in, long ld_dy, long ld_x,
-                                           long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
-    if (tokens <= 0 || tokens > 0x7fffffffL || !db) return ANTMMF_EINVAL;
-    bool fused = false;
-    const int rc = gemm_impl(dY, X, dW, n_out, k_in, (int)tokens, ld_dy, ld_x, ld_dw, 1, 1, ANTMMF_F32, 1.0f, nullptr, ANTMMF_ACT_NONE, nullptr, 0, nullptr, 0,
-                             nullptr, 0, 1, split_k_hint, workspace, workspace_bytes, stream, db, &fused);
-    if (rc || fused) return rc;
-    return antmmf_colsum(dY, db, tokens, n_out, ld_dy, ANTMMF_BF16, stream);
-}
-
 extern "C" int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, long tokens, int n_out, int k_in, long ld_dy, long ld_x,
                                       long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
     if (tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;

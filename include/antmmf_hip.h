@@ -155,11 +155,6 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
 int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tokens, int n_out, int k_in, int64_t ld_dy,
                            int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes,
                            antmmf_stream_t stream);
-/* The same plus the bias gradient db[n_out] += column sums of dY (nn.Linear's bias.grad; reference sites as for antmmf_gemm_bf16).  On the BK = 64 wgrad
- * kernel (256-aligned outputs, >= 4096 tokens, k_in >= 1024) the sums ride on the GEMM -- the dY fragments are in registers anyway -- and no pass over dY is
- * made; other shapes run antmmf_colsum behind the GEMM. */
-int antmmf_gemm_wgrad_bias_bf16(const void* dY, const void* X, float* dW, float* db, int64_t tokens, int n_out, int k_in, int64_t ld_dy, int64_t ld_x,
-                                int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes, antmmf_stream_t stream);
 
 /* ---- fused multi-head attention, head_dim = 64, bf16, Nk <= 288 (whole key row in LDS):
  *   O[b,q,h,:] = softmax_k( scale * <Q[b,q,h,:], K[b,k,h,:]> + key_bias[b,k] ) V[b,k,h,:]

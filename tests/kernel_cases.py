@@ -428,23 +428,6 @@ def case_gemm_wgrad_ring(ops, dev, tokens=4096, n_out=256, k_in=256):
     assert float(big[:, k_in:].abs().max()) == 0.0
 
 
-def case_gemm_wgrad_bias(ops, dev, tokens=4096, n_out=256, k_in=1024, seed=57):
-    """dW += dY^T X and db += column sums of dY in one call: on the BK = 64 wgrad kernel (k_in >= 1024) the sums come out of the fragments the K loop holds
-    (every (fragment, 32-token half) unit exactly once across the column-tile workgroups and waves); smaller k_in takes the column-sum kernel behind the GEMM."""
-    dY = q(rnd((tokens, n_out), seed, 0.5) + 0.05)
-    Xa = q(rnd((tokens, k_in), seed + 1, 0.5))
-    dw = torch.full((n_out, k_in), 0.25, device=dev)
-    db = torch.full((n_out,), -1.5, device=dev)
-    ops.gemm_wgrad_(dw, dY.to(dev, BF), Xa.to(dev, BF), db=db)
-    check("gemm.wgrad_bias.dw", dw, dY.t() @ Xa + 0.25, 2e-3, 2e-3)
-    check("gemm.wgrad_bias.db", db, dY.sum(0) - 1.5, 1e-4, 1e-4)
-    dqkv = q(rnd((tokens, 3 * n_out), seed + 2, 0.5))                      # a column slice of a packed gradient (the separate q / k / v projections)
-    dw2, db2 = torch.zeros(n_out, k_in, device=dev), torch.zeros(n_out, device=dev)
-    ops.gemm_wgrad_(dw2, dqkv.to(dev, BF)[:, n_out:2 * n_out], Xa.to(dev, BF), db=db2)
-    check("gemm.wgrad_bias.slice.dw", dw2, dqkv[:, n_out:2 * n_out].t() @ Xa, 2e-3, 2e-3)
-    check("gemm.wgrad_bias.slice.db", db2, dqkv[:, n_out:2 * n_out].sum(0), 1e-4, 1e-4)
-
-
 # ------------------------------------------------------------------------------ attention
 def _attn_ref(qh, kh, vh, scale, key_bias):
     return oops.attention_core(qh, kh, vh, scale, key_bias)

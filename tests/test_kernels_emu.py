@@ -167,11 +167,6 @@ def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV)
 
 
-def test_gemm_wgrad_bias(ops):
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=4096, n_out=256, k_in=1024)   # inside the BK = 64 wgrad kernel (4 column tiles share the 16 units)
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=300, n_out=64, k_in=128)      # generic kernel + column-sum pass
-
-
 def test_attention_self(ops):
     kc.case_attention(ops, DEV, B=2, heads=2, Nq=17, Nk=17, bias_kind="none")
 

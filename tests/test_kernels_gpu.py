@@ -42,13 +42,6 @@ def test_act_layernorm(ops):
         kc.case_act_layernorm(ops, DEV, dtype, rows=77, cols=512, act="quick_gelu")
 
 
-def test_gemm_wgrad_bias(ops):
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=4096, n_out=256, k_in=1024)
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=8192 + 64, n_out=1024, k_in=4096, seed=77)   # 16 column tiles: only the first four carry bias units; a ragged last split
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=5120, n_out=768, k_in=768, seed=87)          # 3 column tiles: column-sum kernel
-    kc.case_gemm_wgrad_bias(ops, DEV, tokens=300, n_out=64, k_in=128)
-
-
 def test_ffn_fold(ops):
     """Sub-LN fold: element-wise epilogues + row / column passes (unaligned shapes), then ViT-L/14 widths where all three GEMMs run on the persistent
     kernel (>= 512 tiles each: fc1 / dgrad 128 x 16, fc2 128 x 4) with their per-tile partial sums."""
