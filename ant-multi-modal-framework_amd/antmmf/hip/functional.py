@@ -572,9 +572,14 @@ class _TransformerLayer(torch.autograd.Function):
         o2 = o.view(T, d)
         dy_wo = ops.dropout_add(dmid.contiguous(), p_hid, seed + 1) if p_hid > 0 else dmid
         do = dgrad(dy_wo, P["wo"])
+        bv_fused = False
         if spec.kind == "m2":
             dgw, dgb = lnw("inner")
-            do, o_n = ops.layernorm_bwd_renorm(do, o2, mi, ri, f32(P["inner_w"]), f32(P["inner_b"]), dgw, dgb)
+            # The value-projection bias gradient for free: softmax rows sum to one, so sum_k dV[k] = sum_q dO[q] per head -- the column sums of the gradient at
+            # the attention output, which the inner LayerNorm's backward can emit while it writes that tensor (no column-sum pass over dV).  Needs the separate
+            # v bias of this layer kind and no attention-probability dropout (dropped rows no longer sum to one).
+            bv_fused = (not spec.packed_qkv) and p_att == 0 and P["bv"] is not None and P["bv"].requires_grad
+            do, o_n = ops.layernorm_bwd_renorm(do, o2, mi, ri, f32(P["inner_w"]), f32(P["inner_b"]), dgw, dgb, dxsum=sink.buf(P["bv"]) if bv_fused else None)
         else:
             o_n = o2
         _wgrad(sink, P["wo"], dy_wo, o_n)
@@ -603,7 +608,8 @@ class _TransformerLayer(torch.autograd.Function):
             for i, nm in enumerate("qkv"):
                 sl = dqkv2[:, i * d:(i + 1) * d]
                 _wgrad(sink, P["w" + nm], sl, h)
-                _bgrad(sink, P["b" + nm], sl)
+                if not (nm == "v" and bv_fused):
+                    _bgrad(sink, P["b" + nm], sl)
         del h
         if ctx.needs_input_grad[0]:
             if not pre_ln:
