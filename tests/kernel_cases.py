@@ -255,6 +255,15 @@ def case_movers(ops, dev):
     ref = torch.zeros(12, d)
     ref[2:7] = dx.sum(0)
     check("embed_scatter.pos", dpos, ref, 1e-5, 1e-5)
+    # the batched position path (>= 64 sequences: a thread walks a slice of the batch per (position, vector), one atomic per slice), with skipped rows
+    nb, sq = 70, 6
+    dxb = q(rnd((nb, sq, 16), 38))
+    skipb = (torch.arange(nb * sq) % 5 == 3).to(torch.uint8).view(nb, sq)
+    dposb = torch.full((10, 16), 0.5, device=dev)
+    ops.embed_scatter_add_(dposb, dxb.to(dev, BF), None, skipb.to(dev), seq=sq, offset=3)
+    refb = torch.full((10, 16), 0.5)
+    refb[3:3 + sq] += (dxb * (1 - skipb.float())[..., None]).sum(0)
+    check("embed_scatter.pos.batched", dposb, refb, 1e-5, 1e-5)
 
 
 def case_adamw(ops, dev):
