@@ -103,7 +103,9 @@ __device__ __forceinline__ void store_rm(char* lds, const uint4 (&v)[4]) {
     }
 }
 
-template <int TI, int TJ>
+// FFN: the sub-LN fold's element-wise forms are compiled in (only the generic NT kernel asks for them: inside the wgrad kernel, which shares this function, the extra
+// branch cost its register allocation -- 238 VGPRs / no scratch became 234 / 528 B of spills and the kernel ran 17 % slower)
+template <int TI, int TJ, bool FFN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[TI][TJ], int i0, int j0, int wi, int wj, int l15, int grp, bool splitk) {
     // epilogue: lane holds out[i = .. + l15][j = .. + 4*grp + 0..3] for each (it, jt); wave tile = (16 TI) x (16 TJ)
 #pragma unroll
@@ -115,7 +117,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             const int j = j0 + wj * (16 * TJ) + jt * 16 + grp * 4;
             if (j >= g.J) continue;  // J % 4 == 0 is required, so a 4-group is all-in or all-out
             float v[4] = {acc[it][jt][0] * g.alpha, acc[it][jt][1] * g.alpha, acc[it][jt][2] * g.alpha, acc[it][jt][3] * g.alpha};
-            if (g.ffn_mode) {   // sub-LN fold, element-wise form (the statistics / column sums of these shapes come from their own small passes)
+            if (FFN && g.ffn_mode) {   // sub-LN fold, element-wise form (the statistics / column sums of these shapes come from their own small passes)
                 bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long)i * g.ldc + j;
                 if (g.ffn_mode == 1) {
                     const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         cur ^= 1;
     }
 
-    gemm_epilogue<4, 4>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
+    gemm_epilogue<4, 4, !PT && !QT>(g, acc, i0, j0, wi, wj, l15, grp, gridDim.z > 1);
 }
 
 // ---- LDS-DMA variant for the all-r-contiguous layout (forward; dgrad against a pre-transposed weight) ----
