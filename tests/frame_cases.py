@@ -70,7 +70,7 @@ def case_dark_clip_keeps_reference_semantics(dev):
     return "ok"
 
 
-def case_collate(dev):
+def case_collate(dev, n_clips=2, num_frm=2):
     """A ragged batch of videos -> padded image_data + image_pad_mask, random_scale drawn in the reference's order."""
     import antmmf.datasets.processors  # noqa: F401
     from antmmf.datasets.processors import Processor
@@ -80,9 +80,9 @@ def case_collate(dev):
         {"type": "ImageLongsideScaleAndPad", "params": {"max_size": 288, "random_scale": True, "pad": False}},
         {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}}
     proc = Processor(cfg)
-    vids = [_frames(4, h, w, 40 + i) for i, (h, w) in enumerate(((36, 64), (64, 36), (48, 48)))]
+    vids = [_frames(n_clips * num_frm, h, w, 40 + i) for i, (h, w) in enumerate(((36, 64), (64, 36), (48, 48)))]
     random.seed(21)
-    data, mask = collate_video_frames([v.to(dev) for v in vids], proc.processor, n_clips=2, num_frm=2)
+    data, mask = collate_video_frames([v.to(dev) for v in vids], proc.processor, n_clips=n_clips, num_frm=num_frm)
     random.seed(21)
     want_d, want_m = oframes.collate([oframes.frame_processor(v, 288, MEAN, STD, random_scale=True) for v in vids])
     _close(data, want_d, "collate data")
