@@ -127,7 +127,7 @@ def main():
 
 def main_glm():
     """The M2 tokenizer call of prj/M2_Encoder/m2_encoder.py:39-45 through the reference's GLMChineseTokenizer (loaded from its file, with the
-    reference's sp.model; both copied to tests/golden/m2_tokenizer/ as data fixtures)."""
+    reference's sp.model, which stays where it is: the test reads it from the reference checkout and skips without it)."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("ref_tokenization_glm", f"{REF}/prj/M2_Encoder/vlmo/tokenizer/tokenization_glm.py")
