@@ -1,0 +1,24 @@
+#!/bin/bash
+TAG=${1:-r3k}
+mkdir -p gpurun_out
+python - <<'PY'
+import os, sys, subprocess, torch
+sys.path.insert(0, "ant-multi-modal-framework_amd")
+code = r"""
+import sys, torch
+sys.path.insert(0, "ant-multi-modal-framework_amd")
+from antmmf.hip import ops
+torch.manual_seed(0)
+qkv = torch.randn(8, 257, 3 * 1024, device="cuda").to(torch.bfloat16)
+q, k, v = qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:]
+o, lse = ops.attention_fwd(q, k, v, 16, 0.125)
+torch.save((o.cpu(), lse.cpu()), sys.argv[1])
+"""
+outs = []
+for v in ("0", "2"):
+    env = dict(os.environ, ANTMMF_ATTN_VARIANT=v)
+    subprocess.check_call([sys.executable, "-c", code, f"/tmp/attn_{v}.pt"], env=env)
+    outs.append(torch.load(f"/tmp/attn_{v}.pt"))
+print("max |o2 - o0|", float((outs[0][0].float() - outs[1][0].float()).abs().max()), "max |lse diff|", float((outs[0][1] - outs[1][1]).abs().max()))
+PY
+for v in 0 2 28 24 0 28 24; do echo "--- ANTMMF_ATTN_VARIANT=$v"; ANTMMF_ATTN_VARIANT=$v timeout 300 python tools/attn_bench.py v$v 10 2>&1 | grep "fwd.N257" | cut -c1-200; done | tee gpurun_out/${TAG}_attn_pair.txt
