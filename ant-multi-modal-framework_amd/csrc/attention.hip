@@ -47,7 +47,9 @@
 #endif
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
-#define ATTN_THREADS 384  // 6 waves: 18 key / 17 query tiles of the 257-token image tower split 3-3-3-3-3-3
+#define ATTN_THREADS 512  // 8 waves: the 16 full query / key tiles of the 257-token image tower in two even rounds (the 17th tile holds the one remaining token and costs
+                          // one wave a third round); two workgroups = 16 waves per CU, every kernel <= 128 VGPRs.  Round 3, same-box A/B against 6 waves (18 / 17 tiles
+                          // split 3-3-3-3-3-3, 12 waves per CU): forward 0.80 -> 0.73 ms, backward 2.30 -> 2.16 ms, 77-token tower unchanged (profiles/r3_attn_waves_ab.txt)
 
 struct AttnArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const float* key_bias;
