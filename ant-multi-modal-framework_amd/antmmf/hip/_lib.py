@@ -38,6 +38,7 @@ _SIGNATURES = {
     "antmmf_split_tokens": [P, P, L, I, I, P],
     "antmmf_embed_gather": [P, P, P, P, P, P, P, L, I, I, I, P],
     "antmmf_embed_scatter_add": [P, P, P, P, L, I, I, I, P],
+    "antmmf_embed_scatter_add_sorted": [P, P, P, P, L, L, I, P],
     "antmmf_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, F, P],
     "antmmf_adamw_step_scaled": [P, P, P, P, P, L, F, F, F, F, F, I, F, P, P],
     "antmmf_sumsq": [P, P, L, P],

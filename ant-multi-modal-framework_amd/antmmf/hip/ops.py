@@ -239,10 +239,22 @@ def embed_gather(ids, word, pos=None, type_table=None, type_ids=None, zero_rows=
     return out
 
 
+SCATTER_SORT_MIN_ROWS = 8192   # below this the element-wise atomic kernel is cheaper than a device sort
+
+
 def embed_scatter_add_(dtable, dx, idx=None, skip_rows=None, seq=1, offset=0):
     _dev_ok(dtable, dx, idx, skip_rows); _c(dx, "dx"); _f32(dtable, "dtable")
     d = dx.shape[-1]
     rows = dx.numel() // d
+    if idx is not None and rows >= SCATTER_SORT_MIN_ROWS and dtable.is_contiguous():
+        # table rows with one writer each instead of one fp32 atomic per element: sort the ids (torch's device radix sort: plumbing), then one wave per run
+        keys = idx.reshape(-1)
+        if skip_rows is not None:
+            keys = torch.where(skip_rows.reshape(-1) != 0, torch.full_like(keys, dtable.shape[0]), keys)
+        sorted_idx, src_row = torch.sort(keys, stable=True)   # stable: the rows of a run are summed in batch order -- deterministic, unlike the atomics
+        _rc(_lib.load().antmmf_embed_scatter_add_sorted(_p(dx), _p(sorted_idx), _p(src_row), _p(dtable), rows, dtable.shape[0], d, _stream()),
+            "antmmf_embed_scatter_add_sorted")
+        return dtable
     _rc(_lib.load().antmmf_embed_scatter_add(_p(dx), _p(idx), _p(skip_rows), _p(dtable), rows, seq, d, offset, _stream()),
         "antmmf_embed_scatter_add")
     return dtable

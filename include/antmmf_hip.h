@@ -117,6 +117,10 @@ int antmmf_embed_gather(const int64_t* ids, const float* word, const float* pos,
 /* ---- dtable[idx ? idx[r] : offset + r % seq] += dx[r]  (fp32 atomics; rows flagged in skip_rows are skipped). */
 int antmmf_embed_scatter_add(const void* dx, const int64_t* idx, const unsigned char* skip_rows, float* dtable,
                              int64_t rows, int seq, int d, int offset, antmmf_stream_t stream);
+/* The word-table gradient without atomics: sorted_idx = the token ids in ascending order (rows to skip carry an id >= n_table), src_row = the row of dx each entry came
+ * from (the sort's permutation).  One wave per run of equal ids sums the run and adds it to its table row: a single writer per row. */
+int antmmf_embed_scatter_add_sorted(const void* dx, const int64_t* sorted_idx, const int64_t* src_row, float* dtable, int64_t rows, int64_t n_table, int d,
+                                    antmmf_stream_t stream);
 
 /* ---- fused AdamW over a flat fp32 arena segment (torch.optim.AdamW semantics, decoupled decay);
  * g is multiplied by grad_scale first; `shadow` (bf16 compute copy, nullable) is rewritten. */

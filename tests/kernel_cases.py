@@ -264,6 +264,15 @@ def case_movers(ops, dev):
     refb = torch.full((10, 16), 0.5)
     refb[3:3 + sq] += (dxb * (1 - skipb.float())[..., None]).sum(0)
     check("embed_scatter.pos.batched", dposb, refb, 1e-5, 1e-5)
+    # the sorted word-table path (>= 8192 rows: one writer per table row, no atomics), repeated ids, skipped rows, untouched rows
+    nbw, sqw, V = 1100, 8, 37
+    idsw = torch.randint(0, V - 3, (nbw, sqw), generator=torch.Generator().manual_seed(3))
+    dxw = q(rnd((nbw, sqw, 16), 39))
+    skipw = (torch.arange(nbw * sqw) % 7 == 2).to(torch.uint8).view(nbw, sqw)
+    dw2 = torch.full((V, 16), -0.25, device=dev)
+    ops.embed_scatter_add_(dw2, dxw.to(dev, BF), idsw.to(dev), skipw.to(dev))
+    refw = torch.full((V, 16), -0.25).index_add_(0, idsw.flatten(), (dxw * (1 - skipw.float())[..., None]).reshape(-1, 16))
+    check("embed_scatter.sorted", dw2, refw, 1e-5, 1e-5)
 
 
 def case_adamw(ops, dev):
