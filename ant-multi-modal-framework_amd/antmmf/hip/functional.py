@@ -149,9 +149,12 @@ def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
     out = sink.buf(W)
     tiles = ((out.shape[0] + 127) // 128) * ((out.shape[1] + 127) // 128)
     tokens = dy2d.shape[0]
+    # token split for the kernels that take the hint (the small / unaligned shapes; the BK = 64 wgrad kernel sizes its own): enough workgroups to cover the chip even
+    # when the weight is a handful of 128 x 128 tiles -- a [32, 16] predictor weight over 98304 pair-tokens ran as ONE workgroup x 8 splits for 2.1 ms per call
+    # (6.3 ms of the dmae12 step), the 768-wide text tower at 3840 tokens as 36 workgroups without any split
     split = 1
-    if tiles < 256 and tokens >= 4096:
-        split = min(8, max(1, 512 // tiles), tokens // 2048)
+    if tiles < 256 and tokens >= 1024:
+        split = min(64, max(1, 512 // tiles), max(1, tokens // 512))
     if w_is_in_out:
         ops.gemm_wgrad_(out, x2d, dy2d, split)
     else:
