@@ -135,8 +135,16 @@ def matmul_f32(A, B, a_rmajor=False, b_rmajor=False):
     ah, al = _split(A)
     bh, bl = _split(B)
     out = torch.zeros(Ip, Jp, dtype=torch.float32, device=A.device)
+    # a long reduction into a handful of output tiles (the weight gradient of a small Linear over ~1e5 rows: the TPM-CL predictors) is split over the rows -- as ONE
+    # workgroup per GEMM it took 2.1 ms x 3 (6.3 ms of the dmae12 step)
+    split = 1
+    if a_rmajor and b_rmajor:
+        R = A.shape[0]
+        tiles = ((Ip + 127) // 128) * ((Jp + 127) // 128)
+        if tiles < 64 and R >= 4096:
+            split = min(64, max(1, 256 // tiles), R // 1024)
     for x, y in ((ah, bh), (ah, bl), (al, bh)):
-        ops.gemm(x, y, out=out, p_rmajor=a_rmajor, q_rmajor=b_rmajor, accumulate=True)
+        ops.gemm(x, y, out=out, p_rmajor=a_rmajor, q_rmajor=b_rmajor, accumulate=True, split_k=split)
     return out[:I, :J] if (Ip != I or Jp != J) else out
 
 

@@ -153,8 +153,10 @@ def _wgrad(sink, W, dy2d, x2d, w_is_in_out=False):
     # when the weight is a handful of 128 x 128 tiles -- a [32, 16] predictor weight over 98304 pair-tokens ran as ONE workgroup x 8 splits for 2.1 ms per call
     # (6.3 ms of the dmae12 step), the 768-wide text tower at 3840 tokens as 36 workgroups without any split
     split = 1
-    if tiles < 256 and tokens >= 1024:
-        split = min(64, max(1, 512 // tiles), max(1, tokens // 512))
+    if tiles < 256 and tokens >= 4096:
+        split = min(64, max(1, 512 // tiles), tokens // 2048)
+    elif tiles <= 64 and tokens >= 1024:     # (measured: with more tiles the atomic accumulation of the splits costs more than the idle CUs, 768 x 3072 at 3840 tokens 1.09 -> 1.40 ms)
+        split = min(8, max(1, 256 // tiles), tokens // 512)
     if w_is_in_out:
         ops.gemm_wgrad_(out, x2d, dy2d, split)
     else:
