@@ -676,7 +676,8 @@ class _PatchEmbed(torch.autograd.Function):
         dtok = ops.split_tokens(dx)
         if weight.requires_grad:
             dwp = torch.zeros(d, kpad, dtype=torch.float32, device=dx.device)
-            ops.gemm(dtok, patches, out=dwp, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=4)
+            # (kpad = 640 for 14 x 14 patches is not a multiple of 256: the 128 x 128-tile kernel, 40 tiles -- split over the tokens to cover the chip)
+            ops.gemm(dtok, patches, out=dwp, p_rmajor=True, q_rmajor=True, accumulate=True, split_k=min(16, max(4, dtok.shape[0] // 16384)))
             sink.buf(weight).add_(dwp[:, :kk].reshape(weight.shape))
         _bgrad(sink, bias, dtok)
         if cls.requires_grad:

@@ -1,7 +1,7 @@
 #!/bin/bash
 TAG=${1:-r3p}
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 900 -x -k "movers or gemm" 2>&1 | tail -3
+python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout 900 -x -k "movers or gemm or tpmcl or token_weight or pair" 2>&1 | tail -3
 for wl in dmae12 vtp8; do
   timeout 600 python bench.py --workload $wl --no-cpu-baseline --gemm-table gpurun_out/${TAG}_gemm_table_$wl.txt > gpurun_out/${TAG}_bench_$wl.json 2> gpurun_out/${TAG}_bench_$wl.err; tail -1 gpurun_out/${TAG}_bench_$wl.err; cut -c1-330 gpurun_out/${TAG}_bench_$wl.json
 done
