@@ -361,7 +361,12 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
     if (nvec <= 64) LN_FWD(1, false, gw);
     else if (nvec <= 128) LN_FWD(2, false, gw);
     else if (nvec <= 256) LN_FWD(1, true, gb);
-    else if (nvec <= 512) LN_FWD(2, true, gb);
+    else if (nvec <= 512) {
+        // 4096-wide bf16 rows (the M2 feed-forward's gelu -> ffn_layernorm): a WAVE per row with the whole row in its registers (8 vectors per lane; 204 VGPRs, two waves per
+        // SIMD) beats the workgroup-per-row form with its two block reductions and barriers: 1.02 -> 0.97 ms on 263168 rows, 0.312 -> 0.283 ms on 78848 (round 3, same box,
+        // insensitive to an occupancy limiter); fp32 rows would need > 256 VGPRs and keep the workgroup form
+        if (sizeof(T) == 2 && nvec > 256) LN_FWD(8, false, gw); else LN_FWD(2, true, gb);
+    }
     else return ANTMMF_EINVAL;
 #undef LN_FWD
 #undef LN_FWD_A
