@@ -117,6 +117,7 @@ def test_hf_bert_checkpoint_on_fused_bert_emulated(emu, tmp_path):
     print(_case(emu, str(tmp_path)))
 
 
+@pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="set ANTMMF_SLOW_TESTS=1 (an emulated model step: ~1.5 min; the same case runs under -m gpu)")
 def test_univl_arch_model_emulated(emu):
     print(_case_univl_arch(emu, "stage1"))
 

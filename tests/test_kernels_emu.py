@@ -164,7 +164,7 @@ def test_gemm_k64_persistent(variant):
 
 
 def test_gemm_wgrad_ring(ops):
-    kc.case_gemm_wgrad_ring(ops, DEV)
+    kc.case_gemm_wgrad_ring(ops, DEV, quick=not os.environ.get("ANTMMF_SLOW_TESTS"))
 
 
 def test_attention_self(ops):
