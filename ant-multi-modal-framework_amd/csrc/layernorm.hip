@@ -373,6 +373,23 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
     return antmmf_check_launch();
 }
 
+// A persistent grid should be exactly what is RESIDENT: the workgroup-per-row backward launched 1024 workgroups, but at 168 VGPRs (the fused-GELU variant) only three
+// 256-thread workgroups fit a CU -- 768 resident, the last 256 ran as a second, one-third-full round (round 3: 1.446 -> 1.339 ms on 263168 x 4096, 0.468 -> 0.439 ms on
+// 78848 rows with a 768-workgroup grid; 512 and 1536 are both slower).  Asked from the runtime per kernel variant (they differ in registers), capped by `cap`.
+template <typename K>
+static int ln_resident_grid(K kern, size_t lds, int cap) {
+#ifdef ANTMMF_EMULATE
+    (void)kern; (void)lds;
+    return cap;
+#else
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu <= 0) return cap;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return cap;
+    const long g = (long)per_cu * cus;
+    return (int)(g < cap ? g : cap);
+#endif
+}
+
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
                          const void* dres, void* dx, float* dgamma, float* dbeta, float* dxsum, long rows, int cols, int act,
@@ -387,10 +404,17 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
     // for the 4096-wide GELU backward -- the column-sum closing phase is per workgroup)
     const int gw = (int)(want < 512 ? want : 512);
     const int gb = (int)(rows < 1024 ? rows : 1024);
+    int gb_used = gb;   // the grid the workgroup-per-row kernel was launched with (<= gb: what is resident), = the number of partial rows it wrote
     if (!(wide && partials && partial_elems >= (long)gb * ns * cols)) partials = nullptr;
     const size_t lds = (size_t)(ns + (yout ? 1 : 0)) * cols * sizeof(float);
     const size_t ldsb = (size_t)(1 + (yout ? 1 : 0)) * cols * sizeof(float);
-#define LN_BWD_Y(V, BLK, GRID, LDS, A, D, Y) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D, Y>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials, beta, (T*)yout)
+#define LN_BWD_Y(V, BLK, GRID, LDS, A, D, Y) \
+    do { \
+        int grid_ = GRID; \
+        if (BLK) { static int res_ = 0; if (!res_) res_ = ln_resident_grid(ln_bwd_kernel<T, V, BLK, A, D, Y>, LDS, 1024); grid_ = grid_ < res_ ? grid_ : res_; gb_used = grid_; } \
+        LN_BWD_Z(V, BLK, grid_, LDS, A, D, Y); \
+    } while (0)
+#define LN_BWD_Z(V, BLK, GRID, LDS, A, D, Y) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D, Y>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials, beta, (T*)yout)
 #define LN_BWD_D(V, BLK, GRID, LDS, A, D) do { if (yout && A == ANTMMF_ACT_NONE) LN_BWD_Y(V, BLK, GRID, LDS, ANTMMF_ACT_NONE, D, true); else LN_BWD_Y(V, BLK, GRID, LDS, A, D, false); } while (0)
 #define LN_BWD_A(V, BLK, GRID, LDS, A) do { if (dxsum) LN_BWD_D(V, BLK, GRID, LDS, A, true); else LN_BWD_D(V, BLK, GRID, LDS, A, false); } while (0)
 #define LN_BWD(V, BLK, GRID, LDS) do { if (act == ANTMMF_ACT_NONE) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_NONE); else if (act == ANTMMF_ACT_GELU_ERF) LN_BWD_A(V, BLK, GRID, LDS, ANTMMF_ACT_GELU_ERF); else LN_BWD_A(V, BLK, GRID, LDS, -1); } while (0)
@@ -403,8 +427,9 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
 #undef LN_BWD_A
 #undef LN_BWD_D
 #undef LN_BWD_Y
+#undef LN_BWD_Z
     if (partials && (dgamma || dbeta || dxsum))
-        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((ns * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb, cols, ns, dgamma, dbeta, dxsum);
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((ns * cols + 255) / 256, 8), dim3(256), 0, s, partials, gb_used, cols, ns, dgamma, dbeta, dxsum);
     return antmmf_check_launch();
 }
 
