@@ -109,6 +109,84 @@ def _reduce_scatter_packed(fulls, group):
     return outs
 
 
+def _all_reduce_sum(t, group):
+    w, _ = _world(group)
+    if not _single(w):
+        dist.all_reduce(t, group=group)
+    return t
+
+
+_DEFAULT_MAX_ROWS = None
+
+
+def set_max_rows_per_rank(n):
+    """Per-rank batch size of the run (BaseTrainer sets it from `training_parameters.batch_size` when `training_parameters.pad_ragged_batches` is on):
+    the sharded losses then accept FEWER rows on any rank (the last, partial batch of an epoch) -- see _Rows.  None restores the equal-batch contract."""
+    global _DEFAULT_MAX_ROWS
+    _DEFAULT_MAX_ROWS = None if n is None else int(n)
+
+
+class _Rows:
+    """Where this rank's rows sit in the gathered batch.
+
+    Equal batches (max_rows None, the default: what a DistributedSampler hands out, also for a short last batch): row0 = rank * B, every gathered
+    row is real, Bg = W * B; a one-element all-gather + device-side assert guards the assumption.
+    Ragged batches (max_rows given: the per-rank batch size of the configuration): the reference pads every gathered tensor to the largest rank and trims
+    afterwards, with a size exchange + host sync per call (antmmf/utils/distributed_utils.py:131-160).  Here every rank pads its embeddings with zero rows to
+    the STATIC max_rows, gathers [W * max_rows, ...], and gathers the W row counts once (device tensor, no host sync): padded columns of a similarity slab
+    get -inf (they drop out of every log-sum-exp and receive zero gradient), padded local rows get coefficient 0, the mean divides by the true global
+    count.  Shapes never depend on another rank's batch."""
+
+    def __init__(self, B, device, group, max_rows=None):
+        self.world, self.rank = _world(group)
+        self.B, self.group = B, group
+        if max_rows is None:
+            max_rows = _DEFAULT_MAX_ROWS
+        self.ragged = max_rows is not None and not _single(self.world)
+        if not self.ragged:
+            self.Bp, self.row0 = B, self.rank * B
+            self.Bg = self.world * B      # python int
+            return
+        if B > max_rows:
+            raise ValueError(f"{B} rows on rank {self.rank} exceed max_rows = {max_rows}")
+        self.Bp, self.row0 = int(max_rows), self.rank * int(max_rows)
+        mine = torch.full((1,), B, dtype=torch.int64, device=device)
+        counts = torch.empty(self.world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        self.counts = counts
+        self.Bg = counts.sum().to(torch.float32)                        # device scalar: the true global batch
+        ar = torch.arange(self.Bp, device=device)
+        valid_cols = (ar[None, :] < counts[:, None]).reshape(-1)        # [W * Bp]
+        self.col_bias = torch.zeros(self.world * self.Bp, dtype=torch.float32, device=device).masked_fill_(~valid_cols, float("-inf"))
+        self.row_valid = ar < B                                         # [Bp]
+
+    def pad(self, t):
+        """[B, ...] -> [Bp, ...] (zero rows)"""
+        if not self.ragged or t.shape[0] == self.Bp:
+            return t
+        return torch.cat([t, t.new_zeros((self.Bp - t.shape[0],) + tuple(t.shape[1:]))], 0)
+
+    def mask_cols(self, slab, per=1):
+        """-inf into the columns of padded rows of other ranks (per = columns per gathered row: the clips of a video)"""
+        if not self.ragged:
+            return slab
+        bias = self.col_bias if per == 1 else self.col_bias.repeat_interleave(per)
+        return (slab + bias[None, :]).contiguous()
+
+    def mask_rows(self, rows):
+        """loss terms of padded local rows (their target column is a padded one: +inf) -> 0"""
+        return torch.where(self.row_valid, rows, torch.zeros_like(rows)) if self.ragged else rows
+
+    def coef(self, scale):
+        """per-row backward coefficient scale / Bg (0 on padded rows)"""
+        if not self.ragged:
+            return None
+        return torch.where(self.row_valid, scale / self.Bg, torch.zeros((), device=self.Bg.device)).float().contiguous()
+
+    def unpad(self, g):
+        return g[:self.B] if self.ragged and g.shape[0] != self.B else g
+
+
 def _split(x):
     hi = x.to(BF)
     lo = (x - hi.float()).to(BF)
@@ -150,90 +228,102 @@ def matmul_f32(A, B, a_rmajor=False, b_rmajor=False):
 
 class _MilNceSharded(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, text, clips, n_clips, weight, group):
-        world, rank = _world(group)
+    def forward(ctx, text, clips, n_clips, weight, group, max_rows):
         B, D = text.shape
-        text, clips = text.float().contiguous(), clips.float().contiguous()
-        T_all, V_all = _all_gather_packed([text, clips.view(B, n_clips * D)], group)   # one message: [B, (1 + n) D]
+        rows = _Rows(B, text.device, group, max_rows)
+        text, clips = rows.pad(text.float()).contiguous(), rows.pad(clips.float().view(B, n_clips * D)).contiguous()
+        Bp = rows.Bp
+        T_all, V_all = _all_gather_packed([text, clips], group)   # one message: [Bp, (1 + n) D]
         V_all = V_all.view(-1, D)
-        Bg = T_all.shape[0]
-        centre = clips.view(B, n_clips, D)[:, n_clips // 2].contiguous()
-        Rm = matmul_f32(text, V_all).contiguous()      # [B, Bg*n]   <text_i, clip_c>
-        Cm = matmul_f32(centre, T_all).contiguous()    # [B, Bg]     <centre clip of video_i, text_t>
-        row0 = rank * B
-        loss_rows, denom = ops.milnce_fwd(Rm, Cm, n_clips, row0)
-        coef = torch.full((B,), 1.0 / Bg, dtype=torch.float32, device=text.device)
+        centre = clips.view(Bp, n_clips, D)[:, n_clips // 2].contiguous()
+        Rm = rows.mask_cols(matmul_f32(text, V_all).contiguous(), n_clips)      # [Bp, W Bp n]   <text_i, clip_c>
+        Cm = rows.mask_cols(matmul_f32(centre, T_all).contiguous())             # [Bp, W Bp]     <centre clip of video_i, text_t>
+        loss_rows, denom = ops.milnce_fwd(Rm, Cm, n_clips, rows.row0)
+        if rows.ragged:
+            coef = rows.coef(torch.ones((), device=text.device))
+            loss_rows = rows.mask_rows(loss_rows)
+        else:
+            coef = torch.full((B,), 1.0 / rows.Bg, dtype=torch.float32, device=text.device)
         if weight is not None:
-            coef = coef * weight.float()
-        loss = (loss_rows * coef).sum()
-        if not _single(world):
-            dist.all_reduce(loss, group=group)
+            coef = coef * rows.pad(weight.float())
+        loss = _all_reduce_sum((loss_rows * coef).sum(), group)
         ctx.save_for_backward(text, centre, T_all, V_all, Rm, Cm, denom, coef)
-        ctx.meta = (n_clips, row0, world, group, B, D)
+        ctx.meta = (n_clips, rows, D)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
         text, centre, T_all, V_all, Rm, Cm, denom, coef = ctx.saved_tensors
-        n, row0, world, group, B, D = ctx.meta
-        dR, dC = ops.milnce_bwd(Rm, Cm, denom, (coef * gout * world).contiguous(), n, row0, out_dtype=torch.float32)
+        n, rows, D = ctx.meta
+        row0, Bp = rows.row0, rows.Bp
+        dR, dC = ops.milnce_bwd(Rm, Cm, denom, (coef * gout * rows.world).contiguous(), n, row0, out_dtype=torch.float32)
         dT_all = matmul_f32(dC, centre, a_rmajor=True, b_rmajor=True)   # [Bg, D]   dC^T centre
         dV_all = matmul_f32(dR, text, a_rmajor=True, b_rmajor=True)     # [Bg*n, D] dR^T text
-        dT_all[row0:row0 + B] += matmul_f32(dR, V_all, b_rmajor=True)   # dR V_all
+        dT_all[row0:row0 + Bp] += matmul_f32(dR, V_all, b_rmajor=True)  # dR V_all
         dVc = matmul_f32(dC, T_all, b_rmajor=True)                      # dC T_all -> centre clips of the local videos
-        dV_all.view(-1, n, D)[row0:row0 + B, n // 2] += dVc
-        dT, dV = _reduce_scatter_packed([dT_all, dV_all.view(-1, n * D)], group)
-        return dT, dV.view(-1, D), None, None, None
+        dV_all.view(-1, n, D)[row0:row0 + Bp, n // 2] += dVc
+        dT, dV = _reduce_scatter_packed([dT_all, dV_all.view(-1, n * D)], rows.group)
+        return rows.unpad(dT), rows.unpad(dV).reshape(-1, D), None, None, None, None
 
 
-def mil_nce_sharded(text_embed, clip_embed, n_clips=1, weight=None, group=None):
+def mil_nce_sharded(text_embed, clip_embed, n_clips=1, weight=None, group=None, max_rows=None):
     """MIL-NCE over the global batch (get_mil_nce_loss, univl_video_ret.py:146-197), rows sharded over ranks.
-    text_embed [B, D], clip_embed [B*n_clips, D]: this rank's L2-normalised embeddings."""
-    return _MilNceSharded.apply(text_embed, clip_embed, n_clips, weight, group)
+    text_embed [B, D], clip_embed [B*n_clips, D]: this rank's L2-normalised embeddings.  max_rows: see _Rows (ragged per-rank batches)."""
+    return _MilNceSharded.apply(text_embed, clip_embed, n_clips, weight, group, max_rows)
+
+
+def _itc_term_fwd(im, tx, I_all, T_all, lsp, rows):
+    """one symmetric InfoNCE term on this rank's rows: (local loss sum, tensors for backward)"""
+    ls = lsp.detach().float().reshape(1).contiguous()
+    xi = rows.mask_cols(matmul_f32(im, T_all).contiguous())   # image rows vs all texts
+    xt = rows.mask_cols(matmul_f32(tx, I_all).contiguous())   # text rows vs all images
+    li, lse_i = ops.softmax_ce_fwd(xi, rows.row0, ls)
+    lt, lse_t = ops.softmax_ce_fwd(xt, rows.row0, ls)
+    total = rows.mask_rows(li).sum() + rows.mask_rows(lt).sum()
+    return total * (0.5 / rows.Bg), [im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls]
+
+
+def _itc_term_bwd(saved, gout, rows):
+    im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls = saved
+    row0, Bp = rows.row0, rows.Bp
+    if rows.ragged:
+        coef = rows.coef(gout * rows.world * 0.5)
+    else:
+        coef = (gout * rows.world * 0.5 / rows.Bg).reshape(1).expand(Bp).contiguous().float()
+    dscale = torch.zeros(1, dtype=torch.float32, device=im.device)
+    dxi = ops.softmax_ce_bwd(xi, lse_i, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
+    dxt = ops.softmax_ce_bwd(xt, lse_t, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
+    dI_all = matmul_f32(dxt, tx, a_rmajor=True, b_rmajor=True)
+    dT_all = matmul_f32(dxi, im, a_rmajor=True, b_rmajor=True)
+    dI_all[row0:row0 + Bp] += matmul_f32(dxi, T_all, b_rmajor=True)
+    dT_all[row0:row0 + Bp] += matmul_f32(dxt, I_all, b_rmajor=True)
+    return dI_all, dT_all, (dscale * ls.exp()).reshape(())  # d/d log_scale = d/d s * s
 
 
 class _ClipItcSharded(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, txt, log_scale, group):
-        world, rank = _world(group)
-        B, D = img.shape
-        img, txt = img.float().contiguous(), txt.float().contiguous()
+    def forward(ctx, img, txt, log_scale, group, max_rows):
+        rows = _Rows(img.shape[0], img.device, group, max_rows)
+        img, txt = rows.pad(img.float()).contiguous(), rows.pad(txt.float()).contiguous()
         I_all, T_all = _all_gather_packed([img, txt], group)
-        Bg = I_all.shape[0]
-        row0 = rank * B
-        ls = log_scale.detach().float().reshape(1).contiguous()
-        xi = matmul_f32(img, T_all).contiguous()   # image rows vs all texts
-        xt = matmul_f32(txt, I_all).contiguous()   # text rows vs all images
-        li, lse_i = ops.softmax_ce_fwd(xi, row0, ls)
-        lt, lse_t = ops.softmax_ce_fwd(xt, row0, ls)
-        loss = (li.sum() + lt.sum()) * (0.5 / Bg)
-        if not _single(world):
-            dist.all_reduce(loss, group=group)
-        ctx.save_for_backward(img, txt, I_all, T_all, xi, xt, lse_i, lse_t, ls)
-        ctx.meta = (row0, world, group, B, Bg)
+        loss, saved = _itc_term_fwd(img, txt, I_all, T_all, log_scale, rows)
+        loss = _all_reduce_sum(loss, group)
+        ctx.save_for_backward(*saved)
+        ctx.rows = rows
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        img, txt, I_all, T_all, xi, xt, lse_i, lse_t, ls = ctx.saved_tensors
-        row0, world, group, B, Bg = ctx.meta
-        coef = (gout * world * 0.5 / Bg).reshape(1).expand(B).contiguous().float()
-        dscale = torch.zeros(1, dtype=torch.float32, device=img.device)
-        dxi = ops.softmax_ce_bwd(xi, lse_i, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
-        dxt = ops.softmax_ce_bwd(xt, lse_t, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
-        dI_all = matmul_f32(dxt, txt, a_rmajor=True, b_rmajor=True)
-        dT_all = matmul_f32(dxi, img, a_rmajor=True, b_rmajor=True)
-        dI_all[row0:row0 + B] += matmul_f32(dxi, T_all, b_rmajor=True)
-        dT_all[row0:row0 + B] += matmul_f32(dxt, I_all, b_rmajor=True)
-        dls = (dscale * ls.exp()).reshape(())  # d/d log_scale = d/d s * s
-        dI, dT = _reduce_scatter_packed([dI_all, dT_all], group)
-        return dI, dT, dls, None
+        rows = ctx.rows
+        dI_all, dT_all, dls = _itc_term_bwd(ctx.saved_tensors, gout, rows)
+        dI, dT = _reduce_scatter_packed([dI_all, dT_all], rows.group)
+        return rows.unpad(dI), rows.unpad(dT), dls, None, None
 
 
-def clip_itc_sharded(img_embed, txt_embed, log_scale, group=None):
+def clip_itc_sharded(img_embed, txt_embed, log_scale, group=None, max_rows=None):
     """Symmetric InfoNCE over logits = exp(log_scale) * img @ txt^T (prj/M2_Encoder/m2_encoder.py:92-95;
-    antmmf/modules/vision/backbone/clip/model.py:442-444), rows sharded over ranks."""
-    return _ClipItcSharded.apply(img_embed, txt_embed, log_scale, group)
+    antmmf/modules/vision/backbone/clip/model.py:442-444), rows sharded over ranks.  max_rows: see _Rows (ragged per-rank batches)."""
+    return _ClipItcSharded.apply(img_embed, txt_embed, log_scale, group, max_rows)
 
 
 class _ClipItcPairSharded(torch.autograd.Function):
@@ -242,53 +332,37 @@ class _ClipItcPairSharded(torch.autograd.Function):
     the four embedding gradients in a single reduce-scatter.  Arithmetic per term is _ClipItcSharded's."""
 
     @staticmethod
-    def forward(ctx, img1, txt1, ls1, img2, txt2, ls2, group):
-        world, rank = _world(group)
-        B = img1.shape[0]
-        locs = [t.float().contiguous() for t in (img1, txt1, img2, txt2)]
+    def forward(ctx, img1, txt1, ls1, img2, txt2, ls2, group, max_rows):
+        rows = _Rows(img1.shape[0], img1.device, group, max_rows)
+        locs = [rows.pad(t.float()).contiguous() for t in (img1, txt1, img2, txt2)]
         alls = _all_gather_packed(locs, group)
-        Bg, row0 = alls[0].shape[0], rank * B
         saved, losses = [], []
         for (im, tx, I_all, T_all, lsp) in ((locs[0], locs[1], alls[0], alls[1], ls1), (locs[2], locs[3], alls[2], alls[3], ls2)):
-            ls = lsp.detach().float().reshape(1).contiguous()
-            xi = matmul_f32(im, T_all).contiguous()
-            xt = matmul_f32(tx, I_all).contiguous()
-            li, lse_i = ops.softmax_ce_fwd(xi, row0, ls)
-            lt, lse_t = ops.softmax_ce_fwd(xt, row0, ls)
-            losses.append((li.sum() + lt.sum()) * (0.5 / Bg))
-            saved += [im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls]
-        loss = torch.stack(losses)
-        if not _single(world):
-            dist.all_reduce(loss, group=group)
+            l, sv = _itc_term_fwd(im, tx, I_all, T_all, lsp, rows)
+            losses.append(l)
+            saved += sv
+        loss = _all_reduce_sum(torch.stack(losses), group)
         ctx.save_for_backward(*saved)
-        ctx.meta = (row0, world, group, B, Bg)
+        ctx.rows = rows
         return loss[0], loss[1]
 
     @staticmethod
     def backward(ctx, g1, g2):
-        row0, world, group, B, Bg = ctx.meta
+        rows = ctx.rows
         sv = ctx.saved_tensors
         grads, dlss = [], []
         for k, gout in enumerate((g1, g2)):
-            im, tx, I_all, T_all, xi, xt, lse_i, lse_t, ls = sv[9 * k:9 * k + 9]
-            coef = (gout * world * 0.5 / Bg).reshape(1).expand(B).contiguous().float()
-            dscale = torch.zeros(1, dtype=torch.float32, device=im.device)
-            dxi = ops.softmax_ce_bwd(xi, lse_i, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
-            dxt = ops.softmax_ce_bwd(xt, lse_t, coef, row0, ls, dscale=dscale, out_dtype=torch.float32)
-            dI_all = matmul_f32(dxt, tx, a_rmajor=True, b_rmajor=True)
-            dT_all = matmul_f32(dxi, im, a_rmajor=True, b_rmajor=True)
-            dI_all[row0:row0 + B] += matmul_f32(dxi, T_all, b_rmajor=True)
-            dT_all[row0:row0 + B] += matmul_f32(dxt, I_all, b_rmajor=True)
+            dI_all, dT_all, dls = _itc_term_bwd(sv[9 * k:9 * k + 9], gout, rows)
             grads += [dI_all, dT_all]
-            dlss.append((dscale * ls.exp()).reshape(()))
-        dI1, dT1, dI2, dT2 = _reduce_scatter_packed(grads, group)
-        return dI1, dT1, dlss[0], dI2, dT2, dlss[1], None
+            dlss.append(dls)
+        dI1, dT1, dI2, dT2 = [rows.unpad(g) for g in _reduce_scatter_packed(grads, rows.group)]
+        return dI1, dT1, dlss[0], dI2, dT2, dlss[1], None, None
 
 
-def clip_itc_pair_sharded(img1, txt1, log_scale1, img2, txt2, log_scale2, group=None):
+def clip_itc_pair_sharded(img1, txt1, log_scale1, img2, txt2, log_scale2, group=None, max_rows=None):
     """(loss of pair 1, loss of pair 2) -- two clip_itc_sharded terms with packed collectives (one all-gather, one loss all-reduce,
-    one reduce-scatter for both)."""
-    return _ClipItcPairSharded.apply(img1, txt1, log_scale1, img2, txt2, log_scale2, group)
+    one reduce-scatter for both).  max_rows: see _Rows (ragged per-rank batches)."""
+    return _ClipItcPairSharded.apply(img1, txt1, log_scale1, img2, txt2, log_scale2, group, max_rows)
 
 
 # ------------------------------------------------------------------------------ MoCo (queue negatives)

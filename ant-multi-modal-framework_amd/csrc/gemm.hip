@@ -1501,6 +1501,306 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 #undef K64P_DMA11
 }
 
+// ---- gemm_nt_k64r_kernel: the K loop of gemm_nt_k64p_kernel (one barrier per 16-MFMA phase) with a ROLLING epilogue -------------------------
+// What the persistent kernel above leaves on the table (profiles/r2_gemm_store_ablation.txt, r3_gemm_residual_epilogue_ablation.txt): all 256
+// workgroups reach their epilogues together, none of a CU's eight waves issues MFMAs while its 128-KB tile is converted / stored (6-12 % of
+// the R = 1024 shapes) or while the residual tile is fetched (out-projection: 19 %).  Here no epilogue phase exists:
+//   * phase ph of a K-tile multiplies the wave's rows [32 ph, +32), so after phase q of the LAST K-tile of an output tile the accumulators of
+//     row quarter q are final: quarter q is converted (lane swap -> 8 consecutive columns per lane) and stored inside the LOAD interval of
+//     phase q + 1, next to the partner wave's MFMA block; quarter 3 goes out in phase 0 of the NEXT tile's first K-tile;
+//   * bias and residual are what the accumulators START from instead of what is added to the result: as soon as quarter q has been stored its
+//     32 accumulator registers are dead, and the residual vectors of the NEXT tile's quarter q (four 16-B loads per lane, coalesced 64-B row
+//     segments; inline asm, so hipcc neither waits for them nor drains the DMA ring) are requested into that hole.  Three phases (> 1 us) later,
+//     in phase q of the next tile's first K-tile, they are unpacked to fp32, taken back to the fragment layout (the lane swap is its own
+//     inverse), the bias fragment (DMAed into a 256-B LDS strip per wave during the previous tile) is added and the MFMAs accumulate on top:
+//     out = (bias + residual) + sum_r P Q in fp32 -- the same real number as "product first", rounded to bf16 once.  Without a residual the
+//     first MFMA of every accumulator takes the bias fragment (or an inline zero) as its C operand: no initialisation pass at all;
+//   * vmcnt ladders: one in-order counter covers DMA pieces, residual loads and stores; every wait allows exactly the operations younger than
+//     the one it needs (tools/k64r_ladder.py replays the issue order and prints the tables below; smaller is safe, larger is a race);
+//   * the prologue loads K-tile 0 and the Q half of K-tile 1 (what the steady-state refill schedule does not bring itself), so the first
+//     K-tile issues the same operations as every other; the last tile's look-ahead refills wrap to its own first K-tiles (harmless re-reads,
+//     drained before the kernel ends) instead of the two special wait ladders of the kernel above.
+// Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual.
+#ifdef ANTMMF_EMULATE
+#define K64R_GLOAD16(dst, voff, sbase, OFF) dst = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sbase) + (voff) + (OFF))
+#define K64R_GSTORE16(voff, val, sbase, OFF) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(sbase) + (voff) + (OFF)) = (val)
+#define K64R_GSTORE16_NT K64R_GSTORE16
+#define K64R_VMFENCE4(N, a) do {} while (0)
+#define K64R_VMWAIT(N) do {} while (0)
+#define K64R_LREAD16(dst, addr, OFF) dst = *reinterpret_cast<const f32x4_t*>(smem + (addr) + (OFF))
+#define K64R_OPAQUE(x) do {} while (0)
+#define K64R_KEEP(x) do {} while (0)
+#else
+#define K64R_KEEP(x) asm volatile("" :: "v"(x))
+#define K64R_GLOAD16(dst, voff, sbase, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF))
+// (plain stores: inside the K loop the acknowledgement latency of a store is on the critical path -- the DMA pieces issued behind it retire behind it -- and a
+// write-back store is acknowledged by the L2; measured against nt / sc0 / sc0 nt / sc1 / sc1 nt / sc0 sc1 in profiles/r4_gemm_rolling_epilogue_ab.txt)
+#define K64R_GSTORE16(voff, val, sbase, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(val), "s"(sbase), "n"(OFF) : "memory")
+#define K64R_GSTORE16_NT(voff, val, sbase, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" :: "v"(voff), "v"(val), "s"(sbase), "n"(OFF) : "memory")
+#define K64R_VMFENCE4(N, a) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory")
+#define K64R_VMWAIT(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
+#define K64R_LREAD16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds0 + (addr)), "n"(OFF))
+#define K64R_OPAQUE(x) asm volatile("" : "+s"(x))
+#endif
+// tools/k64r_ladder.py: end-of-phase waits W[role][phase] (roles T0 = first K-tile of an output tile, TR = steady, TE = last), the waits INIT[q] in
+// front of the accumulator initialisation of row quarter q, BIASW in front of the bias strip read of a bias-only kernel
+template <int EPI> struct K64RWaits;
+template <> struct K64RWaits<0> { static constexpr int W[3][4] = {{24, 25, 26, 7}, {8, 9, 10, 7}, {8, 13, 18, 19}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 0; };
+template <> struct K64RWaits<1> { static constexpr int W[3][4] = {{25, 25, 26, 7}, {8, 9, 10, 7}, {9, 14, 19, 20}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 24; };
+template <> struct K64RWaits<2> { static constexpr int W[3][4] = {{40, 41, 42, 11}, {8, 9, 10, 7}, {8, 17, 26, 31}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 0; };
+template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
+
+// ABL (ablations, variant bits 15 / 16): 1 = the converted rows are not stored (timing only: the ladders count the stores), 4 = non-temporal stores
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int ntiles) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
+    constexpr int STAGE = 65536, QOFF = 32768, BIASOFF = 2 * STAGE;
+    constexpr bool BIAS = EPI & 1, RES = EPI & 2;
+    using WT = K64RWaits<EPI>;
+    const int lane = threadIdx.x & 63;
+#ifdef ANTMMF_EMULATE
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lds0 = 0;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#endif
+    (void)lds0;
+    const int wi = wave / NWJ, wj = wave % NWJ;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int tiles_j = g.J / BN, tiles_i = g.I / BM;
+    const int nk = g.R >> 6;
+    const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int qd = ntiles >> 3, rm = ntiles & 7;
+    const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
+    auto tile_origin = [&](int local, int& i0, int& j0) {
+        const int wgid = xbase + local;
+        const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+        const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+        i0 = (band * 4 + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
+    };
+    int local = lx;
+    if (local >= xcount) return;
+
+    // fragment read bases; the Q fragment row of lane l15 is l15 with bits 2 and 3 exchanged (lane-swap store layout, see gemm_nt_k64p_kernel)
+    const int pl15 = (l15 & 3) | (((l15 >> 3) & 1) << 2) | (((l15 >> 2) & 1) << 3);
+    uint32_t pbase[4], qbase[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        pbase[x] = (uint32_t)(l15 * 128 + (((grp ^ lds_swz(l15)) ^ (2 * x)) << 4) + wi * 128 * 128);
+        qbase[x] = (uint32_t)(pl15 * 128 + (((grp ^ lds_swz(pl15)) ^ (2 * x)) << 4) + QOFF + wj * 64 * 128);
+    }
+    const int pl = lane >> 3, pslot = lane & 7;
+    const int prow0 = (wave >> 2) * 128 + (wave & 3) * 8, qrow0 = (wave >> 1) * 64 + (wave & 1) * 8;
+    const long ldpb = g.ldp * 2, ldqb = g.ldq * 2;
+    uint32_t pv[2], qv[4];
+    {
+        const uint32_t ps0 = (uint32_t)((pslot ^ lds_swz(prow0 + pl)) << 4), qs0 = (uint32_t)((pslot ^ lds_swz(qrow0 + pl)) << 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) pv[b] = (uint32_t)(pl * (int)ldpb) + (ps0 ^ (uint32_t)(b << 6));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) qv[b] = (uint32_t)(pl * (int)ldqb) + (qs0 ^ (uint32_t)(b << 5));
+    }
+    const char* pgc; const char* qgc; const char* pgn = nullptr; const char* qgn = nullptr;
+    auto tile_bases = [&](int i0, int j0, const char*& pgx, const char*& qgx) {
+        pgx = reinterpret_cast<const char*>(g.P) + (long)(i0 + prow0) * ldpb;
+        qgx = reinterpret_cast<const char*>(g.Q) + (long)(j0 + qrow0) * ldqb;
+    };
+    auto dma_p = [&](const char* base, int pq, int kk, uint32_t stage_off) {
+        glds16(base + (long)pq * 32 * ldpb + (long)kk * 128 + pv[pq & 1], smem + stage_off + (prow0 + 32 * pq) * 128);
+    };
+    auto dma_q = [&](const char* base, int pq, int kk, uint32_t stage_off) {
+        glds16(base + (long)pq * 16 * ldqb + (long)kk * 128 + qv[pq], smem + stage_off + QOFF + (qrow0 + 16 * pq) * 128);
+    };
+    auto dma_bias = [&](int tj0) {   // this wave's 64 bias values -> its LDS strip (4 B per lane)
+#ifdef ANTMMF_EMULATE
+        reinterpret_cast<float*>(smem + BIASOFF + wave * 256)[lane] = g.bias[tj0 + wj * 64 + lane];
+#else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + tj0 + wj * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(smem + BIASOFF + wave * 256), 4, 0, 0);
+#endif
+    };
+    // per-lane byte offsets of the row-layout accesses (row l15 of a 16-row fragment, 8 consecutive columns at (lane >> 5) * 16 + (grp & 1) * 8; + 64 B for the second column pair)
+    const uint32_t cvoff = (uint32_t)((l15 * (int)g.ldc + (lane >> 5) * 16 + (grp & 1) * 8) * 2);
+    const uint32_t rvoff = RES ? (uint32_t)((l15 * (int)g.ldr + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
+    const int pbg = ((grp & 1) << 1) | (grp >> 1);
+    u32x4_t rv[4][4] = {};   // residual vectors of row quarter q, in flight between the store of the previous tile's quarter q and this tile's phase q
+    f32x4_t bf[4] = {};      // bias fragment of the current tile (live across its first K-tile only)
+    // request the residual of row quarter QQ of the tile at (ti0, tj0)
+#define K64R_RESLOAD(QQ, ti0, tj0)                                                                                                  \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
+            const char* rb = reinterpret_cast<const char*>(g.residual) + ((long)((ti0) + wi * 128 + (2 * (QQ) + ih) * 16) * g.ldr + (tj0) + wj * 64) * 2; \
+            K64R_GLOAD16(rv[QQ][2 * ih], rvoff, rb, 0);                                                                             \
+            K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff, rb, 64);                                                                        \
+        }                                                                                                                           \
+    } while (0)
+
+    int i0, j0;
+    tile_origin(local, i0, j0);
+    tile_bases(i0, j0, pgc, qgc);
+    // prologue: K-tile 0 and the Q half of K-tile 1 (12 pieces per wave), the first tile's bias strip and residual quarters 0 - 2; drained once
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, 0, 0); dma_q(qgc, pq, 0, 0); dma_q(qgc, pq, 1, STAGE); }
+    if (BIAS) dma_bias(j0);
+    if (RES) { K64R_RESLOAD(0, i0, j0); K64R_RESLOAD(1, i0, j0); K64R_RESLOAD(2, i0, j0); }
+    if (RES) { K64R_VMFENCE4(0, rv[0]); K64R_VMFENCE4(0, rv[1]); K64R_VMFENCE4(0, rv[2]); }
+    glds_wait_all();
+    wg_barrier_lds_only();
+
+    bf16x8_t qa[8], pb[4];
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool late = wave >= 4;
+    uint32_t so = 0;
+    bool pending = false;    // quarter 3 of the previous tile still sits in the accumulators
+    int ei0 = 0, ej0 = 0;    // that tile's origin
+    int ni0 = 0, nj0 = 0;    // the next tile's
+    int t = 0;
+
+    // convert + store row quarter QQ of the tile at (ti0, tj0): rows it 16 + l15, it in {2 QQ, 2 QQ + 1}
+#define K64R_EPIQ(QQ, ti0, tj0)                                                                                                     \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
+            const int it = 2 * (QQ) + ih;                                                                                           \
+            char* cb = reinterpret_cast<char*>(g.C) + ((long)((ti0) + wi * 128 + it * 16) * g.ldc + (tj0) + wj * 64) * 2;           \
+            _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
+                u32x4_t ov;                                                                                                         \
+                _Pragma("unroll") for (int rr = 0; rr < 4; rr += 2) {                                                               \
+                    const k64_u2_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][2 * p2][rr]), __float_as_uint(acc[it][2 * p2 + 1][rr]), false, false); \
+                    const k64_u2_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][2 * p2][rr + 1]), __float_as_uint(acc[it][2 * p2 + 1][rr + 1]), false, false); \
+                    ov[rr >> 1] = pack_bf2(__uint_as_float(s0[0]), __uint_as_float(s1[0]));                                         \
+                    ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                                   \
+                }                                                                                                                   \
+                if (ABL & 1) K64R_KEEP(ov);                                                                                         \
+                else if (ABL & 4) { if (p2 == 0) K64R_GSTORE16_NT(cvoff, ov, cb, 0); else K64R_GSTORE16_NT(cvoff, ov, cb, 64); }         \
+                else if (p2 == 0) K64R_GSTORE16(cvoff, ov, cb, 0); else K64R_GSTORE16(cvoff, ov, cb, 64);                           \
+                SCHED_FENCE();                                                                                                      \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    } while (0)
+    // accumulators of row quarter QQ <- residual (row layout -> fragment layout: the lane swap is its own inverse) + bias fragment
+#define K64R_INIT(QQ)                                                                                                               \
+    do {                                                                                                                            \
+        K64R_VMFENCE4(WT::INIT[QQ], rv[QQ]);                                                                                        \
+        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih)                                                                            \
+            _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
+                const u32x4_t w = rv[QQ][2 * ih + p2];                                                                              \
+                _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                                  \
+                    const uint32_t lo = w[rr >> 1], hi = w[2 + (rr >> 1)];                                                          \
+                    const float flo = (rr & 1) ? bf_hi(lo) : bf_lo(lo), fhi = (rr & 1) ? bf_hi(hi) : bf_lo(hi);                     \
+                    const k64_u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(flo), __float_as_uint(fhi), false, false); \
+                    acc[2 * (QQ) + ih][2 * p2][rr] = __uint_as_float(sw[0]) + (BIAS ? bf[2 * p2][rr] : 0.f);                        \
+                    acc[2 * (QQ) + ih][2 * p2 + 1][rr] = __uint_as_float(sw[1]) + (BIAS ? bf[2 * p2 + 1][rr] : 0.f);                \
+                }                                                                                                                   \
+                SCHED_FENCE();                                                                                                      \
+            }                                                                                                                       \
+    } while (0)
+#define K64R_PIECE(IDX)                                                                                                             \
+    do {                                                                                                                            \
+        int kk = t + (IDX < 4 ? 1 : 2);                                                                                             \
+        const bool nx = kk >= nk;                                                                                                   \
+        if (nx) kk -= nk;                                                                                                           \
+        const char* pbs = nx ? pgn : pgc;                                                                                           \
+        const char* qbs = nx ? qgn : qgc;                                                                                           \
+        const uint32_t st = IDX < 4 ? (so ^ STAGE) : so;                                                                            \
+        if (IDX < 4) dma_p(pbs, IDX, kk, st); else dma_q(qbs, IDX - 4, kk, st);                                                     \
+    } while (0)
+#define K64R_READS(PH)                                                                                                              \
+    do {                                                                                                                            \
+        if (PH == 0) {                                                                                                              \
+            K64_READ(qa[0], so + qbase[0], 0);    K64_READ(qa[1], so + qbase[2], 0);                                                \
+            K64_READ(qa[2], so + qbase[1], 2048); K64_READ(qa[3], so + qbase[3], 2048);                                             \
+            K64_READ(qa[4], so + qbase[2], 4096); K64_READ(qa[5], so + qbase[0], 4096);                                             \
+            K64_READ(qa[6], so + qbase[3], 6144); K64_READ(qa[7], so + qbase[1], 6144);                                             \
+        }                                                                                                                           \
+        K64_READ(pb[0], so + pbase[((PH & 1) * 2 + 0)], PH * 4096);                                                                 \
+        K64_READ(pb[1], so + pbase[((PH & 1) * 2 + 0) ^ 2], PH * 4096);                                                             \
+        K64_READ(pb[2], so + pbase[((PH & 1) * 2 + 1)], PH * 4096 + 2048);                                                          \
+        K64_READ(pb[3], so + pbase[((PH & 1) * 2 + 1) ^ 2], PH * 4096 + 2048);                                                      \
+    } while (0)
+    // CMODE: what the first MFMA of an accumulator starts from: 0 = the accumulator (steady state, or initialised by K64R_INIT), 1 = the bias fragment, 2 = zero
+#define K64R_MFMA(MPH, CMODE)                                                                                                       \
+    do {                                                                                                                            \
+        if (MPH == 0) K64_FENCE8(qa);                                                                                               \
+        K64_FENCE4(pb);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+        K64_SETPRIO(1);                                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                            \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                           \
+                _Pragma("unroll") for (int jt = 0; jt < 4; ++jt)                                                                    \
+                    acc[2 * MPH + f][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[2 * jt + ks], pb[2 * f + ks],                 \
+                        ((CMODE) == 0 || ks == 1) ? acc[2 * MPH + f][jt] : ((CMODE) == 1 ? bf[jt] : (f32x4_t){0.f, 0.f, 0.f, 0.f}), 0, 0, 0); \
+        K64_SETPRIO(0);                                                                                                             \
+        SCHED_FENCE();                                                                                                              \
+    } while (0)
+    // ROLE: 0 = first K-tile of the output tile, 1 = steady, 2 = last K-tile
+#define K64R_HOOK(ROLE, PH)                                                                                                         \
+    do {                                                                                                                            \
+        if (ROLE == 0 && PH == 0) {                                                                                                 \
+            if (pending) K64R_EPIQ(3, ei0, ej0);                                                                                    \
+            if (RES) K64R_RESLOAD(3, i0, j0);                                                                                       \
+            if (BIAS) {                                                                                                             \
+                if (!RES) K64R_VMWAIT(WT::BIASW);   /* with a residual the wait in front of K64R_INIT(0) is the stronger one */      \
+                else K64R_VMFENCE4(WT::INIT[0], rv[0]);                                                                             \
+                K64R_LREAD16(bf[0], BIASOFF + wave * 256 + pbg * 16, 0);   K64R_LREAD16(bf[1], BIASOFF + wave * 256 + pbg * 16, 64);  \
+                K64R_LREAD16(bf[2], BIASOFF + wave * 256 + pbg * 16, 128); K64R_LREAD16(bf[3], BIASOFF + wave * 256 + pbg * 16, 192); \
+                K64_FENCE4(bf);                                                                                                     \
+            }                                                                                                                       \
+        }                                                                                                                           \
+        if (ROLE == 0 && RES) K64R_INIT(PH);                                                                                        \
+        if (ROLE == 2 && PH == 0 && BIAS) dma_bias(nj0);                                                                            \
+        if (ROLE == 2 && PH >= 1) { K64R_EPIQ(PH - 1, i0, j0); if (RES) K64R_RESLOAD(PH - 1, ni0, nj0); }             \
+    } while (0)
+#define K64R_PHASE(ROLE, PH)                                                                                                        \
+    do {                                                                                                                            \
+        K64R_READS(PH);                                                                                                             \
+        K64R_PIECE(2 * PH);                                                                                                         \
+        K64R_PIECE(2 * PH + 1);                                                                                                     \
+        SCHED_FENCE();                                                                                                              \
+        K64R_HOOK(ROLE, PH);                                                                                                        \
+        SCHED_FENCE();                                                                                                              \
+        if (!late) { glds_wait_le<WT::W[ROLE][PH]>(); K64_BARRIER(); }                                                              \
+        K64R_MFMA(PH, ((ROLE != 0 || RES) ? 0 : (BIAS ? 1 : 2)));                                                                  \
+        if (late) { glds_wait_le<WT::W[ROLE][PH]>(); K64_BARRIER(); }                                                               \
+    } while (0)
+#define K64R_TILE(ROLE) do { K64R_PHASE(ROLE, 0); K64R_PHASE(ROLE, 1); K64R_PHASE(ROLE, 2); K64R_PHASE(ROLE, 3); so ^= STAGE; } while (0)
+
+    for (;;) {
+        const bool more = local + per_xcd < xcount;
+        if (more) { tile_origin(local + per_xcd, ni0, nj0); tile_bases(ni0, nj0, pgn, qgn); }
+        else { ni0 = i0; nj0 = j0; pgn = pgc; qgn = qgc; }   // the look-ahead of the last tile re-reads the tile's own operands (never consumed)
+        // (t stays a run-time value: with literal K-tile numbers hipcc precomputes a 64-bit DMA address vector per (role, piece) and spills them)
+        t = 0; K64R_OPAQUE(t); K64R_TILE(0);
+        for (++t; t < nk - 1; ++t) K64R_TILE(1);
+        K64R_OPAQUE(t);
+        K64R_TILE(2);
+        pending = true; ei0 = i0; ej0 = j0;
+        if (!more) break;
+        local += per_xcd;
+        i0 = ni0; j0 = nj0; pgc = pgn; qgc = qgn;
+    }
+    // the wrapped look-ahead of the last tile must land before its targets are reused: the residual vectors' registers (the fences keep them allocated
+    // up to here) and, for the DMA pieces, this LDS
+    if (RES) { K64R_VMFENCE4(0, rv[0]); K64R_VMFENCE4(0, rv[1]); K64R_VMFENCE4(0, rv[2]); }
+    glds_wait_all();
+    SCHED_FENCE();
+    K64R_EPIQ(3, ei0, ej0);
+#undef K64R_TILE
+#undef K64R_PHASE
+#undef K64R_HOOK
+#undef K64R_MFMA
+#undef K64R_READS
+#undef K64R_PIECE
+#undef K64R_INIT
+#undef K64R_EPIQ
+#undef K64R_RESLOAD
+}
+
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
 // instruction writes whole 256-B row segments (fp32 atomics straight from the fragment layout measured ~90 G adds / s:
 // 0.37 ms for the 33 M adds of one fc1 wgrad, as long as its whole K loop).
@@ -1905,9 +2205,25 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             ++g_k64_launches;                                                                                                     \
             const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);  /* the tile walk needs a multiple of 8 workgroups (XCD = id % 8) */ \
             const unsigned gridp = (g_gemm_variant & 64) ? t8 : (pwgs < t8 ? pwgs : t8);                                          \
-            /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
             constexpr int PROD = K64F_ONEBAR | ((E & 2) && E != 4 ? K64F_DIST11 : 0);                                             \
-            if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);                                                     \
+            /* the rolling-epilogue kernel (bias / residual start the accumulators, stores inside the K loop; plain write-back stores).  Same-process A/B    \
+               against the burst epilogue (profiles/r4_gemm_rolling_epilogue_ab.txt): + 1 ... + 3 % on every shape of the step except the small plain one  \
+               (R = J = 1024, no operands: - 2.7 %), which stays on the kernel above.  Variant bit 13 forces it for every R >= 192, bit 14 disables it;     \
+               bits 15 / 17: ablations (no stores / non-temporal stores) */                                                                                \
+            if (E < 4 && !(g_gemm_variant & 16384) && R >= 192 && ((g_gemm_variant & 8192) || E != 0 || R > 1024 || J > 1024)) {  \
+                static bool oncer = false;                                                                                        \
+                if (!oncer) {                                                                                                     \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    oncer = true;                                                                                                 \
+                }                                                                                                                 \
+                if (g_gemm_variant & 32768) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+            }                                                                                                                     \
+            /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
+            else if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);                                                \
             else if (g_gemm_variant & 128) K64P_LAUNCH(E, PROD);                                                                  \
             else if (g_gemm_variant & 256) K64P_LAUNCH(E, PROD | K64F_PRIO | K64F_CLK);                                           \
             else K64P_LAUNCH(E, PROD | K64F_PRIO);                                                                                \

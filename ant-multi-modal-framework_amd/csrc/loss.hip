@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
     float ds = 0.f;
     for (int c = threadIdx.x; c < W; c += 256) {
         const float xv = x[(long)i * W + c];
+        if (xv == -INFINITY) { st1<TO>(dx + (long)i * W + c, 0.f); continue; }   // masked column (padding rows of a ragged global batch): no probability, no gradient
         const float p = __expf(sc * xv - l) - (c == gi ? 1.f : 0.f);
         st1<TO>(dx + (long)i * W + c, k * sc * p);
         ds += p * xv;

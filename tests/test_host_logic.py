@@ -251,6 +251,83 @@ def test_sharded_losses_two_ranks_match_oracle():
     torch.testing.assert_close(out[0]["dls"] + out[1]["dls"], world * ls.grad, rtol=1e-3, atol=1e-6)
 
 
+def _ragged_loss_case(rank, world):
+    """Row-sharded MIL-NCE / ITC on 2 ranks with UNEQUAL batches (3 and 2 pairs; max_rows = 3): pad + mask instead of the equal-batch assert."""
+    os.environ["ANTMMF_HIP_LIB"] = os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")
+    import weightgen as W
+    from antmmf.hip import _lib, contrastive
+
+    _lib.reset_for_tests()
+    counts, n, D = [3, 2], 2, 16
+    lo = sum(counts[:rank])
+    B = counts[rank]
+    Bg = sum(counts)
+    T = torch.nn.functional.normalize(W.data_tensor("ragged.t", (Bg, D)), dim=-1)
+    V = torch.nn.functional.normalize(W.data_tensor("ragged.v", (Bg * n, D)), dim=-1)
+    wgt = W.data_tensor("ragged.w", (Bg,)).abs() + 0.5
+    t = T[lo:lo + B].clone().requires_grad_(True)
+    v = V[lo * n:(lo + B) * n].clone().requires_grad_(True)
+    loss = contrastive.mil_nce_sharded(t, v, n_clips=n, weight=wgt[lo:lo + B], max_rows=3)
+    loss.backward()
+    ls1, ls2 = torch.tensor(2.0, requires_grad=True), torch.tensor(1.5, requires_grad=True)
+    i1 = T[lo:lo + B].clone().requires_grad_(True)
+    t1 = V[::n][lo:lo + B].clone().requires_grad_(True)
+    i2 = V[1::n][lo:lo + B].clone().requires_grad_(True)
+    t2 = T[lo:lo + B].clone().requires_grad_(True)
+    contrastive.set_max_rows_per_rank(3)       # the trainer's way of switching the ragged path on
+    try:
+        l1, l2 = contrastive.clip_itc_pair_sharded(i1, t1, ls1, i2, t2, ls2)
+    finally:
+        contrastive.set_max_rows_per_rank(None)
+    (l1 + 2.0 * l2).backward()
+    return dict(loss=loss.detach(), dt=t.grad, dv=v.grad, l1=l1.detach(), l2=l2.detach(), di1=i1.grad, dt1=t1.grad, di2=i2.grad, dt2=t2.grad,
+                dls1=ls1.grad, dls2=ls2.grad)
+
+
+def test_sharded_losses_ragged_batches_match_oracle():
+    """the last, partial batch of an epoch (reference: pad + trim on every gather, antmmf/utils/distributed_utils.py:131-160).
+    2 gloo ranks with 3 and 2 pairs == the oracle on the 5-pair global batch: loss on both ranks, W x the single-process gradient slices, the
+    logit-scale gradients summed over ranks."""
+    import weightgen as W
+    from oracle import losses
+    from test_kernels_emu import _stale
+
+    if _stale():
+        import subprocess
+
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    world, counts, n, D = 2, [3, 2], 2, 16
+    Bg = sum(counts)
+    out = _spawn(_ragged_loss_case, 29647)
+    T = torch.nn.functional.normalize(W.data_tensor("ragged.t", (Bg, D)), dim=-1).requires_grad_(True)
+    V = torch.nn.functional.normalize(W.data_tensor("ragged.v", (Bg * n, D)), dim=-1).requires_grad_(True)
+    wgt = W.data_tensor("ragged.w", (Bg,)).abs() + 0.5
+    simi = torch.matmul(V.view(Bg, n, D), T.t()).permute(2, 0, 1)
+    mil = simi.unsqueeze(1).expand(Bg, n, Bg, n).reshape(Bg * n, Bg * n)
+    ref = losses.mil_nce(mil, Bg, n, weight=wgt)
+    ref.backward()
+    I1, T1 = T.detach().clone().requires_grad_(True), V.detach()[::n].clone().requires_grad_(True)
+    I2, T2 = V.detach()[1::n].clone().requires_grad_(True), T.detach().clone().requires_grad_(True)
+    ls1, ls2 = torch.tensor(2.0, requires_grad=True), torch.tensor(1.5, requires_grad=True)
+    r1, _ = losses.clip_itc(I1, T1, ls1)
+    r2, _ = losses.clip_itc(I2, T2, ls2)
+    (r1 + 2.0 * r2).backward()
+    lo = 0
+    for r in range(world):
+        B = counts[r]
+        torch.testing.assert_close(out[r]["loss"], ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[r]["dt"], world * T.grad[lo:lo + B], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(out[r]["dv"], world * V.grad[lo * n:(lo + B) * n], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(out[r]["l1"], r1.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[r]["l2"], r2.detach(), rtol=1e-5, atol=1e-6)
+        for got, want in (("di1", I1), ("dt1", T1), ("di2", I2), ("dt2", T2)):
+            assert out[r][got].shape[0] == B
+            torch.testing.assert_close(out[r][got], world * want.grad[lo:lo + B], rtol=1e-3, atol=1e-6)
+        lo += B
+    torch.testing.assert_close(out[0]["dls1"] + out[1]["dls1"], world * ls1.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(out[0]["dls2"] + out[1]["dls2"], world * ls2.grad, rtol=1e-3, atol=1e-6)
+
+
 def _trainer_case(rank, world):
     from antmmf.common.configuration import Configuration
     from antmmf.common.registry import registry

@@ -163,6 +163,31 @@ def test_gemm_k64_persistent(variant):
     assert "okk64" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_gemm_k64_rolling_epilogue():
+    """gemm_nt_k64r_kernel (rolling epilogue: bias / residual start the accumulators, row quarters stored inside the last K-tile) on 2 - 16-tile problems
+    with an 8-workgroup grid (workgroups walk up to three tiles: quarter 3 of a tile leaves in the next tile's first K-tile, the next tile's residual is
+    requested during the last K-tile of the previous one): nk = 3 (one K-tile per role), 4, 5; plain / bias / residual / bias + residual.  The
+    kernel must really have run: for bias + residual a few results differ from the burst-epilogue kernel in the last bf16 bit (order of the fp32 sum)."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
+            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '8'; os.environ['ANTMMF_GEMM_VARIANT'] = '8196';"
+            "import ctypes; import kernel_cases as kc; from antmmf.hip import ops, _lib; dev = torch.device('cpu');"
+            "kc.case_gemm_k64(ops, dev, I=512, J=256, R=192, quick=True);"
+            "kc.case_gemm_k64(ops, dev, I=2560, J=256, R=256, quick=True);"
+            "g = torch.Generator().manual_seed(3); X = torch.randn(768, 320, generator=g).bfloat16(); W = (torch.randn(512, 320, generator=g) * 0.05).bfloat16();"
+            "b = torch.randn(512, generator=g); r = (torch.randn(768, 512, generator=g) * 30).bfloat16(); ref = X.float() @ W.float().t();"
+            "lib = _lib.load(); y1 = ops.gemm(X, W, bias=b, residual=r); p1 = ops.gemm(X, W);"
+            "kc.check('k64r.bias', ops.gemm(X, W, bias=b), ref + b, 2e-2, 1e-2); kc.check('k64r.res', ops.gemm(X, W, residual=r), ref + r.float(), 2e-2, 1e-2);"
+            "lib.antmmf_debug_set_gemm_variant(4 | 16384); y0 = ops.gemm(X, W, bias=b, residual=r); p0 = ops.gemm(X, W);"
+            "assert torch.equal(p0, p1); d = (y0.float() - y1.float()).abs(); assert 0 < int((d > 0).sum()) < 400 and float(d.max()) <= 0.5, (int((d > 0).sum()), float(d.max()));"
+            "print('okk64r')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert "okk64r" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, quick=not os.environ.get("ANTMMF_SLOW_TESTS"))
 

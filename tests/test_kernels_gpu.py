@@ -113,29 +113,41 @@ def test_gemm_k64_persistent(ops):
 
 
 def test_gemm_k64_full_size_vs_fp32(ops):
-    """BASELINE sizes (ViT-L/14, 256 pairs): fc2-shaped GEMM with bias + residual (register-level epilogue) and fc1-shaped with bias
-    (staged epilogue) against an fp32 matmul of the same bf16 operands on sampled rows; bit-exact against the BK = 32 ring kernel
-    (same K order) through the variant knob."""
+    """BASELINE sizes (ViT-L/14, 256 pairs): fc2-shaped GEMM with bias + residual, fc1-shaped with bias, a plain dgrad shape -- on the rolling-epilogue kernel
+    (the default for these shapes) against an fp32 matmul of the same bf16 operands on sampled rows; the burst-epilogue kernel (variant bit 14) bit-exact
+    against the BK = 32 ring kernel (same K order); the rolling kernel bit-exact for the plain epilogue and within one bf16 ulp on a small fraction of the
+    elements where bias / residual enter the fp32 sum first instead of last; every run of it bit-identical to the first (a DMA piece consumed before it
+    landed would show up as a sporadically different tile)."""
     from antmmf.hip import _lib
 
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(5)
     I = 257 * 256
-    for (J, R, with_res) in ((1024, 4096, True), (4096, 1024, False)):
+    for (J, R, with_bias, with_res) in ((1024, 4096, True, True), (4096, 1024, True, False), (1024, 3072, False, False)):
         X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
         W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
-        bias = torch.randn(J, generator=g, device=DEV)
+        bias = torch.randn(J, generator=g, device=DEV) if with_bias else None
         res = torch.randn(I, J, generator=g, device=DEV).bfloat16() if with_res else None
         y = ops.gemm(X, W, bias=bias, residual=res)
         rows = torch.randint(0, I, (96,), device=DEV)
-        ref = X[rows].float() @ W.float().t() + bias + (res[rows].float() if with_res else 0)
+        ref = X[rows].float() @ W.float().t() + (bias if with_bias else 0) + (res[rows].float() if with_res else 0)
         torch.testing.assert_close(y[rows].float(), ref, rtol=2e-2, atol=2e-2)
-        lib.antmmf_debug_set_gemm_variant(0)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(X, W, bias=bias, residual=res), y)
         try:
+            lib.antmmf_debug_set_gemm_variant(0)
             y0 = ops.gemm(X, W, bias=bias, residual=res)
+            lib.antmmf_debug_set_gemm_variant(4 | 16384)
+            yb = ops.gemm(X, W, bias=bias, residual=res)
         finally:
             lib.antmmf_debug_set_gemm_variant(4)
-        assert torch.equal(y, y0)
+        assert torch.equal(yb, y0)
+        if not (with_bias or with_res):
+            assert torch.equal(y, y0)
+        else:
+            diff = (y.float() - y0.float()).abs()
+            ulp = torch.maximum(y0.float().abs(), torch.tensor(2.0 ** -126, device=DEV)).log2().floor().exp2() * 2.0 ** -7
+            assert int((diff > 0).sum()) <= y.numel() // 200 and bool((diff <= ulp * 1.001).all()), (int((diff > 0).sum()), float((diff / ulp).max()))
 
 
 def test_gemm_wgrad_ring(ops):

@@ -1,0 +1,48 @@
+"""Race screen for a GEMM variant (GPU): every shape of the ViT-L/14 step is run N times with the variant under test; every run must be bit-identical to the
+first (a DMA piece read before it landed shows up as a sporadically different tile), and the first run is compared with the product kernel (variant 4):
+plain epilogues bit-identical, bias / residual ones within one bf16 ulp on a few elements (bias + residual enter the fp32 sum first instead of last),
+plus sampled rows against an fp32 matmul.  usage: python tools/gemm_race_screen.py [variant=8196] [pairs=1024] [runs=20]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT]
+from antmmf.hip import _lib, ops  # noqa: E402
+
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 8196
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+runs = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+lib = _lib.load()
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cuda").manual_seed(7)
+bad = 0
+for tokens in (257 * pairs, 77 * pairs):
+    tokens = tokens // 256 * 256
+    for (tag, J, R, bias, res) in (("fc1", 4096, 1024, 1, 0), ("fc2", 1024, 4096, 1, 1), ("qkv", 3072, 1024, 1, 0), ("out", 1024, 1024, 1, 1),
+                                   ("dgrad_fc1", 1024, 4096, 0, 0), ("dgrad_qkv", 1024, 3072, 0, 0), ("res_only", 1024, 1024, 0, 1), ("b16_fc2", 768, 3072, 1, 1)):
+        X = torch.randn(tokens, R, generator=g, device=dev).bfloat16()
+        W = (torch.randn(J, R, generator=g, device=dev) * R ** -0.5).bfloat16()
+        b = torch.randn(J, generator=g, device=dev) if bias else None
+        r = (torch.randn(tokens, J, generator=g, device=dev) * 4).bfloat16() if res else None
+        lib.antmmf_debug_set_gemm_variant(4)
+        y0 = ops.gemm(X, W, bias=b, residual=r)
+        lib.antmmf_debug_set_gemm_variant(variant)
+        y1 = ops.gemm(X, W, bias=b, residual=r)
+        nd = 0
+        for _ in range(runs):
+            # unrelated traffic between runs so that DMA latencies vary
+            y = ops.gemm(X, W, bias=b, residual=r)
+            nd += int((y != y1).sum())
+        lib.antmmf_debug_set_gemm_variant(4)
+        ndiff = int((y0 != y1).sum())
+        maxd = float((y0.float() - y1.float()).abs().max())
+        rows = torch.randint(0, tokens, (64,), device=dev)
+        ref = X[rows].float() @ W.float().t() + (b if bias else 0) + (r[rows].float() if res else 0)
+        e0 = float((y0[rows].float() - ref).abs().max()); e1 = float((y1[rows].float() - ref).abs().max())
+        ok = nd == 0 and (ndiff == 0 if not (bias or res) else ndiff < y0.numel() * 1e-3) and e1 <= max(2 * e0, 0.26)
+        bad += 0 if ok else 1
+        print({"shape": tag, "tokens": tokens, "J": J, "R": R, "self_mismatch": nd, "vs_product_ndiff": ndiff, "vs_product_max": maxd, "err_product": e0, "err_variant": e1, "ok": ok}, flush=True)
+print("RACE SCREEN", "FAILED" if bad else "clean", "variant", variant)
+sys.exit(1 if bad else 0)
