@@ -1,5 +1,5 @@
 """Race screen for a GEMM variant (GPU): every shape of the ViT-L/14 step is run N times with the variant under test; every run must be bit-identical to the
-first (a DMA piece read before it landed shows up as a sporadically different tile), and the first run is compared with the product kernel (variant 4):
+first (a DMA piece read before it landed shows up as a sporadically different tile), and the first run is compared with the burst-epilogue kernel (variant 4 | 16384):
 plain epilogues bit-identical, bias / residual ones within one bf16 ulp on a few elements (bias + residual enter the fp32 sum first instead of last),
 plus sampled rows against an fp32 matmul.  usage: python tools/gemm_race_screen.py [variant=8196] [pairs=1024] [runs=20]"""
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT]
 from antmmf.hip import _lib, ops  # noqa: E402
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 8196
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 lib = _lib.load()
@@ -26,7 +26,7 @@ for tokens in (257 * pairs, 77 * pairs):
         W = (torch.randn(J, R, generator=g, device=dev) * R ** -0.5).bfloat16()
         b = torch.randn(J, generator=g, device=dev) if bias else None
         r = (torch.randn(tokens, J, generator=g, device=dev) * 4).bfloat16() if res else None
-        lib.antmmf_debug_set_gemm_variant(4)
+        lib.antmmf_debug_set_gemm_variant(4 | 16384)   # the burst-epilogue kernel
         y0 = ops.gemm(X, W, bias=b, residual=r)
         lib.antmmf_debug_set_gemm_variant(variant)
         y1 = ops.gemm(X, W, bias=b, residual=r)
