@@ -515,6 +515,55 @@ class _WtiReduce(torch.autograd.Function):
         return dtext.reshape(A, T, D).to(tdt), dvideo.reshape(B, V, D).to(vdt), None, None, df2f, None
 
 
+class _FrameTable(torch.autograd.Function):
+    """F[b] = X[b] X[b]^T for X [B, V, D] (the frame-frame cosines of each video, DmaeUtils._get_wti_similarity's second-best-frame term,
+    dmae_utils.py:98-119) on the fp32-accurate split MFMA GEMM: videos are taken in groups, one [G V, G V] product per group whose diagonal
+    V x V blocks are the answer (a batched [V, D] x [D, V] product is 12 x 12 outputs per video: no tile shape fits it).  Backward: dX = (dF + dF^T) X per
+    video, as one product of the block-diagonal gradient with the group's rows."""
+
+    GROUP_ROWS = 2048
+
+    @staticmethod
+    def _groups(B, V):
+        g = max(1, _FrameTable.GROUP_ROWS // V)
+        return [(b0, min(B, b0 + g)) for b0 in range(0, B, g)]
+
+    @staticmethod
+    def forward(ctx, X):
+        B, V, D = X.shape
+        Xf = X.float().contiguous()
+        out = torch.empty(B, V, V, dtype=torch.float32, device=X.device)
+        for b0, b1 in _FrameTable._groups(B, V):
+            G = b1 - b0
+            rows = Xf[b0:b1].reshape(G * V, D)
+            S = matmul_f32(rows, rows).view(G, V, G, V)
+            idx = torch.arange(G, device=X.device)
+            out[b0:b1] = S[idx, :, idx, :]
+        ctx.save_for_backward(Xf)
+        ctx.dt = X.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dF):
+        (Xf,) = ctx.saved_tensors
+        B, V, D = Xf.shape
+        dX = torch.empty_like(Xf)
+        sym = (dF + dF.transpose(1, 2)).float()
+        for b0, b1 in _FrameTable._groups(B, V):
+            G = b1 - b0
+            blk = torch.zeros(G, V, G, V, dtype=torch.float32, device=Xf.device)
+            idx = torch.arange(G, device=Xf.device)
+            blk[idx, :, idx, :] = sym[b0:b1]
+            rows = Xf[b0:b1].reshape(G * V, D)
+            dX[b0:b1] = matmul_f32(blk.view(G * V, G * V), rows, b_rmajor=True).view(G, V, D)
+        return dX.to(ctx.dt)
+
+
+def frame_table(video_feat):
+    """[B, V, D] -> [B, V, V] per-video Gram matrices (see _FrameTable)."""
+    return _FrameTable.apply(video_feat)
+
+
 def wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight=None, video_weight=None, self_weight=False, weighted=True,
                    rows_per_block=None):
     """DmaeUtils._get_wti_similarity (prj/dmae_vtp/roi_univl/univl/model/dmae_utils.py:85-131) -> [A, B].
@@ -525,8 +574,7 @@ def wti_similarity(text_feat, video_feat, text_mask, video_mask, text_weight=Non
     tmask, vmask = text_mask.float(), video_mask.float()
     f2f = z2_of = None
     if self_weight:  # per-video frame-frame table: [B, V, V], tiny next to the text-video slab
-        vf = video_feat.float()
-        F = torch.matmul(vf, vf.transpose(1, 2)) * vmask[:, :, None] * vmask[:, None, :]
+        F = frame_table(video_feat) * vmask[:, :, None] * vmask[:, None, :]
         F = F * (1.0 - torch.eye(V, device=F.device, dtype=F.dtype))[None]
         f2f, z2_of = F.max(dim=-1)
     if rows_per_block is None:

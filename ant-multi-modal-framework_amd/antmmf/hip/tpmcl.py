@@ -9,25 +9,11 @@ What they replace in the reference (prj/dmae_vtp/roi_univl/univl/model/dmae_util
                     contrastive.matmul_f32 (three GEMMs: fp32-accurate products, fp32 accumulation)
 No torch / rocBLAS GEMM, softmax or sort is left on that path.
 """
-import os
-
 import torch
 
-from . import _lib, ops
-from .contrastive import matmul_f32 as _matmul_f32_mfma
+from . import ops
+from .contrastive import matmul_f32      # fp32-accurate products on the bf16 MFMA GEMM (hi / lo split); module-level so that the lane-emulator tests can stub it
 from .functional import GradSink, _note_untracked, f32
-
-
-def matmul_f32(A, B, a_rmajor=False, b_rmajor=False):
-    """contrastive.matmul_f32 (hi / lo split on the bf16 MFMA GEMM).  TEST SHORTCUT, CPU lane emulator only (a library the loader refuses
-    outside pytest): with ANTMMF_EMU_TORCH_F32_GEMM=1 the product is taken with torch on the host tensors -- an emulated MFMA GEMM costs ~10 s
-    a launch and the TPM-CL head makes dozens; the split GEMM itself is exercised without the shortcut by tests/test_kernels_emu.py::
-    test_linear_f32 and by every -m gpu run."""
-    if _lib.backend() == 0 and os.environ.get("ANTMMF_EMU_TORCH_F32_GEMM"):
-        a = A.float().t() if a_rmajor else A.float()
-        b = B.float() if b_rmajor else B.float().t()
-        return a @ b
-    return _matmul_f32_mfma(A, B, a_rmajor=a_rmajor, b_rmajor=b_rmajor)
 
 
 class _TokenWeights(torch.autograd.Function):

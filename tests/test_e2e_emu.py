@@ -21,10 +21,22 @@ def emu():
 
     old = os.environ.get("ANTMMF_HIP_LIB")
     os.environ["ANTMMF_HIP_LIB"] = EMU_LIB
-    os.environ["ANTMMF_EMU_TORCH_F32_GEMM"] = "1"   # the TPM-CL head's small fp32 GEMMs (dozens per case) -- see antmmf.hip.tpmcl.matmul_f32
     _lib.reset_for_tests()
+    # TEST SHORTCUT (lane emulator only): the TPM-CL head makes dozens of small fp32-accurate GEMMs and an emulated MFMA GEMM costs ~10 s a launch, so this
+    # module swaps the head's GEMM for a host product; the split GEMM itself is exercised by tests/test_kernels_emu.py::test_tpmcl_ops_and_linear_f32
+    # and by every -m gpu run.  The product module carries no such switch.
+    import antmmf.hip.tpmcl as tpm
+
+    real = tpm.matmul_f32
+
+    def host_matmul(A, B, a_rmajor=False, b_rmajor=False):
+        a = A.float().t() if a_rmajor else A.float()
+        b = B.float() if b_rmajor else B.float().t()
+        return a @ b
+
+    tpm.matmul_f32 = host_matmul
     yield
-    os.environ.pop("ANTMMF_EMU_TORCH_F32_GEMM", None)
+    tpm.matmul_f32 = real
     if old is None:
         os.environ.pop("ANTMMF_HIP_LIB", None)
     else:

@@ -245,6 +245,5 @@ def test_softmax_ce(ops):
 
 
 def test_tpmcl_ops_and_linear_f32(ops):
-    """csrc/tpmcl.hip + antmmf.hip.tpmcl on the lane emulator, the split GEMM of linear_f32 WITHOUT the emulator shortcut."""
-    os.environ.pop("ANTMMF_EMU_TORCH_F32_GEMM", None)
+    """csrc/tpmcl.hip + antmmf.hip.tpmcl on the lane emulator, the split GEMM of linear_f32 on the emulated MFMA GEMM."""
     kc.case_tpmcl_ops(DEV, C=9, V=5, T=7, D=40)

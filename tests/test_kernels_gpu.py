@@ -146,8 +146,9 @@ def test_gemm_k64_full_size_vs_fp32(ops):
             assert torch.equal(y, y0)
         else:
             diff = (y.float() - y0.float()).abs()
-            ulp = torch.maximum(y0.float().abs(), torch.tensor(2.0 ** -126, device=DEV)).log2().floor().exp2() * 2.0 ** -7
-            assert int((diff > 0).sum()) <= y.numel() // 200 and bool((diff <= ulp * 1.001).all()), (int((diff > 0).sum()), float((diff / ulp).max()))
+            big = torch.maximum(y.float().abs(), y0.float().abs()).clamp_min(2.0 ** -100)
+            ulp = big.log2().floor().exp2() * 2.0 ** -7      # one bf16 ulp at the larger magnitude; results near zero may differ by the fp32 reordering error itself
+            assert int((diff > 0).sum()) <= y.numel() // 200 and bool((diff <= ulp * 1.001 + 2e-5).all()), (int((diff > 0).sum()), float((diff - ulp).max()))
 
 
 def test_gemm_wgrad_ring(ops):
