@@ -1582,7 +1582,6 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     };
     int local = lx;
     if (local >= xcount) return;
-
     // fragment read bases; the Q fragment row of lane l15 is l15 with bits 2 and 3 exchanged (lane-swap store layout, see gemm_nt_k64p_kernel)
     const int pl15 = (l15 & 3) | (((l15 >> 3) & 1) << 2) | (((l15 >> 2) & 1) << 3);
     uint32_t pbase[4], qbase[4];
