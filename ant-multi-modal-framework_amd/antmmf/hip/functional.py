@@ -699,10 +699,10 @@ class _Embed(torch.autograd.Function):
     LayerNorm; torchscale TextEmbedding + PositionalEmbedding with padded rows zeroed, encoder.py:350-386,440)."""
 
     @staticmethod
-    def forward(ctx, ids, word, pos, type_table, zero_rows, pos_offset):
+    def forward(ctx, ids, word, pos, type_table, zero_rows, pos_offset, padding_idx):
         out = ops.embed_gather(ids.contiguous(), f32(word), f32(pos), f32(type_table), None, zero_rows, pos_offset)
         ctx.save_for_backward(ids, word, pos, type_table, zero_rows)
-        ctx.pos_offset = pos_offset
+        ctx.pos_offset, ctx.padding_idx = pos_offset, padding_idx
         return out
 
     @staticmethod
@@ -712,7 +712,13 @@ class _Embed(torch.autograd.Function):
         seq = ids.shape[1]
         sink = GradSink()
         if word.requires_grad:
-            ops.embed_scatter_add_(sink.buf(word), dx, ids.contiguous(), zero_rows)
+            # nn.Embedding(padding_idx=k) never updates row k (BertEmbeddings: modeling_bert.py:71-73, clip_text_encoder.py:21-23, padding_idx = 0).  Skipping those
+            # rows is also what keeps the sorted scatter balanced: on real captions every [PAD] position carries id 0 -- one run of tens of thousands of rows.
+            skip = zero_rows
+            if ctx.padding_idx is not None:
+                pad = (ids == ctx.padding_idx).to(torch.uint8)
+                skip = pad if skip is None else (skip.to(torch.uint8).reshape(pad.shape) | pad)
+            ops.embed_scatter_add_(sink.buf(word), dx, ids.contiguous(), skip)
         if pos is not None and pos.requires_grad:
             ops.embed_scatter_add_(sink.buf(pos), dx, None, zero_rows, seq=seq, offset=ctx.pos_offset)
         if type_table is not None and type_table.requires_grad:
@@ -725,9 +731,10 @@ class _Embed(torch.autograd.Function):
             sink.buf(type_table)[0].add_(tmp)
         ng = ctx.needs_input_grad
         return (None, sink.result(word, ng[1]), sink.result(pos, pos is not None and ng[2]),
-                sink.result(type_table, type_table is not None and ng[3]), None, None)
+                sink.result(type_table, type_table is not None and ng[3]), None, None, None)
 
 
-def embed(ids, word, pos=None, type_table=None, zero_rows=None, pos_offset=0):
+def embed(ids, word, pos=None, type_table=None, zero_rows=None, pos_offset=0, padding_idx=None):
+    """padding_idx: table row that receives no gradient (torch.nn.Embedding's padding_idx)."""
     _note_untracked(word, pos, type_table)
-    return _Embed.apply(ids, word, pos, type_table, zero_rows, pos_offset)
+    return _Embed.apply(ids, word, pos, type_table, zero_rows, pos_offset, padding_idx)

@@ -151,10 +151,10 @@ class BertEmbeddings(nn.Module):
             raise NotImplementedError("explicit position_ids (default positions 0..N-1 only)")
         nonzero_types = token_type_ids is not None and bool((token_type_ids != 0).any())
         if inputs_embeds is None and not nonzero_types:
-            x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight)
+            x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight, padding_idx=0)
         else:
             if inputs_embeds is None:
-                x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, None).float()
+                x = HF.embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight, None, padding_idx=0).float()
                 seq = input_ids.shape[1]
             else:
                 seq = inputs_embeds.shape[1]

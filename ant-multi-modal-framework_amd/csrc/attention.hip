@@ -33,6 +33,8 @@
 // are recomputed in both backward kernels), in practice bounded by the softmax VALU work (~10 VALU slots per score).
 // Algorithmic HBM bytes per (b, h): fwd 2*64*(2Nq + 2Nk) + 4Nq.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 // Compiler-level fence: keeps hipcc from hoisting every LDS fragment read of a fully unrolled tile loop to the
 // top (which costs > 256 VGPRs and spills); a few tiles' worth of reads stay in flight between fences.
@@ -236,6 +238,253 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
                     make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
         }
         if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
+    }
+}
+
+// ---- forward on 32 x 32 x 16 MFMA tiles (head size 64, no dropout: the M2 / CLIP image towers and every tower in evaluation) --------------------------
+// Same residency as the kernel above (one workgroup per (batch, head), K and V token tiles in LDS), different unit of work: a wave owns 32 queries and walks
+// the keys in blocks of 64 with an online softmax.
+//   * v_mfma_f32_32x32x16_bf16 (A: lane l holds A[l & 31][8 (l >> 5) + e], B: B[8 (l >> 5) + e][l & 31], D: D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r < 16).
+//     Scores are computed transposed, S^T = K Q^T: a lane holds one query (column l & 31) and 16 keys of a 32-key tile, so the row max / sum are in-lane plus ONE
+//     exchange with lane l ^ 32 (v_permlane32_swap: no LDS crossbar);
+//   * a K fragment (one ds_read_b128) now feeds 32 x 32 x 16 MACs instead of 16 x 16 x 32: half the LDS bytes, half the LDS and MFMA instructions per flop,
+//     half the shuffles per score of the 16 x 16 kernel -- its waves spent 48 % of their cycles parked on s_waitcnt and another 24 % on issue stalls
+//     (profiles/r3_pmc_attn_summary.txt), i.e. on the NUMBER of dependent LDS -> MFMA round trips, not on any pipe's throughput;
+//   * the probabilities a lane holds ARE its P.V B fragment: the 8 k-slots of lane group g = l >> 5 in the MFMA of key half h of a tile are DEFINED as keys
+//     {16 h + 4 g + 0..3, 16 h + 8 + 4 g + 0..3} (score registers 8 h .. 8 h + 7), and the matching A fragment (V^T: 32 head-dim rows x those 16 keys) is two
+//     transposing reads of the row-major V tile;
+//   * online softmax over 64-key blocks (32 score registers, 32 output accumulators, 16 packed probabilities: ~125 VGPRs, 4 waves per SIMD as before); the
+//     running maximum only ever rescales when some lane of the wave saw a larger score (wave-uniform branch).  exp2 domain, scale folded into one FMA.
+// Tile bookkeeping: 257 queries = 8 full tiles + one tile with a single row; the extra tile goes to a different wave (hence SIMD) in every workgroup.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__device__ __forceinline__ bf16_t f2bf_hw(float v) { return (bf16_t)(pack_bf2(v, 0.f) & 0xffffu); }
+#ifdef ANTMMF_EMULATE
+__device__ __forceinline__ float lane32_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float lane32_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+#else
+typedef __attribute__((ext_vector_type(2))) unsigned int attn_u2_t;
+__device__ __forceinline__ float lane32_max(float v) {
+    const attn_u2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+__device__ __forceinline__ float lane32_sum(float v) {
+    const attn_u2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+#endif
+// A fragment "head-dim rows 32 d2 + (l & 31), key slots of key half h of 32-key tile t" (keys {32 t + 16 h + 4 g + 0..3, + 8}): two transposing reads
+__device__ __forceinline__ bf16x8_t frag_tokens32(const char* tile, int t, int h, int d2, int lane) {
+    const int g = lane >> 5, sub16 = (lane >> 4) & 1, j = lane & 15;
+    const int row = 32 * t + 16 * h + 4 * g + (j >> 2);
+    const int slot = 4 * d2 + 2 * sub16 + ((j >> 1) & 1), sub = (j & 1) << 3;
+    const bf16x4_t lo = lds_read_tr16(tile + row * 128 + ((slot ^ attn_swz<64>(row)) << 4) + sub);
+    const bf16x4_t hi = lds_read_tr16(tile + (row + 8) * 128 + ((slot ^ attn_swz<64>(row + 8)) << 4) + sub);
+    return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <int NT32, bool HASBIAS, int KB>  // keys padded to 32 * NT32; HASBIAS: an additive key bias exists (BERT / torchscale padding masks); KB: 32-key tiles per softmax block
+__global__ __launch_bounds__(ATTN_THREADS, 4) void attn_fwd32_kernel(const AttnArgs a) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int NKP = 32 * NT32;
+    char* Ks = smem;
+    char* Vs = smem + NKP * 128;
+    float* kb = reinterpret_cast<float*>(Vs + NKP * 128);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, g = lane >> 5;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    // K keeps the 16 x 16 kernels' swizzle (conflict-free for the 32-row ds_read_b128 fragments as well); V is only ever read by transposing reads of 4 rows x 64 B
+    // per half-wave here, so its 16-B slot index is XORed with ((row >> 1) & 1) << 2: rows r and r + 2 of such a read land in different 64-B halves of the bank row
+    {
+        constexpr int TRIPS = (NKP * 8 + ATTN_THREADS - 1) / ATTN_THREADS;
+        const bf16_t* ksrc = a.k + (long)b * a.Nk * a.ldk + h * 64;
+        const bf16_t* vsrc = a.v + (long)b * a.Nk * a.ldv + h * 64;
+        uint4 kv[TRIPS], vv[TRIPS];
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+            const int id = threadIdx.x + i * ATTN_THREADS, row = id >> 3, slot = id & 7;
+            const bool ok = id < NKP * 8 && row < a.Nk;
+            kv[i] = ok ? *reinterpret_cast<const uint4*>(ksrc + (long)row * a.ldk + slot * 8) : make_uint4(0, 0, 0, 0);
+            vv[i] = ok ? *reinterpret_cast<const uint4*>(vsrc + (long)row * a.ldv + slot * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+            const int id = threadIdx.x + i * ATTN_THREADS, row = id >> 3, slot = id & 7;
+            if (id < NKP * 8) {
+                *reinterpret_cast<uint4*>(Ks + row * 128 + ((slot ^ attn_swz<64>(row)) << 4)) = kv[i];
+                *reinterpret_cast<uint4*>(Vs + row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4)) = vv[i];
+            }
+        }
+    }
+    if (HASBIAS) stage_key_bias(kb, a, b, NKP);
+    __syncthreads();
+
+    const float scale2 = a.scale * LOG2E;
+    // A last tile with one or two valid queries (257 tokens = 8 x 32 + CLS) is not given to ONE wave -- the workgroup would live two tile times for 9 / 8
+    // of a tile's work per wave -- but split over the KEYS: every wave takes the key tiles wave, wave + 8, .. of it, the partial (max, sum, output) triples
+    // meet in LDS and one wave merges them (the flash-decoding combine).
+    const int nfull = a.Nq >> 5, nrem = a.Nq & 31;
+    const bool split_last = nrem > 0 && nrem <= 2;
+    const int nqt = split_last ? nfull : ((a.Nq + 31) >> 5);
+    const int first = (wave + blockIdx.x) & 7;   // an extra whole tile (nqt = 8 k + 1, not split) lands on a different wave -- hence SIMD -- in every workgroup
+    float* comb = kb + NKP;                      // [8 waves][2 columns][68]: 64 outputs, max, the two lane groups' sums
+    // per-lane LDS byte offsets of the fragment reads inside tile 0; tile t adds 4096 t, key half h adds 2048 h (the swizzle reads row bits 1 - 3 only)
+    int kofs[4], vofs_lo[2], vofs_hi[2];
+    {
+        const int sub16 = (lane >> 4) & 1, j = lane & 15, vrow = 4 * g + (j >> 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kofs[c] = l31 * 128 + (((2 * c + g) ^ attn_swz<64>(l31)) << 4);
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+            const int slot = 4 * d2 + 2 * sub16 + ((j >> 1) & 1), sub = (j & 1) << 3;
+            vofs_lo[d2] = vrow * 128 + ((slot ^ (((vrow >> 1) & 1) << 2)) << 4) + sub;
+            vofs_hi[d2] = (vrow + 8) * 128 + ((slot ^ (((vrow >> 1) & 1) << 2)) << 4) + sub;
+        }
+    }
+    auto vfrag = [&](int t, int hh, int d2) {
+        const char* p = Vs + t * 4096 + hh * 2048;
+        const bf16x4_t lo = lds_read_tr16(p + vofs_lo[d2]), hi = lds_read_tr16(p + vofs_hi[d2]);
+        return (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    // one 32-query tile against the key tiles [t_begin, t_end) step t_step: -> running (m, lsum, o0, o1) of this lane
+    auto run_tile = [&](int qt, int t_begin, int t_end, int t_step, float& m, float& lsum, f32x16_t& o0, f32x16_t& o1) {
+        const int qi = qt * 32 + l31;
+        const int qrow = qi < a.Nq ? qi : a.Nq - 1;
+        const bf16_t* qp = a.q + ((long)b * a.Nq + qrow) * a.ldq + h * 64 + g * 8;
+        bf16x8_t qf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[c] = load_frag_global(qp + 16 * c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        m = -INFINITY; lsum = 0.f;   // running maximum (exp2 domain, of the scaled + biased scores) and this lane's share of the running sum
+        // one block of NTB 32-key tiles starting at tile t0; LASTB: the block that holds the padding keys.  (The full blocks run as a rolled loop: unrolled,
+        // hipcc keeps an address register per tile and the 9-tile kernel spills.)
+        auto block = [&](int t0, auto ntb_c, auto last_c) {
+            constexpr int NTB = decltype(ntb_c)::value;
+            constexpr bool LASTB = decltype(last_c)::value;
+            f32x16_t s[NTB];
+#pragma unroll
+            for (int tt = 0; tt < NTB; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[tt][r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    s[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + (t0 + tt) * 4096 + kofs[c]), qf[c], s[tt], 0, 0, 0);
+            }
+            LDS_FENCE();
+            // scaled (+ biased) scores; padding keys (>= Nk) exist only in the last tile of the last block
+            float mb = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < NTB; ++tt) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int key0 = 32 * (t0 + tt) + 8 * r4 + 4 * g;
+                    if (HASBIAS) {
+                        const float4 bias = *reinterpret_cast<const float4*>(kb + key0);
+                        s[tt][4 * r4 + 0] = s[tt][4 * r4 + 0] * scale2 + bias.x; s[tt][4 * r4 + 1] = s[tt][4 * r4 + 1] * scale2 + bias.y;
+                        s[tt][4 * r4 + 2] = s[tt][4 * r4 + 2] * scale2 + bias.z; s[tt][4 * r4 + 3] = s[tt][4 * r4 + 3] * scale2 + bias.w;
+                    } else if (LASTB && tt == NTB - 1) {   // (without a bias the scores stay unscaled: the scale is positive, so the maximum can be taken first and
+#pragma unroll                                  //  scaled once, and exp2(s scale2 - m) is ONE fused multiply-add in front of the exponential)
+                        for (int e = 0; e < 4; ++e) s[tt][4 * r4 + e] = key0 + e < a.Nk ? s[tt][4 * r4 + e] : -INFINITY;
+                    }
+                    mb = fmaxf(mb, fmaxf(fmaxf(s[tt][4 * r4], s[tt][4 * r4 + 1]), fmaxf(s[tt][4 * r4 + 2], s[tt][4 * r4 + 3])));
+                }
+            }
+            if (!HASBIAS) mb *= scale2;
+            mb = lane32_max(mb);
+            if (__any(mb > m)) {   // some query of this wave saw a larger score: rescale (wave-uniform branch; always taken in the first block)
+                const float mn = fmaxf(m, mb);
+                const float alpha = mn == -INFINITY ? 1.f : EXP2F(m - mn);   // m = -inf (nothing seen yet): exp2(-inf) = 0 on zeros
+                lsum *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                m = mn;
+            }
+            const float msub = m == -INFINITY ? 0.f : m;   // fully masked so far: every score is -inf, exp2(-inf - 0) = 0
+            bf16x8_t pf[NTB][2];
+#pragma unroll
+            for (int tt = 0; tt < NTB; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[tt][r] = EXP2F(HASBIAS ? s[tt][r] - msub : __builtin_fmaf(s[tt][r], scale2, -msub)); lsum += s[tt][r]; }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    union { uint4 u; bf16x8_t f; } cv;
+                    cv.u = make_uint4(pack_bf2(s[tt][8 * hh], s[tt][8 * hh + 1]), pack_bf2(s[tt][8 * hh + 2], s[tt][8 * hh + 3]),
+                                      pack_bf2(s[tt][8 * hh + 4], s[tt][8 * hh + 5]), pack_bf2(s[tt][8 * hh + 6], s[tt][8 * hh + 7]));
+                    pf[tt][hh] = cv.f;
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < NTB; ++tt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(t0 + tt, hh, 0), pf[tt][hh], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(t0 + tt, hh, 1), pf[tt][hh], o1, 0, 0, 0);
+                }
+            LDS_FENCE();
+        };
+        if (t_step == 1) {   // all keys: full blocks, then the block with the padding keys
+            constexpr int NFULL = (NT32 - 1) / KB;
+#pragma unroll 1
+            for (int kbi = 0; kbi < NFULL; ++kbi) block(KB * kbi, std::integral_constant<int, KB>{}, std::false_type{});
+            block(KB * NFULL, std::integral_constant<int, NT32 - KB * NFULL>{}, std::true_type{});
+        } else {             // a share of the key tiles (split last query tile)
+#pragma unroll 1
+            for (int t = t_begin; t < t_end; t += t_step) {
+                if (t == NT32 - 1) block(t, std::integral_constant<int, 1>{}, std::true_type{});
+                else block(t, std::integral_constant<int, 1>{}, std::false_type{});
+            }
+        }
+    };
+
+    for (int qt = first; qt < nqt; qt += ATTN_THREADS / 64) {
+        float m, lsum;
+        f32x16_t o0, o1;
+        run_tile(qt, 0, NT32, 1, m, lsum, o0, o1);
+        const int qi = qt * 32 + l31;
+        const float sum = lane32_sum(lsum);
+        const float inv = sum > 0.f ? fast_rcp(sum) : 0.f;
+        if (qi < a.Nq) {
+            bf16_t* op = a.o + ((long)b * a.Nq + qi) * a.ldo + h * 64 + 4 * g;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                *reinterpret_cast<uint2*>(op + 8 * r4) = make_uint2(pack_bf2(o0[4 * r4] * inv, o0[4 * r4 + 1] * inv), pack_bf2(o0[4 * r4 + 2] * inv, o0[4 * r4 + 3] * inv));
+                *reinterpret_cast<uint2*>(op + 32 + 8 * r4) = make_uint2(pack_bf2(o1[4 * r4] * inv, o1[4 * r4 + 1] * inv), pack_bf2(o1[4 * r4 + 2] * inv, o1[4 * r4 + 3] * inv));
+            }
+            if (g == 0) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
+        }
+    }
+    if (split_last) {
+        float m, lsum;
+        f32x16_t o0, o1;
+        run_tile(nfull, wave, NT32, ATTN_THREADS / 64, m, lsum, o0, o1);
+        if (l31 < nrem) {
+            float* cw = comb + (wave * 2 + l31) * 68;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dh = (r & 3) + 8 * (r >> 2) + 4 * g;
+                cw[dh] = o0[r]; cw[32 + dh] = o1[r];
+            }
+            if (g == 0) cw[64] = m;
+            cw[65 + g] = lsum;
+        }
+        __syncthreads();
+        if (wave < nrem) {   // wave c merges column c: lane = head-dim index
+            const int c = wave;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < ATTN_THREADS / 64; ++w) M = fmaxf(M, comb[(w * 2 + c) * 68 + 64]);
+            float L = 0.f, acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATTN_THREADS / 64; ++w) {
+                const float* cw = comb + (w * 2 + c) * 68;
+                const float f = cw[64] == -INFINITY ? 0.f : EXP2F(cw[64] - M);
+                L += (cw[65] + cw[66]) * f;
+                acc += cw[lane] * f;
+            }
+            const int qi = nfull * 32 + c;
+            const float inv = L > 0.f ? fast_rcp(L) : 0.f;
+            a.o[((long)b * a.Nq + qi) * a.ldo + h * 64 + lane] = f2bf_hw(acc * inv);
+            if (lane == 0) a.lse[((long)b * a.heads + h) * a.Nq + qi] = L > 0.f ? (M + LOG2F(L)) * LN2 : -INFINITY;
+        }
     }
 }
 
@@ -554,6 +803,24 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
 #define FWD(N) do { const size_t lds = (size_t)(32 * N) * (4 * DH) + (32 * N) * 4; \
         if (a.drop_thr) { set_lds(attn_fwd_kernel<N, true, DH>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, true, DH>), grid, block, lds, stream, a); } \
         else { set_lds(attn_fwd_kernel<N, false, DH>, lds); hipLaunchKernelGGL((attn_fwd_kernel<N, false, DH>), grid, block, lds, stream, a); } } while (0)
+    // attn_fwd32_kernel (32 x 32 x 16 tiles, online softmax) is an OPT-IN experiment: ANTMMF_ATTN_VARIANT bit 2 selects it for the long rows without dropout, bit 1 its
+    // 64-key softmax blocks.  Measured same-box against the 16 x 16 whole-row kernel at 1024 x 16 heads x 257 tokens (profiles/r4_attn_fwd32_ab.txt): 0.78 - 0.81 ms vs
+    // 0.72 - 0.73 ms -- half the LDS instructions and bytes, fewer parked cycles (34 % vs 48 %), but more issue stalls behind the 16-pass MFMAs (35 % vs 24 %) and the same
+    // VALU work per score (one 16-cycle v_exp_f32 per score is as long as all the MFMAs of a tile): not faster, so not the default.
+    static const char* av_env = getenv("ANTMMF_ATTN_VARIANT");
+    const int av = av_env ? atoi(av_env) : 0;
+    if constexpr (DH == 64) {
+        if (!a.drop_thr && nch > 3 && (av & 4)) {
+#define FWD32K(N, HB, KB) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4 + 8 * 2 * 68 * 4; set_lds(attn_fwd32_kernel<N, HB, KB>, lds); \
+            hipLaunchKernelGGL((attn_fwd32_kernel<N, HB, KB>), grid, block, lds, stream, a); } while (0)
+#define FWD32(N, HB) do { if (av & 2) FWD32K(N, HB, 2); else FWD32K(N, HB, 1); } while (0)   /* variant bit 1: 64-key softmax blocks */
+            if (nch <= 7) { if (a.key_bias) FWD32(7, true); else FWD32(7, false); }
+            else { if (a.key_bias) FWD32(9, true); else FWD32(9, false); }
+#undef FWD32
+#undef FWD32K
+            return antmmf_check_launch();
+        }
+    }
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
     return antmmf_check_launch();

@@ -191,6 +191,43 @@ static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32_bf16(a, b, c)
 
+// wave vote: true in every lane if the predicate holds in any lane of the wave
+static inline bool emu_wave_any(bool pred) {
+    auto* w = emu::tls.wave;
+    const int l = emu::tls.lane;
+    w->fbuf[l] = pred ? 1.0f : 0.0f;
+    w->bar.arrive_and_wait();
+    bool any = false;
+    for (int i = 0; i < 64; ++i) any = any || w->fbuf[i] != 0.0f;
+    w->bar.arrive_and_wait();
+    return any;
+}
+#define __any(p) emu_wave_any(p)
+
+// v_mfma_f32_32x32x16_bf16: lane l holds A[l & 31][8 (l >> 5) + e], B[8 (l >> 5) + e][l & 31], D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r < 16
+typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
+static inline emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
+    auto* w = emu::tls.wave;
+    const int l = emu::tls.lane;
+    for (int e = 0; e < 8; ++e) { w->a[l][e] = (uint16_t)a[e]; w->b[l][e] = (uint16_t)b[e]; }
+    w->bar.arrive_and_wait();
+    emu_f32x16 d = c;
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float s = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const float av = __uint_as_float((uint32_t)w->a[row + 32 * (k >> 3)][k & 7] << 16);
+            const float bv = __uint_as_float((uint32_t)w->b[col + 32 * (k >> 3)][k & 7] << 16);
+            s = std::fma(av, bv, s);
+        }
+        d[r] = s;
+    }
+    w->bar.arrive_and_wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16_bf16(a, b, c)
+
 // v_permlane32_swap_b32 (gfx950): lanes 0-31 keep `a` and receive the upper half's `a` in `b`; lanes 32-63 receive the lower half's
 // `b` in `a` and keep `b`  (vdst[32..63] <-> vsrc[0..31]).
 typedef __attribute__((ext_vector_type(2))) unsigned emu_u2;
