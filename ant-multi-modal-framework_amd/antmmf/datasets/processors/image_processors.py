@@ -34,6 +34,15 @@ class CustomTransforms(BaseProcessor):
         return (self.mode == "sequential" and len(f) == 2 and isinstance(f[0], image_ops.ImageLongsideScaleAndPad)
                 and isinstance(f[1], image_ops.GroupNormalize))
 
+    @staticmethod
+    def _on_library_device(x):
+        from antmmf.hip import _lib
+
+        try:
+            return (x.device.type == "cuda") == (_lib.backend() == 1)
+        except Exception:   # no library at all (a host-only data worker)
+            return False
+
     def output_size(self, x):
         """(out_h, out_w) the scale transform gives frames `x` -- draws the random scale exactly once, like one reference call."""
         scale = self.transfunc_list[0]
@@ -45,15 +54,26 @@ class CustomTransforms(BaseProcessor):
         mean, std = norm.channel_stats(x.shape[1])
         if scale.pad:
             raise NotImplementedError("custom_transforms: pad=True inside the fused path (every shipped yml has pad: false)")
-        return hip_image.frames_bilinear_norm(x, oh, ow, mean=mean, std=std, out=out)
+        # GroupNormalize divides by 255 only when the frames exceed 1 AND the means are on the [0, 1] scale (image_ops.py:99-104: detectron2-style
+        # means such as 123.675 mean "pixels stay on 0..255"): the second half is a host-side property of the configuration, the first stays on the device
+        div255 = -1 if max(mean) <= 1 else 0
+        return hip_image.frames_bilinear_norm(x, oh, ow, mean=mean, std=std, out=out, div255=div255)
 
     def __call__(self, x):
         return_dict = isinstance(x, dict)
         if return_dict:
             x = x["image"]
         idx = None
-        if self._fusable() and isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.dim() == 4:
+        if self._fusable() and isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.dim() == 4 and self._on_library_device(x):
             res = self.fused_scale_normalize(x)
+        elif self._fusable() and isinstance(x, torch.Tensor) and x.dim() == 4:
+            # frames that are not on the library's device (a dataloader worker of the reference transforms on the host) or already float: the reference's own
+            # arithmetic -- torchvision's tensor resize IS torch.nn.functional.interpolate(bilinear, align_corners=False) -- then GroupNormalize
+            scale, norm = self.transfunc_list
+            if scale.pad:
+                raise NotImplementedError("custom_transforms: pad=True (every shipped yml has pad: false)")
+            oh, ow = self.output_size(x)
+            res = norm(torch.nn.functional.interpolate(x.float(), size=(oh, ow), mode="bilinear", align_corners=False))
         elif self.mode == "sequential":
             res = x
             for func, param in zip(self.transfunc_list, self.transfunc_params):

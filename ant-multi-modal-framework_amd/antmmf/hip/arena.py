@@ -170,6 +170,10 @@ class ParamArena:
         if i in ov["launched"]:
             return
         ov["launched"].add(i)
+        # launch order of the step, for diagnosing the first multi-GPU runs: (bucket, MiB, from inside backward?, host time) -- `last_bucket_log` after the step
+        import time
+
+        ov.setdefault("log", []).append((i, (b["end"] - b["start"]) * 4 >> 20, not ov.get("closing", False), time.perf_counter()))
         seg = self.grad[b["start"]:b["end"]]
         if ov["dtype"] is not None and ov["dtype"] != torch.float32:
             tmp = seg.to(ov["dtype"])
@@ -191,6 +195,10 @@ class ParamArena:
         if getattr(self, "_ov", None) is None:
             self.arm_overlap(group, bucket_bytes, reduce_dtype)
             self._ov["frozen"], self._ov["left"] = True, [-1] * len(self._buckets)
+        self._ov["closing"] = True
+        import time
+
+        t_close = time.perf_counter()
         for i in range(len(self._buckets)):
             self._launch_bucket(i)
         for h, tmp, seg in self._ov["handles"]:
@@ -198,6 +206,8 @@ class ParamArena:
             if tmp is not None:
                 seg.copy_(tmp)
         self.overlapped_buckets = len(self._ov["launched"]) - sum(1 for x in self._ov["left"] if x != 0)   # diagnostics / tests
+        # per bucket: index, MiB, "bwd" (handed to RCCL while the backward pass was still running) or "end", milliseconds before (-) / after the closing call
+        self.last_bucket_log = [dict(bucket=i, mib=mib, when="bwd" if early else "end", ms=round((t - t_close) * 1e3, 2)) for i, mib, early, t in self._ov.get("log", [])]
         self._ov = None
         return world
 

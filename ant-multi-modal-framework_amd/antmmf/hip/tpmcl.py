@@ -15,6 +15,8 @@ from . import ops
 from .contrastive import matmul_f32      # fp32-accurate products on the bf16 MFMA GEMM (hi / lo split); module-level so that the lane-emulator tests can stub it
 from .functional import GradSink, _note_untracked, f32
 
+TOKEN_WEIGHT_MAX_T, TOKEN_WEIGHT_MAX_D, TIS_KEEP_MAX_T = 128, 1024, 64   # limits of csrc/tpmcl.hip's row kernels
+
 
 class _TokenWeights(torch.autograd.Function):
     @staticmethod
@@ -41,6 +43,15 @@ def token_weights(feat, weight, bias=None, mask=None):
     """feat [N, T, D] -> softmax over T of (feat . weight + bias), tokens with mask < 0.5 excluded.  weight: the [1, D] (or [D]) parameter of
     an nn.Linear(D, 1), bias its [1] bias."""
     _note_untracked(weight, bias)
+    if feat.shape[-2] > TOKEN_WEIGHT_MAX_T or feat.shape[-1] > TOKEN_WEIGHT_MAX_D:
+        # beyond the fused kernel's row budget (one workgroup holds a row's T x D features: csrc/tpmcl.hip) -- e.g. frames x patches video tokens: the same
+        # arithmetic as device tensor ops (a shape guard for configurations the shipped ymls do not use, not a second product path)
+        logits = (feat.float() * weight.float().reshape(-1)).sum(-1)
+        if bias is not None:
+            logits = logits + bias.float().reshape(())
+        if mask is not None:
+            logits = logits.masked_fill(mask < 0.5, float("-inf"))
+        return torch.softmax(logits, dim=-1)
     return _TokenWeights.apply(feat, weight, bias, mask)
 
 
@@ -88,7 +99,12 @@ def pair_wsum(w, y):
 
 def tis_keep(weights, thresh):
     """[R, T] token weights -> keep mask (0 = one of the most important tokens whose descending cumulative weight is < thresh)."""
-    return ops.tis_keep(weights.detach().float().contiguous(), float(thresh))
+    w = weights.detach().float().contiguous()
+    if w.shape[-1] > TIS_KEEP_MAX_T:   # rows longer than the kernel's 64 lanes: the reference's sort / cumsum / scatter (tpmcl_utils.py:101-121) on the device
+        order = torch.argsort(w, dim=-1, descending=True)
+        drop_sorted = torch.cumsum(torch.gather(w, -1, order), dim=-1) < thresh
+        return 1.0 - torch.zeros_like(w).scatter_(-1, order, drop_sorted.float())
+    return ops.tis_keep(w, float(thresh))
 
 
 class _LinearF32(torch.autograd.Function):

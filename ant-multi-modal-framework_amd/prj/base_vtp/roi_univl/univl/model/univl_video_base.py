@@ -68,7 +68,7 @@ class UnivlVideoBase(nn.Module):
         if self.arch_type == "univl":
             # (the reference also asks for the attention maps in training to derive `words_importance`, which only the pretraining head's masking reads:
             # on the fused path the maps never reach HBM and the entry stays None)
-            sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=torch.zeros_like(input_ids))[:2]
+            sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=None)[:2]   # all-zero token types (reference :125): None spares BertEmbeddings its any() host sync
         else:
             sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask)
         pooled_output = HF.l2_normalize(pooled_output.contiguous())
@@ -76,7 +76,7 @@ class UnivlVideoBase(nn.Module):
 
     # ------------------------------------------------------------------ stage-2 cross encoder
     def prepare_cross_text(self, input_ids, input_mask):
-        cap_embed = self.cross_embeddings(input_ids=input_ids, token_type_ids=torch.zeros_like(input_ids))
+        cap_embed = self.cross_embeddings(input_ids=input_ids, token_type_ids=None)   # type 0 everywhere (reference :171-176)
         return cap_embed, input_mask, cap_embed.shape[0]
 
     def prepare_cross_visual(self, visual_embed, visual_mask=None):

@@ -201,9 +201,13 @@ class TokenImportanceSelector(nn.Module):
 
     def keep_mask(self, attn_weight):
         """[R, T] weights -> 0 / 1 keep policy (one wave per row on the device: the descending inclusive prefix sum of every token)."""
-        if not hasattr(self, "_thresh_f"):
-            self._thresh_f = float(self.thresh)      # a construction-time constant: read once (one host sync per model, not per step)
+        if getattr(self, "_thresh_f", None) is None:
+            self._thresh_f = float(self.thresh)      # read once per (re)load of the buffer: one host sync per model, not per step
         return tpmcl.tis_keep(attn_weight, self._thresh_f)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._thresh_f = None                        # a checkpoint may carry another threshold: re-read the buffer on the next call
 
     def forward(self, x, attn_weight):
         keep = self.keep_mask(attn_weight)

@@ -51,6 +51,74 @@ M2_WORKLOADS = {
 }
 M2_TRAIN_GFLOP_PER_PAIR = {"l14": 627.3, "b16": 145.3}  # BASELINE.md section 4 (algorithmic, train = 3 x forward, recompute not counted)
 
+# DRY RUN (ANTMMF_BENCH_DRY_RUN=1; tests/test_host_logic.py::test_bench_two_ranks_dry_run only): the same main() on the host -- gloo instead of RCCL, the
+# lane-emulated kernels, a toy M2 -- so that everything the first real N > 1 run depends on besides the GPUs themselves is exercised where there are none:
+# self-launch under torch.distributed.run, rendezvous, the probe step + agreed activation policy, barriers, max-over-ranks timing, rank 0's JSON line.
+# Its numbers mean nothing and its line says so (`"data": "dry run"`).
+DRY_RUN = os.environ.get("ANTMMF_BENCH_DRY_RUN") == "1"
+if DRY_RUN:
+    M2_WORKLOADS["tiny"] = dict(beit_version="base", encoder_embed_dim=128, out_embed_dim=64, encoder_layers=2, beit3_vl_layers=1,
+                                image_size=32, patch_size=8, vocab_size=300, max_text_len=12, encoder_attention_heads=2)
+    M2_TRAIN_GFLOP_PER_PAIR["tiny"] = 0.01
+
+
+class _Hw:
+    """The device plumbing main() needs.  Real: the MI355X through torch.cuda.  Dry run: the host, with a pretend 288-GiB device whose memory numbers send an
+    N > 1 run through choose_keep_ffn's probe arithmetic."""
+
+    def __init__(self, local_rank):
+        self.dry = DRY_RUN
+        if self.dry:
+            self.device, self.backend = torch.device("cpu"), "gloo"
+        else:
+            torch.cuda.set_device(local_rank)
+            self.device, self.backend = torch.device("cuda", local_rank), "nccl"
+
+    @staticmethod
+    def device_count():
+        return 64 if DRY_RUN else torch.cuda.device_count()
+
+    def sync(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def total_memory(self):
+        return 288 * 2 ** 30 if self.dry else torch.cuda.get_device_properties(self.device).total_memory
+
+    def reset_peak(self):
+        if not self.dry:
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+
+    def max_reserved(self):
+        return 2 ** 30 if self.dry else torch.cuda.max_memory_reserved()
+
+    def max_allocated(self):
+        return 2 ** 30 if self.dry else torch.cuda.max_memory_allocated()
+
+    def free_and_reserved(self):
+        if self.dry:
+            return 280 * 2 ** 30, 2 ** 30
+        return torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+
+    def init_process_group(self, rank, world):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not self.dry:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.device)
+            return
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        real = dist.reduce_scatter_tensor   # gloo has no reduce_scatter_tensor (RCCL has): all_reduce + slice, dry run only
+
+        def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            if dist.get_backend(group) != "gloo":
+                return real(output, input, op=op, group=group, async_op=async_op)
+            full = input.clone()
+            dist.all_reduce(full, op=op, group=group)
+            n = output.shape[0]
+            output.copy_(full[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
+
+        dist.reduce_scatter_tensor = reduce_scatter_tensor
+
 CLIP_B16 = dict(image_encoder=dict(type="VitImageEncoder", params=dict(model_name="ViT-B-16", input_resolution=224, patch_size=16, width=768,
                                                                        layers=12, out_dim=768, pretrained=False)),
                 text_encoder=dict(type="RobertBertEncoder", params=dict(pretrained=False, vocab_size=21128, hidden_size=768, intermediate_size=3072,
@@ -254,7 +322,7 @@ def make_trainer(a, device, world):
     from antmmf.hip.arena import HipAdamW
     from antmmf.trainers.base_trainer import BaseTrainer
 
-    tp = {"trainer": "base_trainer", "device": "cuda", "log_interval": 10 ** 9, "max_iterations": 10 ** 9, "seed": 1234, "lr_scheduler": True,
+    tp = {"trainer": "base_trainer", "device": device.type, "log_interval": 10 ** 9, "max_iterations": 10 ** 9, "seed": 1234, "lr_scheduler": True,
           "use_warmup": True, "warmup_iterations": 1000, "warmup_factor": 0.2, "clip_gradients": False}
     if a.workload in M2_WORKLOADS:
         from vlmo.config import default_config
@@ -299,7 +367,7 @@ def _self_launch(a):
     import socket
     import subprocess
 
-    have = torch.cuda.device_count()
+    have = _Hw.device_count()
     if have < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: this node exposes {have} GPU(s)")
     with socket.socket() as s:
@@ -313,14 +381,15 @@ def _self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def choose_keep_ffn(a, is_m2, batch_size, device, world, probe_step):
+def choose_keep_ffn(a, is_m2, batch_size, hw, world, probe_step):
     """Activation policy: keep fc2's 4d-wide input for backward when HBM allows.  N = 1: the l14 step peaks at 244 GiB
     reserved of 268 (measured, profiles/).  N > 1: RCCL's channel buffers and the bucket staging live OUTSIDE torch's allocator, so the
     decision is made from a measurement on this very process -- one step in recompute mode (`probe_step`), the bytes the kept activation adds
     on top of its peak (analytic), and what the device still has free next to torch's pool -- and agreed over all ranks (MIN)."""
     from antmmf.hip import functional
 
-    total = torch.cuda.get_device_properties(device).total_memory
+    device = hw.device
+    total = hw.total_memory()
     if a.recompute_ffn_norm:
         return False, "recompute (--recompute-ffn-norm)"
     if total < 250 * 2 ** 30 or (is_m2 and batch_size > 1024):
@@ -328,12 +397,12 @@ def choose_keep_ffn(a, is_m2, batch_size, device, world, probe_step):
     if world == 1:
         return True, "kept"
     functional.set_keep_ffn_norm(False)
-    torch.cuda.reset_peak_memory_stats()
+    hw.reset_peak()
     probe_step()
-    torch.cuda.synchronize()
-    reserved = torch.cuda.max_memory_reserved()
-    free, _ = torch.cuda.mem_get_info()
-    outside = total - free - torch.cuda.memory_reserved()        # RCCL buffers, HIP runtime, code objects
+    hw.sync()
+    reserved = hw.max_reserved()
+    free, reserved_now = hw.free_and_reserved()
+    outside = total - free - reserved_now                         # RCCL buffers, HIP runtime, code objects
     if is_m2:
         m = M2_WORKLOADS[a.workload]
         tokens = batch_size * ((m["image_size"] // m["patch_size"]) ** 2 + 1 + m["max_text_len"])
@@ -351,6 +420,31 @@ def choose_keep_ffn(a, is_m2, batch_size, device, world, probe_step):
     return keep, note
 
 
+def _gemm_clock_mhz(device):
+    """Effective shader clock while the persistent NT GEMM runs (outside the timed region): workgroup 0 of the kernel's clock-probe variant reads the
+    shader cycle counter and the constant 100-MHz counter around its whole run (variant bit 8 of the debug knob; restored afterwards)."""
+    import ctypes
+
+    from antmmf.hip import _lib, ops
+
+    try:
+        lib = _lib.load()
+        X = torch.randn(257 * 256, 1024, device=device).bfloat16()
+        W = (torch.randn(1024, 1024, device=device) * 0.03).bfloat16()
+        lib.antmmf_debug_set_gemm_variant(4 | 16384 | 256)
+        for _ in range(4):
+            ops.gemm(X, W)
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 2)()
+        rc = lib.antmmf_debug_gemm_clock(buf)
+        lib.antmmf_debug_set_gemm_variant(4)
+        if rc != 0 or buf[1] == 0:
+            return None
+        return round(buf[0] / (buf[1] / 100.0), 0)   # cycles per microsecond = MHz
+    except Exception:   # a probe must never cost the bench line
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -360,15 +454,14 @@ def main():
         _self_launch(a)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    hw = _Hw(local_rank)
+    device = hw.device
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        hw.init_process_group(rank, world)
 
     from antmmf.hip import _lib, functional, ops
 
-    assert _lib.backend() == 1, "bench.py must run on the gfx950 library"
+    assert hw.dry or _lib.backend() == 1, "bench.py must run on the gfx950 library"
     is_m2 = a.workload in M2_WORKLOADS
     batch_size = a.batch if a.batch is not None else (1024 if is_m2 else VTP_WORKLOADS[a.workload]["default_batch"])
     trainer = make_trainer(a, device, world)
@@ -389,10 +482,9 @@ def main():
     # activation-memory policy: fc2's 4d-wide input kept for backward instead of recomputed when the device has the HBM for it (the video
     # workloads peak at ~90 GiB without it, the M2 ones fit up to 1024 pairs); at N > 1 decided from a probe step (RCCL's buffers count)
     probe_loss = []
-    keep_ffn, keep_note = choose_keep_ffn(a, is_m2, batch_size, device, world, lambda: probe_loss.append(float(step().detach())))
+    keep_ffn, keep_note = choose_keep_ffn(a, is_m2, batch_size, hw, world, lambda: probe_loss.append(float(step().detach())))
     functional.set_keep_ffn_norm(keep_ffn)
-    torch.cuda.empty_cache()
-    torch.cuda.reset_peak_memory_stats()
+    hw.reset_peak()
 
     loss0 = probe_loss[0] if probe_loss else None   # (N > 1: the probe step was the first step of the run)
     for _ in range(a.warmup):
@@ -401,23 +493,24 @@ def main():
             loss0 = float(loss.detach())  # loss of the untouched random init: depends on the forward numerics only
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    ops.GEMM_TRACE = []
+    hw.sync()
+    ops.GEMM_TRACE = None if hw.dry else []   # (HIP events on the launch stream: none on the host)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
-    torch.cuda.synchronize()
+    hw.sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    hw.sync()
     elapsed = time.perf_counter() - t0
-    trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    trace, ops.GEMM_TRACE = (ops.GEMM_TRACE or []), None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
     meters = trainer.read_meters()
+    gemm_clock_mhz = _gemm_clock_mhz(device) if rank == 0 and not hw.dry else None
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -453,28 +546,34 @@ def main():
         metric = {"l14": "image-text pairs/sec/node, M2_Encoder ViT-L/14 ITC, global batch 8192",
                   "b16": "image-text pairs/sec/node, M2_Encoder ViT-B/16 ITC (BASELINE config 1; not the BASELINE metric)",
                   "vtp8": "video-text pairs/sec/node, base_vtp univl clip-arch ViT-B/16 + BERT-base, 8 clips, stage1 + stage2 cross-encoder (BASELINE config 3; not the BASELINE metric)",
-                  "dmae12": "video-text pairs/sec/node, dmae_vtp univl, 12 frames x 30 words, stage1 + stage3 NegNCE + TPM-CL (BASELINE config 4; not the BASELINE metric)"}[a.workload]
+                  "dmae12": "video-text pairs/sec/node, dmae_vtp univl, 12 frames x 30 words, stage1 + stage3 NegNCE + TPM-CL (BASELINE config 4; not the BASELINE metric)",
+                  "tiny": "dry run of the control flow (toy M2; not a metric)"}[a.workload]
         workload = {"l14": "M2_Encoder ViT-L/14 (beit large, patch 14, 21+3 layers) ITC train step, 224x224x3 + 77 tokens",
                     "b16": "M2_Encoder ViT-B/16 (beit base, 9+3 layers) ITC train step, 224x224x3 + 77 tokens",
                     "vtp8": "univl (clip arch) video-text train step: 8 clips x 224x224x3 per video + 77 tokens, MIL-NCE over all clips + cross-encoder scores of every text x video pair",
-                    "dmae12": "univl (DMAE) video-text train step: 12 frames x 224x224x3 per video + 30 words, MIL-NCE + seqTransf / WTI / NegNCE / TPM-CL"}[a.workload]
+                    "dmae12": "univl (DMAE) video-text train step: 12 frames x 224x224x3 per video + 30 words, MIL-NCE + seqTransf / WTI / NegNCE / TPM-CL",
+                    "tiny": "toy M2 (d = 128, 2 + 1 layers, 32 x 32 images, 12 tokens)"}[a.workload]
         out = {
             "metric": metric, "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
+            "data": "dry run (host, gloo, emulated kernels): not a measurement" if hw.dry else "synthetic",
             "config": {"workload": workload, "per_gpu_batch": batch_size, "global_batch": batch_size * world, "parallelism": f"dp{world}", "ranks_seen": ranks_seen,
                        "step": "BaseTrainer.train_step (forward, device-side meters, backward, arena all-reduce, fused AdamW, LR schedule)",
                        "loss": round(final_loss, 5), "meters": {k: round(v, 5) for k, v in meters.items()},
                        "train_gflop_per_pair": round(gflop_pair, 1), "step_tflops_per_gpu": round(step_tflops, 1),
                        "step_frac_of_bf16_peak": round(step_tflops / PEAK_TFLOPS, 4),
                        "loss_step0": None if loss0 is None else round(loss0, 5), "keep_ffn_norm": keep_ffn, "ffn_activation_policy": keep_note,
-                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                       "reserved_hbm_gib": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)},
+                       # N > 1: the gradient buckets of the last step in launch order (which went to RCCL from inside backward, which at the end, and when)
+                       "grad_buckets": getattr(trainer.arena, "last_bucket_log", None) if world > 1 else None,
+                       "peak_hbm_gib": round(hw.max_allocated() / 2 ** 30, 1),
+                       "reserved_hbm_gib": round(hw.max_reserved() / 2 ** 30, 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_k64p_kernel / gemm_tn_k64_kernel (bf16 MFMA GEMM family, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gemm_traffic_*.json); algorithmic bytes per launch = 2(I R + J R + I J)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),
                          "avg_launch_gflop": round(gemm_flops / n / 1e9, 2), "avg_launch_algorithmic_bytes": int(gemm_bytes / n), "gemm_ms_per_step": round(gemm_ms / a.steps, 2),
-                         "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0}},
+                         "by_layout_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_layout.items() if v[1] > 0},
+                         # shader clock under the MFMA loop on THIS box (the pool's boxes differ by +-4 % at identical code: compare runs at equal clock)
+                         "gemm_clock_mhz": gemm_clock_mhz},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_sample)

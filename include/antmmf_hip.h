@@ -14,7 +14,10 @@
  *  - dtype tags: ANTMMF_F32 = 0, ANTMMF_BF16 = 1 (bf16 = upper 16 bits of an IEEE fp32, RNE);
  *  - every function enqueues on `stream` (a hipStream_t; pass torch's current stream) and returns
  *    0, or a negative errno-style code (-22 bad argument, -5 launch failure); nothing throws;
- *  - re-entrant, no global state; one process per GPU.
+ *  - re-entrant; one process per GPU.  The entry points declared here keep no state between calls (beyond per-kernel launch attributes set once).
+ *    The library also exports a few `antmmf_debug_*` symbols that are deliberately NOT declared here: process-global A/B switches
+ *    (antmmf_debug_set_gemm_variant; the same knob as the ANTMMF_GEMM_VARIANT environment variable) and launch counters read by the tests and
+ *    by tools/gemm_bench.cpp.  They are measurement infrastructure, not ABI: nothing on the product path calls them, and a binding must not.
  */
 #ifndef ANTMMF_HIP_H
 #define ANTMMF_HIP_H

@@ -67,6 +67,16 @@ def case_dark_clip_keeps_reference_semantics(dev):
     _close(proc(dark.to(dev)), oframes.frame_processor(dark, 32, MEAN, STD), "dark")
     bright = dark.clone(); bright[0, 0, 3, 3] = 200
     _close(proc(bright.to(dev)), oframes.frame_processor(bright, 32, MEAN, STD), "bright")
+    # detectron2-style statistics (means on the 0..255 scale): NO division by 255 although the frames exceed 1 (image_ops.py:99-104)
+    m255, s255 = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    proc255 = Processor({"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+        {"type": "ImageLongsideScaleAndPad", "params": {"max_size": 32}}, {"type": "GroupNormalize", "params": {"mean": m255, "std": s255}}]}})
+    fr = _frames(2, 20, 24, 9)
+    _close(proc255(fr.to(dev)), oframes.frame_processor(fr, 32, m255, s255), "means > 1")
+    # frames that are not on the library's device / already float take the reference's own host arithmetic (a dataloader worker)
+    if dev.type == "cuda":
+        _close(proc(bright), oframes.frame_processor(bright, 32, MEAN, STD), "host frames")
+    _close(proc(bright.float().to(dev)), oframes.frame_processor(bright, 32, MEAN, STD), "float frames")
     return "ok"
 
 

@@ -527,6 +527,36 @@ def test_m2_step_two_ranks_equals_single_rank(mode):
         assert int(bad.sum()) <= max(1, diff.numel() // 100000) and float(diff.max()) <= 2e-2, (int(bad.sum()), float(diff.max()))
 
 
+def test_bench_two_ranks_dry_run():
+    """`python bench.py --gpus 2` end to end where there are no GPUs -- bench.py's dry-run mode (host, gloo, lane-emulated kernels, a toy M2)
+    goes through its own self-launch (torch.distributed.run on 127.0.0.1), the rendezvous, choose_keep_ffn's probe step and the all-reduced decision, the
+    trainer's step with the arena all-reduce, the barriers and the max-over-ranks timing, and rank 0 prints ONE JSON line with the contract's keys."""
+    import json
+    import subprocess
+
+    from test_kernels_emu import _stale
+
+    if _stale():
+        subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+    env = dict(os.environ, ANTMMF_BENCH_DRY_RUN="1", ANTMMF_ALLOW_EMULATOR="1", ANTMMF_HIP_LIB=os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tiny", "--batch", "2",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak" and j["config"]["ranks_seen"] == 2 and j["config"]["global_batch"] == 4
+    assert "dry run" in j["data"] and "probe" in j["config"]["ffn_activation_policy"]     # N > 1: the policy came from the probe step
+    log = j["config"]["grad_buckets"]                                                       # the step's bucket launch order made it into the line
+    assert log and sorted(e["bucket"] for e in log) == list(range(len(log))) and all(e["when"] in ("bwd", "end") for e in log)
+    assert j["config"]["loss"] == j["config"]["loss"] and j["value"] > 0
+
+
 def test_bench_self_launches_n_ranks(monkeypatch):
     """`python bench.py --gpus N` without a launcher (how the driver may call it): bench.py starts N ranks of itself under
     torch.distributed.run on 127.0.0.1 and returns that job's exit code; it refuses when the node has fewer GPUs."""
