@@ -473,12 +473,13 @@ def _m2_step_case(rank, world):
     dev = torch.device("cpu")
     model = mc.build_tiny_m2(dev)
     opt = HipAdamW([{"params": list(model.parameters())}], lr=1e-2, weight_decay=0.01)
-    img = (W.data_tensor("m2dp.image", (4, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1)
-    ids = W.data_ints("m2dp.ids", (4, 12), 1, 300)
-    lengths = torch.tensor([12, 5, 8, 3])
+    pairs = int(os.environ.get("ANTMMF_TEST_DP_PAIRS", "4"))
+    img = (W.data_tensor("m2dp.image", (pairs, 3, 32, 32)) * 0.25 + 0.5).clamp(0, 1)
+    ids = W.data_ints("m2dp.ids", (pairs, 12), 1, 300)
+    lengths = torch.tensor([12, 5, 8, 3, 7, 12, 4, 9])[:pairs]
     mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
     ids = ids * mask
-    per = 4 // world
+    per = pairs // world
     sl = slice(rank * per, (rank + 1) * per)
     mode = os.environ.get("ANTMMF_TEST_DP_MODE", "overlap")
     if world > 1 and mode != "plain":
@@ -525,6 +526,31 @@ def test_m2_step_two_ranks_equals_single_rank(mode):
         diff = (two[0]["master"] - one["master"]).abs()
         bad = diff > (1e-5 + 1e-4 * one["master"].abs())
         assert int(bad.sum()) <= max(1, diff.numel() // 100000) and float(diff.max()) <= 2e-2, (int(bad.sum()), float(diff.max()))
+
+
+@pytest.mark.parametrize("world", [4, pytest.param(8, marks=_SLOW)])
+def test_m2_step_many_ranks_equals_single_rank(world):
+    """The 4- and 8-rank twins of test_m2_step_two_ranks_equals_single_rank: one pair per rank -- rank offsets row0 = rank * B, the x W
+    factor of the embedding gradients, the packed gather / reduce-scatter and the bucketed all-reduce started from inside backward with more than two
+    participants -- equal the single-rank step on the whole batch."""
+    os.environ["ANTMMF_TEST_DP_MODE"] = "overlap"
+    os.environ["ANTMMF_TEST_DP_PAIRS"] = str(world)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            fn = ex.submit(_spawn, _m2_step_case, 29681 + world, world)
+            f1 = ex.submit(_spawn, _m2_step_case, 29691 + world, 1)
+            many, one = fn.result(), f1.result()[0]
+    finally:
+        os.environ.pop("ANTMMF_TEST_DP_MODE", None)
+        os.environ.pop("ANTMMF_TEST_DP_PAIRS", None)
+    assert many[0]["world"] == world and one["world"] == 1
+    for r in range(1, world):
+        assert abs(many[0]["loss"] - many[r]["loss"]) < 1e-6
+        torch.testing.assert_close(many[0]["master"], many[r]["master"], rtol=0, atol=0)      # replicas bit-identical
+    assert abs(many[0]["loss"] - one["loss"]) <= 2e-5 * abs(one["loss"])
+    torch.testing.assert_close(many[0]["grad"], one["grad"], rtol=1e-3, atol=1e-5 * float(one["grad"].abs().max()))
+    assert many[0]["nbuckets"] >= 4 and many[0]["overlapped"] >= 1
 
 
 def test_bench_two_ranks_dry_run():
