@@ -49,9 +49,23 @@ __global__ __launch_bounds__(256) void milnce_fwd_kernel(const float* __restrict
     const float logn = __logf((float)n_pair);
     MS acc; acc.m = -INFINITY; acc.s = 0.f;
     const float* r = Rm + (long)i * Wr;
-    for (int c = threadIdx.x; c < Wr; c += 256) if (c / n_pair != gi) ms_add(acc, r[c]);
     const float* cm = Cm + (long)i * Wc;
-    for (int t = threadIdx.x; t < Wc; t += 256) ms_add(acc, cm[t] + logn);
+    if (((Wr | Wc) & 3) == 0) {
+        for (int c = threadIdx.x * 4; c < Wr; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(r + c);
+            if (c / n_pair != gi) ms_add(acc, v.x);
+            if ((c + 1) / n_pair != gi) ms_add(acc, v.y);
+            if ((c + 2) / n_pair != gi) ms_add(acc, v.z);
+            if ((c + 3) / n_pair != gi) ms_add(acc, v.w);
+        }
+        for (int t = threadIdx.x * 4; t < Wc; t += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(cm + t);
+            ms_add(acc, v.x + logn); ms_add(acc, v.y + logn); ms_add(acc, v.z + logn); ms_add(acc, v.w + logn);
+        }
+    } else {
+        for (int c = threadIdx.x; c < Wr; c += 256) if (c / n_pair != gi) ms_add(acc, r[c]);
+        for (int t = threadIdx.x; t < Wc; t += 256) ms_add(acc, cm[t] + logn);
+    }
     const MS tot = block_ms(acc, sh);
     if (threadIdx.x == 0) {
         const float d = tot.m + __logf(tot.s);
@@ -65,6 +79,23 @@ __global__ __launch_bounds__(256) void milnce_bwd_kernel(const float* __restrict
                                                          TO* __restrict__ dRm, TO* __restrict__ dCm) {
     const int i = blockIdx.x, gi = row_offset + i;
     const float d = denom[i], k = coef[i], logn = __logf((float)n_pair);
+    if (((Wr | Wc) & 3) == 0 && sizeof(TO) == 4) {
+        for (int c = threadIdx.x * 4; c < Wr; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(Rm + (long)i * Wr + c);
+            float4 o;
+            o.x = (c / n_pair != gi) ? k * __expf(v.x - d) : 0.f; o.y = ((c + 1) / n_pair != gi) ? k * __expf(v.y - d) : 0.f;
+            o.z = ((c + 2) / n_pair != gi) ? k * __expf(v.z - d) : 0.f; o.w = ((c + 3) / n_pair != gi) ? k * __expf(v.w - d) : 0.f;
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dRm) + (long)i * Wr + c) = o;
+        }
+        for (int t = threadIdx.x * 4; t < Wc; t += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(Cm + (long)i * Wc + t);
+            float4 o;
+            o.x = k * (__expf(v.x + logn - d) - (t == gi ? 1.f : 0.f)); o.y = k * (__expf(v.y + logn - d) - (t + 1 == gi ? 1.f : 0.f));
+            o.z = k * (__expf(v.z + logn - d) - (t + 2 == gi ? 1.f : 0.f)); o.w = k * (__expf(v.w + logn - d) - (t + 3 == gi ? 1.f : 0.f));
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dCm) + (long)i * Wc + t) = o;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < Wr; c += 256)
         st1<TO>(dRm + (long)i * Wr + c, (c / n_pair != gi) ? k * __expf(Rm[(long)i * Wr + c] - d) : 0.f);
     for (int t = threadIdx.x; t < Wc; t += 256)
@@ -79,7 +110,14 @@ __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __rest
     const float sc = scale_mul * (log_scale ? __expf(*log_scale) : 1.0f);
     MS acc; acc.m = -INFINITY; acc.s = 0.f;
     const float* r = x + (long)i * W;
-    for (int c = threadIdx.x; c < W; c += 256) ms_add(acc, sc * r[c]);
+    if ((W & 3) == 0) {   // 16-B loads (rows start 16-B aligned then): a [1024 x 8192] slab of the global-batch loss streams at HBM rate
+        for (int c = threadIdx.x * 4; c < W; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(r + c);
+            ms_add(acc, sc * v.x); ms_add(acc, sc * v.y); ms_add(acc, sc * v.z); ms_add(acc, sc * v.w);
+        }
+    } else {
+        for (int c = threadIdx.x; c < W; c += 256) ms_add(acc, sc * r[c]);
+    }
     const MS tot = block_ms(acc, sh);
     if (threadIdx.x == 0) {
         const float l = tot.m + __logf(tot.s);
@@ -97,12 +135,20 @@ __global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const float* __rest
     const float sc = scale_mul * (log_scale ? __expf(*log_scale) : 1.0f);
     const float l = lse[i], k = coef[i];
     float ds = 0.f;
-    for (int c = threadIdx.x; c < W; c += 256) {
-        const float xv = x[(long)i * W + c];
-        if (xv == -INFINITY) { st1<TO>(dx + (long)i * W + c, 0.f); continue; }   // masked column (padding rows of a ragged global batch): no probability, no gradient
+    auto one = [&](int c, float xv) -> float {
+        if (xv == -INFINITY) return 0.f;   // masked column (padding rows of a ragged global batch): no probability, no gradient
         const float p = __expf(sc * xv - l) - (c == gi ? 1.f : 0.f);
-        st1<TO>(dx + (long)i * W + c, k * sc * p);
         ds += p * xv;
+        return k * sc * p;
+    };
+    if ((W & 3) == 0 && sizeof(TO) == 4) {   // fp32 in / fp32 out, 16-B accesses
+        for (int c = threadIdx.x * 4; c < W; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long)i * W + c);
+            float4 o; o.x = one(c, v.x); o.y = one(c + 1, v.y); o.z = one(c + 2, v.z); o.w = one(c + 3, v.w);
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dx) + (long)i * W + c) = o;
+        }
+    } else {
+        for (int c = threadIdx.x; c < W; c += 256) st1<TO>(dx + (long)i * W + c, one(c, x[(long)i * W + c]));
     }
     if (dscale) {
         const float tot = block_sum(ds, sh);
