@@ -1520,11 +1520,14 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 //   * the prologue loads K-tile 0 and the Q half of K-tile 1 (what the steady-state refill schedule does not bring itself), so the first
 //     K-tile issues the same operations as every other; the last tile's look-ahead refills wrap to its own first K-tiles (harmless re-reads,
 //     drained before the kernel ends) instead of the two special wait ladders of the kernel above.
-// Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual.
+// Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual; 5 = bias + activation with TWO outputs (the
+// activation -> C, its derivative or the pre-activation -> aux: the forward of a feed-forward whose activation output is kept for backward; g.act at run time);
+// 21 = the same plus per-row (sum z, sum z^2) of the rounded activation over the wave's 64 columns -> g.part (fc1 of the sub-LN fold, GemmArgs::ffn_mode 1).
 #ifdef ANTMMF_EMULATE
 #define K64R_GLOAD16(dst, voff, sbase, OFF) dst = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sbase) + (voff) + (OFF))
 #define K64R_GSTORE16(voff, val, sbase, OFF) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(sbase) + (voff) + (OFF)) = (val)
 #define K64R_GSTORE16_NT K64R_GSTORE16
+#define K64R_GSTORE8(voff, val, sbase) *reinterpret_cast<k64_u2_t*>(reinterpret_cast<char*>(sbase) + (voff)) = (val)
 #define K64R_VMFENCE4(N, a) do {} while (0)
 #define K64R_VMWAIT(N) do {} while (0)
 #define K64R_LREAD16(dst, addr, OFF) dst = *reinterpret_cast<const f32x4_t*>(smem + (addr) + (OFF))
@@ -1537,6 +1540,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 // write-back store is acknowledged by the L2; measured against nt / sc0 / sc0 nt / sc1 / sc1 nt / sc0 sc1 in profiles/r4_gemm_rolling_epilogue_ab.txt)
 #define K64R_GSTORE16(voff, val, sbase, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(val), "s"(sbase), "n"(OFF) : "memory")
 #define K64R_GSTORE16_NT(voff, val, sbase, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" :: "v"(voff), "v"(val), "s"(sbase), "n"(OFF) : "memory")
+#define K64R_GSTORE8(voff, val, sbase) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(val), "s"(sbase) : "memory")
 #define K64R_VMFENCE4(N, a) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory")
 #define K64R_VMWAIT(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
 #define K64R_LREAD16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds0 + (addr)), "n"(OFF))
@@ -1548,6 +1552,8 @@ template <int EPI> struct K64RWaits;
 template <> struct K64RWaits<0> { static constexpr int W[3][4] = {{24, 25, 26, 7}, {8, 9, 10, 7}, {8, 13, 18, 19}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 0; };
 template <> struct K64RWaits<1> { static constexpr int W[3][4] = {{25, 25, 26, 7}, {8, 9, 10, 7}, {9, 14, 19, 20}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 24; };
 template <> struct K64RWaits<2> { static constexpr int W[3][4] = {{40, 41, 42, 11}, {8, 9, 10, 7}, {8, 17, 26, 31}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 0; };
+template <> struct K64RWaits<21> { static constexpr int W[3][4] = {{49, 49, 50, 7}, {8, 9, 10, 7}, {9, 20, 31, 38}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 48; };   // 8 stores + 2 row-sum stores per quarter
+template <> struct K64RWaits<5> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };
 template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
 
 // ABL (ablations, variant bits 15 / 16): 1 = the converted rows are not stored (timing only: the ladders count the stores), 4 = non-temporal stores
@@ -1556,7 +1562,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     ANTMMF_DYN_LDS(char, smem);
     constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
     constexpr int STAGE = 65536, QOFF = 32768, BIASOFF = 2 * STAGE;
-    constexpr bool BIAS = EPI & 1, RES = EPI & 2;
+    constexpr bool BIAS = EPI & 1, RES = (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
     using WT = K64RWaits<EPI>;
     const int lane = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
@@ -1623,6 +1629,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     // per-lane byte offsets of the row-layout accesses (row l15 of a 16-row fragment, 8 consecutive columns at (lane >> 5) * 16 + (grp & 1) * 8; + 64 B for the second column pair)
     const uint32_t cvoff = (uint32_t)((l15 * (int)g.ldc + (lane >> 5) * 16 + (grp & 1) * 8) * 2);
     const uint32_t rvoff = RES ? (uint32_t)((l15 * (int)g.ldr + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
+    const uint32_t avoff = ACT2 ? (uint32_t)((l15 * (int)g.ldaux + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const int pbg = ((grp & 1) << 1) | (grp >> 1);
     u32x4_t rv[4][4] = {};   // residual vectors of row quarter q, in flight between the store of the previous tile's quarter q and this tile's phase q
     f32x4_t bf[4] = {};      // bias fragment of the current tile (live across its first K-tile only)
@@ -1667,17 +1674,42 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
             const int it = 2 * (QQ) + ih;                                                                                           \
             char* cb = reinterpret_cast<char*>(g.C) + ((long)((ti0) + wi * 128 + it * 16) * g.ldc + (tj0) + wj * 64) * 2;           \
+            f2_t t1 = f2_splat(0.f), t2 = f2_splat(0.f);   /* FFN1: row sums of the ROUNDED activation (what fc2 multiplies) */      \
             _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
-                u32x4_t ov;                                                                                                         \
+                u32x4_t ov, av;                                                                                                     \
                 _Pragma("unroll") for (int rr = 0; rr < 4; rr += 2) {                                                               \
                     const k64_u2_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][2 * p2][rr]), __float_as_uint(acc[it][2 * p2 + 1][rr]), false, false); \
                     const k64_u2_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[it][2 * p2][rr + 1]), __float_as_uint(acc[it][2 * p2 + 1][rr + 1]), false, false); \
-                    ov[rr >> 1] = pack_bf2(__uint_as_float(s0[0]), __uint_as_float(s1[0]));                                         \
-                    ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                                   \
+                    if (ACT2) {   /* two column pairs: activation and derivative out of one evaluation each (packed fp32 math) */           \
+                        const f2_t u0 = (f2_t){__uint_as_float(s0[0]), __uint_as_float(s1[0])}, u1 = (f2_t){__uint_as_float(s0[1]), __uint_as_float(s1[1])}; \
+                        f2_t z0, d0, z1, d1;                                                                                        \
+                        act_fwd_grad2<-1>(u0, g.act, z0, d0);                                                                       \
+                        act_fwd_grad2<-1>(u1, g.act, z1, d1);                                                                       \
+                        ov[rr >> 1] = pack_bf2(z0.x, z0.y); ov[2 + (rr >> 1)] = pack_bf2(z1.x, z1.y);                               \
+                        av[rr >> 1] = g.aux_grad ? pack_bf2(d0.x, d0.y) : pack_bf2(u0.x, u0.y);                                     \
+                        av[2 + (rr >> 1)] = g.aux_grad ? pack_bf2(d1.x, d1.y) : pack_bf2(u1.x, u1.y);                               \
+                    } else {                                                                                                        \
+                        ov[rr >> 1] = pack_bf2(__uint_as_float(s0[0]), __uint_as_float(s1[0]));                                     \
+                        ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                               \
+                    }                                                                                                               \
+                }                                                                                                                   \
+                if (ACT2) {                                                                                                         \
+                    char* ab = reinterpret_cast<char*>(g.aux) + ((long)((ti0) + wi * 128 + it * 16) * g.ldaux + (tj0) + wj * 64) * 2; \
+                    if (p2 == 0) K64R_GSTORE16(avoff, av, ab, 0); else K64R_GSTORE16(avoff, av, ab, 64);                            \
+                }                                                                                                                   \
+                if (FFN1) {                                                                                                         \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) { const f2_t zr = f2_bf(ov[e]); t1 += zr; t2 += zr * zr; }        \
                 }                                                                                                                   \
                 if (ABL & 1) K64R_KEEP(ov);                                                                                         \
                 else if (ABL & 4) { if (p2 == 0) K64R_GSTORE16_NT(cvoff, ov, cb, 0); else K64R_GSTORE16_NT(cvoff, ov, cb, 64); }         \
                 else if (p2 == 0) K64R_GSTORE16(cvoff, ov, cb, 0); else K64R_GSTORE16(cvoff, ov, cb, 64);                           \
+                SCHED_FENCE();                                                                                                      \
+            }                                                                                                                       \
+            if (FFN1) {   /* close the row over its four lanes; all four write the same 8 bytes (no exec mask inside the asm store) */ \
+                const float r1 = rows4_sum(t1.x + t1.y), r2 = rows4_sum(t2.x + t2.y);                                               \
+                char* pb2 = reinterpret_cast<char*>(g.part) + ((long)(((tj0) + wj * 64) >> 6) * g.I + (ti0) + wi * 128 + it * 16) * 8; \
+                const k64_u2_t pv2 = {__float_as_uint(r1), __float_as_uint(r2)};                                                    \
+                K64R_GSTORE8((uint32_t)(l15 * 8), pv2, pb2);                                                                        \
                 SCHED_FENCE();                                                                                                      \
             }                                                                                                                       \
         }                                                                                                                           \
@@ -2235,6 +2267,16 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \
     } while (0)
+        if (k64p && aux && bias && !gate && !residual && act != ANTMMF_ACT_NONE && alpha == 1.0f && R >= 192 && !(g_gemm_variant & 16384)) {
+            // forward of a feed-forward whose activation output is kept (CLIP / BERT layers of the video workloads, keep-FFN policy): bias + activation with two outputs on
+            // the rolling-epilogue kernel -- the generic burst epilogue ran this shape at 0.27 of peak (two output tensors per tile behind an idle matrix pipe)
+            ++g_k64_launches;
+            const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);
+            const unsigned gridp = pwgs < t8 ? pwgs : t8;
+            static bool once5 = false;
+            if (!once5) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once5 = true; }
+            hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+        } else
         if (k64p && gate && g.gate_grad && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {
             // out = acc * gate on the register-level epilogue of the residual kernels (16 gate vectors requested up front) instead of the generic one
             ++g_k64_launches;
@@ -2349,7 +2391,13 @@ static int gemm_ffn_launch(GemmArgs& g, hipStream_t stream) {
         if (!oncep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64p_kernel<E_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); oncep = true; } \
         hipLaunchKernelGGL((gemm_nt_k64p_kernel<E_, F_>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);              \
     } while (0)
-    if (g.ffn_mode == 1) FFN_LAUNCH(16, K64F_ONEBAR | K64F_PRIO);
+    if (g.ffn_mode == 1 && g.R >= 192 && !(g_gemm_variant > 0 && (g_gemm_variant & 16384))) {   // fc1 of the fold: the rolling two-output epilogue + row sums
+        static bool once21 = false;
+        if (!once21) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<21, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once21 = true; }
+        g.aux_grad = 1;
+        hipLaunchKernelGGL((gemm_nt_k64r_kernel<21, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+    }
+    else if (g.ffn_mode == 1) FFN_LAUNCH(16, K64F_ONEBAR | K64F_PRIO);
     else if (g.ffn_mode == 2) FFN_LAUNCH(32, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
     else FFN_LAUNCH(64, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
 #undef FFN_LAUNCH

@@ -44,5 +44,22 @@ for tokens in (257 * pairs, 77 * pairs):
         ok = nd == 0 and (ndiff == 0 if not (bias or res) else ndiff < y0.numel() * 1e-3) and e1 <= max(2 * e0, 0.26)
         bad += 0 if ok else 1
         print({"shape": tag, "tokens": tokens, "J": J, "R": R, "self_mismatch": nd, "vs_product_ndiff": ndiff, "vs_product_max": maxd, "err_product": e0, "err_variant": e1, "ok": ok}, flush=True)
+# the two-output activation epilogue (forward of the CLIP / BERT feed-forwards of the video workloads)
+for (tokens, J, R, act) in ((4096 * 86, 3072, 768, "gelu"), (512 * 197, 3072, 768, "quick_gelu")):
+    X = torch.randn(tokens, R, generator=g, device=dev).bfloat16()
+    W = (torch.randn(J, R, generator=g, device=dev) * R ** -0.5).bfloat16()
+    b = torch.randn(J, generator=g, device=dev)
+    res = []
+    for v in (4 | 16384, variant, variant, variant):
+        lib.antmmf_debug_set_gemm_variant(v)
+        aux = torch.empty(tokens, J, dtype=torch.bfloat16, device=dev)
+        y = ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)
+        res.append((y, aux))
+    lib.antmmf_debug_set_gemm_variant(4)
+    nd = sum(int((res[k][0] != res[1][0]).sum()) + int((res[k][1] != res[1][1]).sum()) for k in (2, 3))
+    dy = float((res[0][0].float() - res[1][0].float()).abs().max()); da = float((res[0][1].float() - res[1][1].float()).abs().max())
+    ok = nd == 0 and dy <= 0.07 and da <= 0.02
+    bad += 0 if ok else 1
+    print({"shape": "ffn_fwd_" + act, "tokens": tokens, "J": J, "R": R, "self_mismatch": nd, "vs_burst_max_y": dy, "vs_burst_max_aux": da, "ok": ok}, flush=True)
 print("RACE SCREEN", "FAILED" if bad else "clean", "variant", variant)
 sys.exit(1 if bad else 0)

@@ -8,13 +8,13 @@ Issue order per phase ph of a K-tile (role T0 = first K-tile of an output tile, 
     hook:  T0, ph 0: [4 stores: row quarter 3 of the previous tile] [4 residual loads: quarter 3 of this tile]
            T0, ph q: wait for the residual vectors of quarter q (issued in the previous tile's TE, or in T0 ph 0 for q = 3), initialise its accumulators
            TE, ph 0: [1 DMA: the next tile's bias strip]
-           TE, ph q + 1 (q = 0 .. 2): 4 stores (quarter q) then 4 residual loads (quarter q of the NEXT tile)
+           TE, ph q + 1 (q = 0 .. 2): 4 stores (quarter q; 8 for the two-output activation epilogue) then 4 residual loads (quarter q of the NEXT tile)
     end-of-phase wait: phase ph + 1's fragment reads  (ph 0 .. 2: P quarter ph + 1 of this K-tile = piece ph + 1 of the previous K-tile;
                                                        ph 3: P quarter 0 of the next K-tile = piece 0 of this K-tile; its Q pieces are older)
 The prologue (K-tile 0 whole, Q of K-tile 1, bias strip, residual quarters 0 - 2 of the first tile) is drained with vmcnt(0) and not modelled."""
 
 
-def ladder(res, bias, nks=(3, 4, 5, 6, 9), tiles=3):
+def ladder(res, bias, nks=(3, 4, 5, 6, 9), tiles=3, stores=4):
     waits, inits, biasw = {}, {}, {}
     for nk in nks:
         ops = []
@@ -32,7 +32,7 @@ def ladder(res, bias, nks=(3, 4, 5, 6, 9), tiles=3):
                     for idx in (2 * ph, 2 * ph + 1):
                         pos[(gt, idx)] = len(ops); ops.append("piece")
                     if k == "T0" and ph == 0:
-                        if tile > 0: ops += ["store"] * 4
+                        if tile > 0: ops += ["store"] * stores
                         if res:
                             ops += ["resload"] * 4; rv_last[(tile, 3)] = len(ops) - 1
                         if bias and tile in bias_pos:   # the bias strip is read behind this point
@@ -42,7 +42,7 @@ def ladder(res, bias, nks=(3, 4, 5, 6, 9), tiles=3):
                     if k == "TE" and ph == 0 and bias:
                         ops.append("biasdma"); bias_pos[tile + 1] = len(ops) - 1
                     if k == "TE" and ph >= 1:
-                        ops += ["store"] * 4
+                        ops += ["store"] * stores
                         if res:
                             ops += ["resload"] * 4; rv_last[(tile + 1, ph - 1)] = len(ops) - 1
                     need = {0: (gt - 1, 1), 1: (gt - 1, 2), 2: (gt - 1, 3), 3: (gt, 0)}[ph]
@@ -59,3 +59,7 @@ if __name__ == "__main__":
         print("   W = {" + ", ".join("{" + ", ".join(str(w[(k, ph)]) for ph in range(4)) + "}" for k in ("T0", "TR", "TE")) + "}   (T0, TR, TE)")
         if i: print("   INIT = {%s}" % ", ".join(str(i[q]) for q in range(4)))
         if b: print("   BIASW = %d" % b["T0"])
+    w, i, b = ladder(0, 1, stores=8)
+    print("EPI=5 (bias + activation, two outputs: 8 stores per row quarter)")
+    print("   W = {" + ", ".join("{" + ", ".join(str(w[(k, ph)]) for ph in range(4)) + "}" for k in ("T0", "TR", "TE")) + "}   (T0, TR, TE)")
+    print("   BIASW = %d" % b["T0"])
