@@ -47,6 +47,7 @@ _SIGNATURES = {
     "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, F, U64, P],
     "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
     "antmmf_attention_fwd_hd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, F, U64, P],
+    "antmmf_attention_key_importance": [P, P, P, P, P, I, I, I, I, L, L, F, F, U64, F, P],
     "antmmf_attention_bwd_hd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
     "antmmf_milnce_fwd": [P, P, I, I, I, I, I, P, P, P],
     "antmmf_milnce_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P],

@@ -363,6 +363,11 @@ def set_keep_ffn_norm(flag):
 FFN_FOLD = os.environ.get("ANTMMF_FFN_FOLD", "0") == "1"
 
 
+# Collector for the one thing the reference does with attention MAPS on this path (univl_video_base.py:131-143: words_importance = sum over layers of the
+# head-mean attention, summed over the queries): a [B, N] fp32 tensor while a BertEncoder runs with output_attentions=True, None otherwise.
+KEY_IMPORTANCE = None
+
+
 def set_ffn_fold(flag):
     global FFN_FOLD
     FFN_FOLD = bool(flag)
@@ -402,6 +407,8 @@ class _TransformerLayer(torch.autograd.Function):
         del h
         q3 = qkv.view(B, N, 3 * d)
         o, lse = ops.attention_fwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], spec.heads, scale, key_bias, p_att, seed)
+        if KEY_IMPORTANCE is not None:   # `output_attentions=True` callers: the head-mean column sums of this layer's probabilities join the collector
+            ops.attention_key_importance_(KEY_IMPORTANCE, q3[..., :d], q3[..., d:2 * d], lse, spec.heads, scale, key_bias, p_att, seed or 0, weight=1.0 / spec.heads)
         o2 = o.view(T, d)
         st_in = None
         if spec.kind == "m2":

@@ -502,6 +502,17 @@ def attention_fwd(q, k, v, heads, scale, key_bias=None, dropout_p=0.0, dropout_s
     return o, lse
 
 
+def attention_key_importance_(out, q, k, lse, heads, scale, key_bias=None, dropout_p=0.0, dropout_seed=0, weight=1.0):
+    """out [B, Nk] fp32 += weight * sum over heads and queries of the attention probabilities of (q, k) -- see antmmf_attention_key_importance."""
+    _dev_ok(out, q, k, lse, key_bias); _f32(out, "out"); _c(out, "out"); _c(lse, "lse")
+    B, Nq, D = q.shape
+    Nk = k.shape[1]
+    assert _head_dim(D, heads) == 64 and tuple(out.shape) == (B, Nk)
+    _rc(_lib.load().antmmf_attention_key_importance(_p(q), _p(k), _p(key_bias), _p(lse), _p(out), B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), float(scale),
+                                                    float(dropout_p), int(dropout_seed), float(weight), _stream()), "antmmf_attention_key_importance")
+    return out
+
+
 def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dropout_p=0.0, dropout_seed=0):
     _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
     B, Nq, D = q.shape

@@ -8,8 +8,9 @@ HF BertModel names (embeddings.word_embeddings ... encoder.layer.N.attention.sel
 `pytorch_model.bin` / `model.safetensors` of a BERT checkpoint loads key for key (a leading `bert.` is dropped; heads the model does not
 have -- `cls.*` -- are ignored).  Same constructor arguments, same attributes (`embeddings`, `encoder`, `pooler`, `module`, `config`),
 same forward triple.  Differences, stated: nothing is downloaded (a missing checkpoint directory is an error); `output_attentions=True`
-returns no attention maps (they never reach HBM on the fused path: the caller's `words_importance` -- consumed only by the pretraining
-head's masking -- is None); `model_type` other than "bert" is out of scope."""
+returns, in the place of the attention maps (which never reach HBM on the fused path), their reduction `KeyImportance` -- the sum over layers of
+the head-mean attention summed over the queries, which is all the caller derives from them (`words_importance`, univl_video_base.py:138-143);
+`model_type` other than "bert" is out of scope."""
 import json
 import os
 import warnings
@@ -64,7 +65,10 @@ class _FusedBert(BertModel):
             attention_mask = torch.ones(ref.shape[:2], dtype=torch.long, device=ref.device)
         key_bias = (1.0 - attention_mask.float()) * -10000.0
         x = self.embeddings(input_ids=input_ids, inputs_embeds=inputs_embeds, token_type_ids=token_type_ids, position_ids=position_ids)
-        seq = self.encoder(x, key_bias, head_mask=None)[0]
+        enc = self.encoder(x, key_bias, head_mask=None, output_attentions=output_attentions)
+        seq = enc[0]
+        if output_attentions:   # third output: modeling_bert.KeyImportance in the place of the attention maps (see BertEncoder.forward)
+            return seq, self.pooler(seq), enc[-1]
         return seq, self.pooler(seq)
 
 

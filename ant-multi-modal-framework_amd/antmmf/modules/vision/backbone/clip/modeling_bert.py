@@ -108,18 +108,37 @@ class BertEncoder(nn.Module):
         self.grad_checkpointing = False
         self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
 
-    def forward(self, hidden_states, attention_mask=None, head_mask=None):
-        if self.output_attentions:
-            raise NotImplementedError("attention maps never reach HBM on the fused path (output_attentions=True)")
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, output_attentions=None):
+        """output_attentions (constructor flag or call argument): the attention MAPS of the reference ([B, heads, N, N] per layer, modeling_bert.py:283-314)
+        never reach HBM on the fused path.  What comes back in their place is the reduction their only consumer on this path applies
+        (UnivlVideoBase.forward_text_encoder, univl_video_base.py:138-143): `KeyImportance` = sum over layers of the head-mean attention summed over the
+        queries, a [B, N] fp32 tensor gathered by the attention kernels' sibling antmmf_attention_key_importance (post-dropout probabilities, as HF returns)."""
+        want_att = self.output_attentions if output_attentions is None else bool(output_attentions)
         all_hidden = ()
-        for layer in self.layer:
-            if self.output_hidden_states:
-                all_hidden = all_hidden + (hidden_states,)
-            hidden_states = layer(hidden_states, attention_mask, None)
+        importance = None
+        if want_att:
+            importance = torch.zeros(hidden_states.shape[:2], dtype=torch.float32, device=hidden_states.device)
+            HF.KEY_IMPORTANCE = importance
+        try:
+            for layer in self.layer:
+                if self.output_hidden_states:
+                    all_hidden = all_hidden + (hidden_states,)
+                hidden_states = layer(hidden_states, attention_mask, None)
+        finally:
+            HF.KEY_IMPORTANCE = None
         outputs = (hidden_states,)
         if self.output_hidden_states:
             outputs = outputs + (all_hidden + (hidden_states,),)
+        if want_att:
+            outputs = outputs + (KeyImportance(importance),)
         return outputs
+
+
+class KeyImportance:
+    """Stands where the tuple of attention maps would: `.sum` of the maps' head means over layers and queries ([B, N])."""
+
+    def __init__(self, value):
+        self.value = value
 
 
 class BertPooler(nn.Module):

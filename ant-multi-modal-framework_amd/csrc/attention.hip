@@ -888,3 +888,84 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
     return antmmf_attention_bwd_hd(q, k, v, key_bias, o, lse, d_o, dq, dk, dv, B, heads, 64, Nq, Nk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale,
                                    dropout_p, dropout_seed, stream);
 }
+
+// ---- key importance: column sums of the attention probabilities --------------------------------------------------------------------------------
+// out[b][k] += weight * sum_h sum_q P_drop[b][h][q][k]  -- what the reference does with the attention MAPS it asks the text tower for in training
+// (`output_attentions=True`, prj/base_vtp/roi_univl/univl/model/univl_video_base.py:131-143: cat over layers of the head mean, summed over layers and
+// queries -> words_importance).  The maps never exist here; the probabilities are rebuilt from Q, K and the forward's log-sum-exp exactly as the backward
+// kernels do (same dropout mask: HF's BertSelfAttention returns the probabilities AFTER dropout), summed over the queries in registers, over the 16 query
+// lanes by DPP, over the waves in LDS, and leave as one atomic add per (b, h, key).  Head size 64.
+template <int NCH, bool DROP>
+__global__ __launch_bounds__(ATTN_THREADS, 2) void attn_key_importance_kernel(const AttnArgs a, float* __restrict__ out, float weight) {
+    ANTMMF_DYN_LDS(char, smem);
+    constexpr int NKP = 32 * NCH, NT = 2 * NCH;
+    char* Ks = smem;
+    float* kb = reinterpret_cast<float*>(Ks + NKP * 128);
+    float* colsum = kb + NKP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    stage_rows<64, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, NKP);
+    stage_key_bias(kb, a, b, NKP);
+    for (int i = threadIdx.x; i < NKP; i += ATTN_THREADS) colsum[i] = 0.f;
+    __syncthreads();
+    const float scale2 = a.scale * LOG2E;
+    const int nqt = (a.Nq + 15) >> 4;
+    float part[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[t][r] = 0.f;
+    for (int qt = wave; qt < nqt; qt += ATTN_THREADS / 64) {
+        const int qi = qt * 16 + l15;
+        const int qrow = qi < a.Nq ? qi : a.Nq - 1;
+        const bf16_t* qp = a.q + ((long)b * a.Nq + qrow) * a.ldq + h * 64 + grp * 8;
+        const bf16x8_t qf0 = load_frag_global(qp), qf1 = load_frag_global(qp + 32);
+        const float lse = a.lse[((long)b * a.heads + h) * a.Nq + qrow];
+        // padding queries and fully masked ones (lse = -inf) contribute nothing: subtracting +inf makes every exponent -inf
+        const float lse2 = (qi >= a.Nq || lse == -INFINITY) ? INFINITY : lse * LOG2E;
+        const uint32_t dbase = (uint32_t)((((long)b * a.heads + h) * a.Nq + qrow) * a.Nk);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t % 3 == 0) LDS_FENCE();
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f};
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Ks, 16 * t + l15, grp), qf0, sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<64>(Ks, 16 * t + l15, 4 + grp), qf1, sa, 0, 0, 0);
+            const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
+            const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = EXP2F(sa[r] * scale2 + bb[r] - lse2);
+                if (DROP) pr = DROPOUT_KEEP(dbase + 16 * t + 4 * grp + r, a.drop_seed, a.drop_thr) ? pr * a.drop_scale : 0.f;
+                part[t][r] += pr;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = row16_sum(part[t][r]);   // over the wave's 16 query lanes
+            if (l15 == 0) atomicAdd(colsum + 16 * t + 4 * grp + r, v);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.Nk; i += ATTN_THREADS) atomicAdd(out + (long)b * a.Nk + i, colsum[i] * weight);
+}
+
+extern "C" int antmmf_attention_key_importance(const void* q, const void* k, const float* key_bias, const float* lse, float* out, int B, int heads, int Nq, int Nk,
+                                               long ldq, long ldk, float scale, float dropout_p, uint64_t dropout_seed, float weight, hipStream_t stream) {
+    AttnArgs a{};
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return ANTMMF_EINVAL;
+    a.drop_thr = dropout_threshold(dropout_p); a.drop_scale = 1.0f / (1.0f - dropout_p); a.drop_seed = dropout_seed;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.key_bias = key_bias; a.lse = const_cast<float*>(lse);
+    a.ldq = ldq; a.ldk = ldk; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    if (!q || !k || !lse || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0 || Nk > 288 || Nq > 288 || (ldq & 7) || (ldk & 7)) return ANTMMF_EINVAL;
+    const int nch = (Nk + 31) / 32;
+    const dim3 grid((unsigned)(B * heads)), block(ATTN_THREADS);
+#define KIMP(N) do { const size_t lds = (size_t)(32 * N) * 128 + (32 * N) * 8; \
+        if (a.drop_thr) { set_lds(attn_key_importance_kernel<N, true>, lds); hipLaunchKernelGGL((attn_key_importance_kernel<N, true>), grid, block, lds, stream, a, out, weight); } \
+        else { set_lds(attn_key_importance_kernel<N, false>, lds); hipLaunchKernelGGL((attn_key_importance_kernel<N, false>), grid, block, lds, stream, a, out, weight); } } while (0)
+    if (nch <= 1) KIMP(1); else if (nch <= 3) KIMP(3); else if (nch <= 7) KIMP(7); else KIMP(9);
+#undef KIMP
+    return antmmf_check_launch();
+}
+

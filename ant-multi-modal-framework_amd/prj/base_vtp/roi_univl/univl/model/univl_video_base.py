@@ -65,14 +65,18 @@ class UnivlVideoBase(nn.Module):
 
     def forward_text_encoder(self, input_ids, input_mask, txt_encoder=None):
         text_encoder = txt_encoder or self.text_encoder
+        words_importance = None
         if self.arch_type == "univl":
-            # (the reference also asks for the attention maps in training to derive `words_importance`, which only the pretraining head's masking reads:
-            # on the fused path the maps never reach HBM and the entry stays None)
-            sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=None)[:2]   # all-zero token types (reference :125): None spares BertEmbeddings its any() host sync
+            # all-zero token types (reference :125): None spares BertEmbeddings its any() host sync.  In training the reference asks for the attention maps and
+            # reduces them to `words_importance` (:131-143): here the tower hands back that reduction itself (modeling_bert.KeyImportance)
+            out = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=None, output_attentions=bool(self.training))
+            sequence_output, pooled_output = out[0], out[1]
+            if self.training:
+                words_importance = out[2].value.detach()
         else:
             sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask)
         pooled_output = HF.l2_normalize(pooled_output.contiguous())
-        return dict(sequence_output=sequence_output, pooled_output=pooled_output, input_mask=input_mask, words_importance=None)
+        return dict(sequence_output=sequence_output, pooled_output=pooled_output, input_mask=input_mask, words_importance=words_importance)
 
     # ------------------------------------------------------------------ stage-2 cross encoder
     def prepare_cross_text(self, input_ids, input_mask):

@@ -179,6 +179,12 @@ int antmmf_attention_bwd(const void* q, const void* k, const void* v, const floa
                          int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                          int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed,
                          antmmf_stream_t stream);
+/* Key importance (head size 64): out[b][k] += weight * sum over heads and queries of the (post-dropout) attention probabilities, rebuilt from q, k and the
+ * forward's lse -- the reduction the reference applies to the attention MAPS of `output_attentions=True` (words_importance,
+ * prj/base_vtp/roi_univl/univl/model/univl_video_base.py:131-143; maps from modeling_bert.py:144-172).  out [B, Nk] fp32 is accumulated into (atomics). */
+int antmmf_attention_key_importance(const void* q, const void* k, const float* key_bias, const float* lse, float* out, int B, int heads,
+                                    int Nq, int Nk, int64_t ldq, int64_t ldk, float scale, float dropout_p, uint64_t dropout_seed,
+                                    float weight, antmmf_stream_t stream);
 /* The same pair with an explicit head size: 64 or 128 (ViLBERT's bi_hidden_size 1024 / 8 heads, antmmf/models/vilbert.py:326-339); element
  * (b, n, h, e) lives at base + (b*N + n)*ld + h*head_dim + e.  The two entry points above are head_dim = 64. */
 int antmmf_attention_fwd_hd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,

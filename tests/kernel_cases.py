@@ -765,3 +765,12 @@ def case_dropout(ops, dev):
     check("attn.drop.dq", dq, qr.grad, 3e-2, 3e-2)
     check("attn.drop.dk", dk, kr.grad, 3e-2, 3e-2)
     check("attn.drop.dv", dv, vr.grad, 3e-2, 3e-2)
+    # key importance = head mean of the (dropped) probabilities summed over the queries (the reduction of `output_attentions` maps, univl_video_base.py:138-143),
+    # accumulated into the caller's buffer: with the same dropout mask, and without dropout
+    imp = torch.full((B, N), 0.5, device=dev)
+    ops.attention_key_importance_(imp, qd, kd, lse, heads, scale, key_bias.to(dev), dropout_p=pa, dropout_seed=seed, weight=1.0 / heads)
+    check("attn.drop.importance", imp, 0.5 + (torch.softmax(s, -1) * mask).detach().mean(1).sum(1), 2e-2, 2e-2)
+    o0, lse0 = ops.attention_fwd(qd, kd, vd, heads, scale, key_bias.to(dev))
+    imp0 = torch.zeros(B, N, device=dev)
+    ops.attention_key_importance_(imp0, qd, kd, lse0, heads, scale, key_bias.to(dev), weight=1.0 / heads)
+    check("attn.importance", imp0, torch.softmax(s, -1).detach().mean(1).sum(1), 2e-2, 2e-2)

@@ -15,6 +15,7 @@ def _hf_checkpoint(tmp, layers=3):
     tr = pytest.importorskip("transformers")
     cfg = tr.BertConfig(vocab_size=120, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=256, max_position_embeddings=40,
                         type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg._attn_implementation = "eager"   # the sdpa path of recent transformers cannot return attention maps
     torch.manual_seed(7)
     hf = tr.BertModel(cfg).eval()
     with torch.no_grad():
@@ -44,6 +45,15 @@ def _case(dev, tmp):
     with torch.no_grad():
         ref_seq, ref_pool = hf(input_ids=ids, attention_mask=mask, token_type_ids=tt, return_dict=False)[:2]
         seq, pool = enc(input_ids=ids.to(dev), attention_mask=mask.to(dev), token_type_ids=tt.to(dev))
+        # output_attentions=True: the fused tower returns the reduction the reference applies to the maps (univl_video_base.py:138-143) -- checked here against that
+        # very expression on transformers' own attention maps
+        ref_att = hf(input_ids=ids, attention_mask=mask, token_type_ids=tt, return_dict=False, output_attentions=True)[2]
+        want_imp = torch.cat([a.mean(1, keepdim=True) for a in ref_att], dim=1).sum(dim=(1, 2))
+        out3 = enc(input_ids=ids.to(dev), attention_mask=mask.to(dev), token_type_ids=tt.to(dev), output_attentions=True)
+    assert len(out3) == 3 and torch.allclose(out3[0].float().cpu(), seq.float().cpu())
+    got_imp = out3[2].value.cpu()
+    err_imp = float((got_imp - want_imp).abs().max() / want_imp.abs().max())
+    assert got_imp.shape == want_imp.shape and err_imp < 3e-2, err_imp
     keep = mask.bool()[..., None]
     err_seq = float(((seq.float().cpu() - ref_seq) * keep).abs().max() / ref_seq.abs().max())
     err_pool = float((pool.float().cpu() - ref_pool).abs().max())
@@ -83,6 +93,13 @@ def _case_univl_arch(dev, stage="stage1+stage2"):
     img_input = dict(image_data=img, image_pad_mask=torch.zeros(B, 1, 32, 32, dtype=torch.bool, device=dev), image_n_clips=[1] * B, image_num_frames=[1] * B)
     cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
     out = model(img_input, cap_input)
+    # training + arch univl: the text tower's key importance reaches the model as `words_importance` (reference univl_video_base.py:131-143).  Every softmax row
+    # sums to one, so each caption's importances sum to layers x tokens -- up to the attention-probability dropout of the BERT layers (p = 0.1 in training, and
+    # the maps HF returns are the dropped ones): 24 +- a few per cent
+    wi = model.module.forward_text_encoder(ids, mask)["words_importance"]
+    assert wi is not None and tuple(wi.shape) == (B, 12) and not wi.requires_grad
+    torch.testing.assert_close(wi.sum(-1).cpu(), torch.full((B,), 2.0 * 12), rtol=0.15, atol=0.0)
+    assert float(wi[1, 5:].abs().max()) < 1e-3      # padded words (mask -10000) receive no attention
     loss = sum(out["losses"].values())
     assert torch.isfinite(loss) and 0.2 * math.log(B) < float(out["losses"]["level1_similarity_loss"]) < 6 * math.log(B), out["losses"]
     loss.backward()
