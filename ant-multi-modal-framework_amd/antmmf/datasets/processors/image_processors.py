@@ -57,7 +57,7 @@ class CustomTransforms(BaseProcessor):
         # GroupNormalize divides by 255 only when the frames exceed 1 AND the means are on the [0, 1] scale (image_ops.py:99-104: detectron2-style
         # means such as 123.675 mean "pixels stay on 0..255"): the second half is a host-side property of the configuration, the first stays on the device
         div255 = -1 if max(mean) <= 1 else 0
-        return hip_image.frames_bilinear_norm(x, oh, ow, mean=mean, std=std, out=out, div255=div255)
+        return hip_image.frames_bilinear_norm(x, oh, ow, mean=mean, std=std, out=out, div255=div255, antialias=scale.antialias)
 
     def __call__(self, x):
         return_dict = isinstance(x, dict)
@@ -73,7 +73,7 @@ class CustomTransforms(BaseProcessor):
             if scale.pad:
                 raise NotImplementedError("custom_transforms: pad=True (every shipped yml has pad: false)")
             oh, ow = self.output_size(x)
-            res = norm(torch.nn.functional.interpolate(x.float(), size=(oh, ow), mode="bilinear", align_corners=False))
+            res = norm(torch.nn.functional.interpolate(x.float(), size=(oh, ow), mode="bilinear", align_corners=False, antialias=scale.antialias))
         elif self.mode == "sequential":
             res = x
             for func, param in zip(self.transfunc_list, self.transfunc_params):

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "antmmf_ffn_fc2_dgrad": [P, P, P, P, P, P, P, I, I, I, L, L, L, L, P, L, P],
     "antmmf_ffn_wgrad_post": [P, P, P, P, P, P, P, P, P, I, I, P],
     "antmmf_frames_bilinear_norm": [P, I, I, I, I, L, L, L, L, P, I, I, L, L, L, P, P, I, P, P],
+    "antmmf_frames_bilinear_aa_norm": [P, I, I, I, I, L, L, L, L, P, P, I, I, L, L, L, P, P, I, P, P],
 }
 
 

@@ -125,12 +125,13 @@ def resize_bicubic_u8(images, out_h, out_w, out_f32=True, device=None):
 
 
 # ------------------------------------------------------------------------------ video frames (bilinear, float32, fused normalise + pad)
-def frames_bilinear_norm(frames, out_h, out_w, mean=None, std=None, out=None, div255=-1, layout="nchw"):
+def frames_bilinear_norm(frames, out_h, out_w, mean=None, std=None, out=None, div255=-1, layout="nchw", antialias=False):
     """All frames of one video: uint8 `frames` ([n, C, h, w], or [n, h, w, C] with layout="nhwc": only the strides differ) ->
     float32 [n, C, out_h, out_w] = GroupNormalize(bilinear_resize(frames.float())) (csrc/frames.hip; reference
     image_processors.py:520-547 + image_ops.py:72-108,127-223).  `out`: optional float32 view to write into (last dim contiguous) --
     e.g. the [n, C, :out_h, :out_w] corner of the zero-initialised padded batch canvas, which makes the collate padding free.
-    mean / std None: resize only.  div255 -1: the reference's `max > 1` test, evaluated on the device."""
+    mean / std None: resize only.  div255 -1: the reference's `max > 1` test, evaluated on the device.
+    antialias: torchvision >= 0.17's tensor default (interpolate(..., antialias=True): ATen's separable triangle filter, two passes)."""
     if frames.dtype != torch.uint8 or frames.dim() != 4:
         raise ValueError("frames_bilinear_norm: frames must be a uint8 [n, C, h, w] (or [n, h, w, C]) tensor")
     if (frames.device.type == "cuda") != (_lib.backend() == 1):
@@ -154,6 +155,11 @@ def frames_bilinear_norm(frames, out_h, out_w, mean=None, std=None, out=None, di
             raise ValueError("frames_bilinear_norm: mean / std need one value per channel")
         if div255 < 0:
             scratch = torch.zeros(1, dtype=torch.int32, device=dev)
+    if antialias:
+        temp = torch.empty(n * C * h * out_w, dtype=torch.float32, device=dev)   # the horizontally filtered frames
+        _rc(_lib.load().antmmf_frames_bilinear_aa_norm(_p(frames), n, C, h, w, sn, sc, sh, sw, _p(temp), _p(out), out_h, out_w, out.stride(0), out.stride(1),
+                                                      out.stride(2), _p(mean_t), _p(std_t), int(div255), _p(scratch), _stream()), "antmmf_frames_bilinear_aa_norm")
+        return out
     _rc(_lib.load().antmmf_frames_bilinear_norm(_p(frames), n, C, h, w, sn, sc, sh, sw, _p(out), out_h, out_w, out.stride(0), out.stride(1), out.stride(2),
                                                _p(mean_t), _p(std_t), int(div255), _p(scratch), _stream()), "antmmf_frames_bilinear_norm")
     return out

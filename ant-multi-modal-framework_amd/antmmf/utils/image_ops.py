@@ -15,8 +15,11 @@ def _is_u8_frames(x):
 
 
 class ImageLongsideScaleAndPad:
-    def __init__(self, max_size, random_scale=False, pad=False, interpolation="bilinear"):
+    def __init__(self, max_size, random_scale=False, pad=False, interpolation="bilinear", antialias=False):
+        """antialias (this build's key): False = torchvision < 0.17's tensor resize (what the reference was written against), True = the tensor default of
+        torchvision >= 0.17 (interpolate(..., antialias=True)); both are device kernels (csrc/frames.hip)."""
         assert isinstance(max_size, int)
+        self.antialias = bool(antialias)
         if interpolation not in ("bilinear", 2):   # PIL.Image.BILINEAR == 2
             raise NotImplementedError("ImageLongsideScaleAndPad: bilinear only (the default and what every shipped yml uses)")
         if random_scale is False:
@@ -46,9 +49,9 @@ class ImageLongsideScaleAndPad:
         max_size = self.pick_size()
         oh, ow = self.get_resize_size(img, max_size)
         if not self.pad:
-            return hip_image.frames_bilinear_norm(img, oh, ow)
+            return hip_image.frames_bilinear_norm(img, oh, ow, antialias=self.antialias)
         canvas = torch.zeros(img.shape[0], img.shape[1], max_size, max_size, dtype=torch.float32, device=img.device)
-        hip_image.frames_bilinear_norm(img, oh, ow, out=canvas[:, :, :oh, :ow])
+        hip_image.frames_bilinear_norm(img, oh, ow, out=canvas[:, :, :oh, :ow], antialias=self.antialias)
         return canvas
 
 

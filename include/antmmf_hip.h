@@ -331,6 +331,11 @@ int antmmf_ffn_wgrad_post(const float* Gm, const float* W2, const float* gamma, 
 int antmmf_frames_bilinear_norm(const void* src, int n, int channels, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                                 float* out, int out_h, int out_w, int64_t on, int64_t oc, int64_t oh, const float* mean, const float* std,
                                 int div255, int* max_scratch, antmmf_stream_t stream);
+/* The same transform with torchvision >= 0.17's tensor default antialias=True: torch.nn.functional.interpolate(..., antialias=True), ATen's separable
+ * triangle filter (horizontal pass into `temp`, DEVICE float[n * channels * h * out_w], then the vertical pass + GroupNormalize). */
+int antmmf_frames_bilinear_aa_norm(const void* src, int n, int channels, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* temp,
+                                   float* out, int out_h, int out_w, int64_t on, int64_t oc, int64_t oh, const float* mean, const float* stdv,
+                                   int div255, int* max_scratch, antmmf_stream_t stream);
 
 #ifdef __cplusplus
 }

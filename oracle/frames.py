@@ -10,7 +10,8 @@ frame to the batch maxima, mask True over the padding.
 
 The resize lives in a third-party dependency that is not installed in this image (**torchvision**, requirements.txt `torchvision`
 unpinned): for a float tensor its `resize` is `torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners=False)` -- without
-antialiasing in the torchvision generations contemporary with the reference (antialias became the tensor default only in 0.17).  torch
+antialiasing in the torchvision generations contemporary with the reference (antialias became the tensor default only in 0.17; the
+`antialias=True` argument below restates that later default: the same function with antialias=True).  torch
 IS installed, so the oracle calls that very function; **the torchvision wrapper itself is unpinned** (stated in DESIGN.md).
 """
 import random
@@ -36,12 +37,12 @@ def scales(max_size, random_scale):
     return s
 
 
-def scale_frames(frames_u8, max_size, random_scale=False):
+def scale_frames(frames_u8, max_size, random_scale=False, antialias=False):
     """CustomTransforms' float cast + ImageLongsideScaleAndPad (pad=False) -> float32 [n, C, h', w']."""
     sc = scales(max_size, random_scale)
     m = random.choice(sc) if random_scale else sc[-1]
     x = frames_u8.float()
-    return F.interpolate(x, size=resize_size(x.shape[-2], x.shape[-1], m), mode="bilinear", align_corners=False)
+    return F.interpolate(x, size=resize_size(x.shape[-2], x.shape[-1], m), mode="bilinear", align_corners=False, antialias=antialias)
 
 
 def group_normalize(x, mean, std):
@@ -57,8 +58,8 @@ def group_normalize(x, mean, std):
     return x.sub_(m).div_(s)
 
 
-def frame_processor(frames_u8, max_size, mean, std, random_scale=False):
-    return group_normalize(scale_frames(frames_u8, max_size, random_scale), mean, std)
+def frame_processor(frames_u8, max_size, mean, std, random_scale=False, antialias=False):
+    return group_normalize(scale_frames(frames_u8, max_size, random_scale, antialias), mean, std)
 
 
 def collate(videos):

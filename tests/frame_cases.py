@@ -80,6 +80,39 @@ def case_dark_clip_keeps_reference_semantics(dev):
     return "ok"
 
 
+def case_antialias(dev, shapes=((2, 48, 64, 24), (2, 64, 48, 40), (1, 33, 57, 64), (1, 97, 131, 32), (2, 20, 30, 48), (1, 7, 5, 3), (1, 360, 640, 224))):
+    """`antialias: true` on ImageLongsideScaleAndPad (torchvision >= 0.17's tensor default) = interpolate(..., antialias=True): down-scaling by integer and
+    fractional factors (wide triangle filters), up-scaling (the filter degenerates to plain bilinear taps), tiny outputs, NHWC strides, padded canvas."""
+    import antmmf.datasets.processors  # noqa: F401
+    from antmmf.datasets.processors import Processor
+    from antmmf.hip.image import frames_bilinear_norm
+    from antmmf.utils.image_ops import ImageLongsideScaleAndPad
+
+    worst = 0.0
+    for i, (n, h, w, max_size) in enumerate(shapes):
+        proc = Processor({"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+            {"type": "ImageLongsideScaleAndPad", "params": {"max_size": max_size, "antialias": True}},
+            {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}})
+        fr = _frames(n, h, w, 300 + i)
+        worst = max(worst, _close(proc(fr.to(dev)), oframes.frame_processor(fr, max_size, MEAN, STD, antialias=True), ("aa", n, h, w, max_size)))
+    fr = _frames(2, 40, 56, 17)
+    worst = max(worst, _close(ImageLongsideScaleAndPad(24, antialias=True)(fr.to(dev)), oframes.scale_frames(fr, 24, antialias=True), "aa scale only"))
+    oh, ow = oframes.resize_size(40, 56, 24)
+    nhwc = fr.permute(0, 2, 3, 1).contiguous().to(dev)
+    worst = max(worst, _close(frames_bilinear_norm(nhwc, oh, ow, mean=MEAN, std=STD, layout="nhwc", antialias=True),
+                              oframes.frame_processor(fr, 24, MEAN, STD, antialias=True), "aa nhwc"))
+    padded = ImageLongsideScaleAndPad(24, pad=True, antialias=True)(fr.to(dev)).cpu()
+    assert padded.shape == (2, 3, 24, 24) and float(padded[:, :, oh:, :].abs().max()) == 0.0
+    # the filter really is a different one when down-scaling (guards against the flag being dropped on the way)
+    plain = ImageLongsideScaleAndPad(24)(fr.to(dev)).cpu()
+    assert float((plain - oframes.scale_frames(fr, 24, antialias=True)).abs().max()) > 1.0
+    dark = (_frames(2, 20, 24, 3) % 2).to(torch.uint8)    # the device-side `max > 1` test sees the ANTIALIASED values
+    procd = Processor({"type": "custom_transforms", "params": {"mode": "sequential", "transforms": [
+        {"type": "ImageLongsideScaleAndPad", "params": {"max_size": 12, "antialias": True}}, {"type": "GroupNormalize", "params": {"mean": MEAN, "std": STD}}]}})
+    _close(procd(dark.to(dev)), oframes.frame_processor(dark, 12, MEAN, STD, antialias=True), "aa dark")
+    return f"max abs err {worst:.2e}"
+
+
 def case_collate(dev, n_clips=2, num_frm=2):
     """A ragged batch of videos -> padded image_data + image_pad_mask, random_scale drawn in the reference's order."""
     import antmmf.datasets.processors  # noqa: F401

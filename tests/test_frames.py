@@ -42,6 +42,10 @@ def test_processor_emulated(emu):
     print(fc.case_processor(emu))
 
 
+def test_antialias_emulated(emu):
+    print(fc.case_antialias(emu, shapes=((2, 48, 64, 24), (2, 64, 48, 40), (1, 33, 57, 64), (1, 97, 131, 32), (2, 20, 30, 48), (1, 7, 5, 3))))
+
+
 def test_dark_clip_emulated(emu):
     fc.case_dark_clip_keeps_reference_semantics(emu)
 
@@ -53,6 +57,11 @@ def test_collate_emulated(emu):
 @pytest.mark.gpu
 def test_processor_gpu():
     print(fc.case_processor(torch.device("cuda:0")))
+
+
+@pytest.mark.gpu
+def test_antialias_gpu():
+    print(fc.case_antialias(torch.device("cuda:0")))
 
 
 @pytest.mark.gpu
