@@ -466,7 +466,10 @@ def gen_e2e_clip_stage2():
         model.dropout.p = 0.0  # the only stochastic op on the path (BERT dropouts are 0 in this config)
         out = model(batch["image"], batch["caption"])
         loss = out["losses"]["level1_similarity_loss"] + out["losses"]["level2_similarity_loss"]
+        if tag == "plain":
+            out["l2_simi"].retain_grad()   # (reduce_clips is the identity at level 2: this IS the matrix the level-2 loss reads)
         loss.backward(retain_graph=(tag == "plain"))
+        c = out["l2_simi"].grad.detach().clone() if tag == "plain" else None   # (before the pin backward below accumulates into it)
         d.update({f"s2.{tag}.loss1": out["losses"]["level1_similarity_loss"], f"s2.{tag}.loss2": out["losses"]["level2_similarity_loss"],
                   f"s2.{tag}.l2_simi": out["l2_simi"], f"s2.{tag}.l1_simi": out["l1_simi"]})
         for n, p in model.named_parameters():
@@ -480,11 +483,21 @@ def gen_e2e_clip_stage2():
             # weights on the cross-encoder pair scores
             model.zero_grad(set_to_none=True)
             pin = (out["l2_simi"] * (W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).abs() + 0.5)).sum()
-            pin.backward()
+            pin.backward(retain_graph=True)
             d["s2.pin.value"] = pin.detach()
             for n, p in model.named_parameters():
                 if p.grad is not None:
                     d[f"s2.pin.gfull.{n}"] = p.grad.to(torch.bfloat16)
+            # the level-2 LOSS gradient, decomposed so that it can be checked tightly: c = d loss / d l2_simi (rows and columns of a softmax
+            # gradient: mixed signs, sums ~ 0), loss gradient = J^T c = J^T c+ - J^T c- with c+ = max(c, 0), c- = max(-c, 0).  Each half is a
+            # scalar with NON-NEGATIVE weights on the pair scores (no cancellation: checkable at the pin's gates); the subtraction is exact.
+            d["s2.plain.dl2_simi"] = c
+            for sign, key in ((1.0, "pinp"), (-1.0, "pinm")):
+                model.zero_grad(set_to_none=True)
+                (out["l2_simi"] * (sign * c).clamp(min=0)).sum().backward(retain_graph=True)
+                for n, p in model.named_parameters():
+                    if p.grad is not None:
+                        d[f"s2.{key}.gfull.{n}"] = p.grad.to(torch.bfloat16)
     save("e2e_clip_stage2.pt", d)
 
 

@@ -304,16 +304,19 @@ def case_univl_stage2(dev, golden, mining=False):
     cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
     out = model(img_input, cap_input)
     l1, l2 = out["losses"]["level1_similarity_loss"], out["losses"]["level2_similarity_loss"]
+    if not mining:
+        out["l2_simi"].retain_grad()   # (reduce_clips is the identity at level 2: this is the matrix the level-2 loss reads)
     (l1 + l2).backward(retain_graph=not mining)
     if not mining:
         loss_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        c_prod = out["l2_simi"].grad.detach().float().cpu().clone()
         # (1) THE gradient check of this path: a scalar of the same graph whose gradient does not cancel -- fixed POSITIVE weights on the
         # cross-encoder pair scores (tests/golden/make_golden.py gen_e2e_clip_stage2, "s2.pin"): every parameter of both towers, the cross
         # encoder and the score head against the reference's gradient at the gates of stage 1 / stage 3 / M2 (measured on MI355X: min cosine
         # 0.9978, worst norm 1.7 % over 72 parameters)
         model.zero_grad(set_to_none=True)
         pin = (out["l2_simi"].float() * (W.data_tensor("s2.pin", tuple(out["l2_simi"].shape)).abs() + 0.5).to(dev)).sum()
-        pin.backward()
+        pin.backward(retain_graph=True)
         assert abs(float(pin) - float(g["s2.pin.value"])) <= 5e-2 * max(1.0, abs(float(g["s2.pin.value"]))), (float(pin), float(g["s2.pin.value"]))
         pin_dirs = assert_grad_directions(model.named_parameters(), g, "s2.pin.", min_cos=0.995, max_norm_rel=0.05, min_checked=50)
         prow = [(p.grad.detach().float().flatten().cpu(), g[f"s2.pin.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
@@ -321,6 +324,30 @@ def case_univl_stage2(dev, golden, mining=False):
         pgot, pref = torch.cat([r[0] for r in prow]), torch.cat([r[1] for r in prow])
         pin_dirs["global_cos"] = float(torch.dot(pgot, pref) / (pgot.norm() * pref.norm()))
         assert pin_dirs["global_cos"] >= 0.999, pin_dirs
+        # (1b) the level-2 LOSS gradient, checked tightly in two exact steps.  loss gradient = J^T c with c = d loss / d l2_simi:
+        #   * c itself: the loss kernel's gradient at the product's own scores against the oracle's formula there (fp32: 1e-6), and against the
+        #     reference's c (the scores carry bf16 noise: 3 %);
+        #   * J^T (the backward of both towers, the cross encoder and the score head -- linear in its upstream gradient) applied to c+ = max(c, 0) and
+        #     c- = max(-c, 0) of the REFERENCE's c: two scalars with non-negative weights, no cancellation, each at the pin's gates.  J^T c = J^T c+ - J^T c-
+        #     exactly; the 13x cancellation between the halves (norms 18.7 / 18.7 -> 1.4) is what makes the direct comparison (2) a noise measurement.
+        from oracle import losses as olosses_s2
+
+        s_here = out["l2_simi"].detach().float().cpu().clone().requires_grad_(True)
+        olosses_s2.mil_nce(s_here, bsz, 1, None).backward()
+        assert float((c_prod - s_here.grad).abs().max()) <= 1e-6, (c_prod, s_here.grad)
+        c_ref = g["s2.plain.dl2_simi"].float()
+        assert float((c_prod - c_ref).abs().max()) <= 3e-2 * float(c_ref.abs().max()), (c_prod, c_ref)
+        half_dirs = {}
+        for sign, key in ((1.0, "pinp"), (-1.0, "pinm")):
+            model.zero_grad(set_to_none=True)
+            (out["l2_simi"].float() * (sign * c_ref).clamp(min=0).to(dev)).sum().backward(retain_graph=True)
+            dkey = assert_grad_directions(model.named_parameters(), g, f"s2.{key}.", min_cos=0.995, max_norm_rel=0.05, min_checked=50)
+            hrow = [(p.grad.detach().float().flatten().cpu(), g[f"s2.{key}.gfull.{n}"].float().flatten()) for n, p in model.named_parameters()
+                    if p.grad is not None and f"s2.{key}.gfull.{n}" in g]
+            hgot, href = torch.cat([r[0] for r in hrow]), torch.cat([r[1] for r in hrow])
+            dkey["global_cos"] = float(torch.dot(hgot, href) / (hgot.norm() * href.norm()))
+            assert dkey["global_cos"] >= 0.999, (key, dkey)
+            half_dirs[key] = dkey
         for n, p in model.named_parameters():   # the checks below are on the LOSS gradient again
             p.grad = loss_grads.get(n)
         ref1, ref2 = float(g["s2.plain.loss1"]), float(g["s2.plain.loss2"])
@@ -347,7 +374,7 @@ def case_univl_stage2(dev, golden, mining=False):
         got, ref = torch.cat([r[0] for r in rows]), torch.cat([r[1] for r in rows])
         dirs["global_cos"] = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
         assert dirs["global_cos"] >= 0.7, dirs
-        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs, pin_directions=pin_dirs)
+        return dict(loss1=(float(l1), ref1), loss2=(float(l2), ref2), worst=rel[:3], directions=dirs, pin_directions=pin_dirs, half_directions=half_dirs)
     from oracle import step as ostep
 
     P = tiny_models.clip_arch_params(stage2=True)
