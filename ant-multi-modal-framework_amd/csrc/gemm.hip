@@ -1556,7 +1556,17 @@ template <> struct K64RWaits<21> { static constexpr int W[3][4] = {{49, 49, 50, 
 template <> struct K64RWaits<5> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };
 template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
 
-// ABL (ablations, variant bits 15 / 16): 1 = the converted rows are not stored (timing only: the ladders count the stores), 4 = non-temporal stores
+// ABL 8 (timing only, EPI 0, R = 1024): every K-tile stores ONE 16-row x 32-column block of the tile (out of the running sums: wrong values, right bytes,
+// addresses and instruction count) in phase 1, nothing at the tile boundary: what a kernel whose rows finish at staggered K positions would pay for its stores.
+struct K64RSpreadWaits { static constexpr int W[4] = {9, 11, 12, 8}; };
+// ABL 24 (= 8 + 16): the same bytes, but the DMA pieces of all eight waves are issued by waves 4 - 7 (each also its partner's, 128 rows up) and all the stores
+// by waves 0 - 3 (two blocks per K-tile): no wave that waits on its vmcnt counter for DMA pieces has a store in it, and the storing waves never wait.
+struct K64RSplitWaits { static constexpr int W[4] = {16, 18, 20, 14}; };
+// the two halves of that split on their own: ABL 24 = DMA by waves 4 - 7 only, every wave still stores one block per K-tile (waves 0 - 3 never wait);
+// ABL 40 = every wave issues its own DMA, waves 0 - 3 store two blocks per K-tile, waves 4 - 7 none
+struct K64RProxyWaits { static constexpr int W[4] = {17, 20, 22, 15}; };
+struct K64RTwoStoreWaits { static constexpr int W[4] = {10, 13, 14, 9}; };
+// ABL (ablations, variant bits 15 / 16): 1 = the converted rows are not stored (timing only: the ladders count the stores), 4 = non-temporal stores; 8 = spread stores
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int ntiles) {
     ANTMMF_DYN_LDS(char, smem);
@@ -1588,6 +1598,10 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     };
     int local = lx;
     if (local >= xcount) return;
+#ifndef ANTMMF_EMULATE
+    // workgroup 0 records shader-clock and 100-MHz-clock ticks across its run (antmmf_debug_gemm_clock: the effective clock of this launch; two scalar reads)
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // fragment read bases; the Q fragment row of lane l15 is l15 with bits 2 and 3 exchanged (lane-swap store layout, see gemm_nt_k64p_kernel)
     const int pl15 = (l15 & 3) | (((l15 >> 3) & 1) << 2) | (((l15 >> 2) & 1) << 3);
     uint32_t pbase[4], qbase[4];
@@ -1607,16 +1621,24 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #pragma unroll
         for (int b = 0; b < 4; ++b) qv[b] = (uint32_t)(pl * (int)ldqb) + (qs0 ^ (uint32_t)(b << 5));
     }
+    const int up128 = ((ABL & 16) && wave >= 4) ? 128 : 0;
     const char* pgc; const char* qgc; const char* pgn = nullptr; const char* qgn = nullptr;
     auto tile_bases = [&](int i0, int j0, const char*& pgx, const char*& qgx) {
-        pgx = reinterpret_cast<const char*>(g.P) + (long)(i0 + prow0) * ldpb;
-        qgx = reinterpret_cast<const char*>(g.Q) + (long)(j0 + qrow0) * ldqb;
+        pgx = reinterpret_cast<const char*>(g.P) + (long)(i0 + prow0 - up128) * ldpb;
+        qgx = reinterpret_cast<const char*>(g.Q) + (long)(j0 + qrow0 - up128) * ldqb;
     };
-    auto dma_p = [&](const char* base, int pq, int kk, uint32_t stage_off) {
-        glds16(base + (long)pq * 32 * ldpb + (long)kk * 128 + pv[pq & 1], smem + stage_off + (prow0 + 32 * pq) * 128);
+    // (ABL 16: waves 4 - 7 also issue the pieces of the wave 128 rows up; their tile bases then point at THAT wave's rows and their own pieces add 128 rows
+    // to the per-lane offset: no second set of scalar addresses)
+    uint32_t pvo[2], qvo[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) pvo[b] = pv[b] + (uint32_t)(up128 * (int)ldpb);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) qvo[b] = qv[b] + (uint32_t)(up128 * (int)ldqb);
+    auto dma_p = [&](const char* base, int pq, int kk, uint32_t stage_off, int up = 0) {   // up = 1: the piece of the wave 128 rows up (ABL 16)
+        glds16(base + (long)pq * 32 * ldpb + (long)kk * 128 + (up ? pv[pq & 1] : pvo[pq & 1]), smem + stage_off + (prow0 - up * 128 + 32 * pq) * 128);
     };
-    auto dma_q = [&](const char* base, int pq, int kk, uint32_t stage_off) {
-        glds16(base + (long)pq * 16 * ldqb + (long)kk * 128 + qv[pq], smem + stage_off + QOFF + (qrow0 + 16 * pq) * 128);
+    auto dma_q = [&](const char* base, int pq, int kk, uint32_t stage_off, int up = 0) {
+        glds16(base + (long)pq * 16 * ldqb + (long)kk * 128 + (up ? qv[pq] : qvo[pq]), smem + stage_off + QOFF + (qrow0 - up * 128 + 16 * pq) * 128);
     };
     auto dma_bias = [&](int tj0) {   // this wave's 64 bias values -> its LDS strip (4 B per lane)
 #ifdef ANTMMF_EMULATE
@@ -1628,6 +1650,8 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     };
     // per-lane byte offsets of the row-layout accesses (row l15 of a 16-row fragment, 8 consecutive columns at (lane >> 5) * 16 + (grp & 1) * 8; + 64 B for the second column pair)
     const uint32_t cvoff = (uint32_t)((l15 * (int)g.ldc + (lane >> 5) * 16 + (grp & 1) * 8) * 2);
+    const uint32_t cvoff128 = cvoff + (uint32_t)(128 * (int)g.ldc * 2);   // (ABL 16: the same lane position 128 rows down)
+    (void)cvoff128;
     const uint32_t rvoff = RES ? (uint32_t)((l15 * (int)g.ldr + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const uint32_t avoff = ACT2 ? (uint32_t)((l15 * (int)g.ldaux + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const int pbg = ((grp & 1) << 1) | (grp >> 1);
@@ -1739,7 +1763,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         const char* pbs = nx ? pgn : pgc;                                                                                           \
         const char* qbs = nx ? qgn : qgc;                                                                                           \
         const uint32_t st = IDX < 4 ? (so ^ STAGE) : so;                                                                            \
-        if (IDX < 4) dma_p(pbs, IDX, kk, st); else dma_q(qbs, IDX - 4, kk, st);                                                     \
+        if (ABL & 16) {                                                                                                             \
+            if (late) { if (IDX < 4) { dma_p(pbs, IDX, kk, st); dma_p(pbs, IDX, kk, st, 1); } else { dma_q(qbs, IDX - 4, kk, st); dma_q(qbs, IDX - 4, kk, st, 1); } } \
+        } else if (IDX < 4) dma_p(pbs, IDX, kk, st); else dma_q(qbs, IDX - 4, kk, st);                                              \
     } while (0)
 #define K64R_READS(PH)                                                                                                              \
     do {                                                                                                                            \
@@ -1769,6 +1795,29 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         K64_SETPRIO(0);                                                                                                             \
         SCHED_FENCE();                                                                                                              \
     } while (0)
+#define K64R_SPREAD_BLOCK(IT, P2) do { if (!(ABL & 32)) K64R_SPREAD_BLOCK1(IT, P2, 0); else if (!late) { K64R_SPREAD_BLOCK1(IT, P2, 0); K64R_SPREAD_BLOCK1(((IT + 4) & 7), P2, 128); } } while (0)
+#define K64R_SPREAD_BLOCK1(IT, P2, ROWOFF)                                                                                          \
+    do {                                                                                                                            \
+        u32x4_t ov;                                                                                                                 \
+        _Pragma("unroll") for (int rr = 0; rr < 4; rr += 2) {                                                                       \
+            const k64_u2_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[IT][2 * P2][rr]), __float_as_uint(acc[IT][2 * P2 + 1][rr]), false, false); \
+            const k64_u2_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[IT][2 * P2][rr + 1]), __float_as_uint(acc[IT][2 * P2 + 1][rr + 1]), false, false); \
+            ov[rr >> 1] = pack_bf2(__uint_as_float(s0[0]), __uint_as_float(s1[0]));                                                 \
+            ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                                           \
+        }                                                                                                                           \
+        char* cb = reinterpret_cast<char*>(g.C) + ((long)(i0 + wi * 128 + ((IT - (ROWOFF ? 4 : 0)) & 7) * 16) * g.ldc + j0 + wj * 64 + P2 * 32) * 2; \
+        K64R_GSTORE16((ROWOFF ? cvoff128 : cvoff), ov, cb, 0);                                                                                            \
+        SCHED_FENCE();                                                                                                              \
+    } while (0)
+#define K64R_SPREAD_STORE(ROLE)                                                                                                     \
+    do {   /* (every accumulator is read by some K-tile's store: none of the MFMAs is dead code) */                                  \
+        if (ROLE == 0) K64R_SPREAD_BLOCK(7, 1);                                                                                     \
+        else if (t == 1) K64R_SPREAD_BLOCK(0, 0); else if (t == 2) K64R_SPREAD_BLOCK(0, 1); else if (t == 3) K64R_SPREAD_BLOCK(1, 0);   \
+        else if (t == 4) K64R_SPREAD_BLOCK(1, 1); else if (t == 5) K64R_SPREAD_BLOCK(2, 0); else if (t == 6) K64R_SPREAD_BLOCK(2, 1);   \
+        else if (t == 7) K64R_SPREAD_BLOCK(3, 0); else if (t == 8) K64R_SPREAD_BLOCK(3, 1); else if (t == 9) K64R_SPREAD_BLOCK(4, 0);   \
+        else if (t == 10) K64R_SPREAD_BLOCK(4, 1); else if (t == 11) K64R_SPREAD_BLOCK(5, 0); else if (t == 12) K64R_SPREAD_BLOCK(5, 1); \
+        else if (t == 13) K64R_SPREAD_BLOCK(6, 0); else if (t == 14) K64R_SPREAD_BLOCK(6, 1); else K64R_SPREAD_BLOCK(7, 0);           \
+    } while (0)
     // ROLE: 0 = first K-tile of the output tile, 1 = steady, 2 = last K-tile
 #define K64R_HOOK(ROLE, PH)                                                                                                         \
     do {                                                                                                                            \
@@ -1786,6 +1835,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         if (ROLE == 0 && RES) K64R_INIT(PH);                                                                                        \
         if (ROLE == 2 && PH == 0 && BIAS) dma_bias(nj0);                                                                            \
         if (ROLE == 2 && PH >= 1) { K64R_EPIQ(PH - 1, i0, j0); if (RES) K64R_RESLOAD(PH - 1, ni0, nj0); }             \
+        if ((ABL & 8) && PH == 1) K64R_SPREAD_STORE(ROLE);                                                                              \
     } while (0)
 #define K64R_PHASE(ROLE, PH)                                                                                                        \
     do {                                                                                                                            \
@@ -1795,9 +1845,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         SCHED_FENCE();                                                                                                              \
         K64R_HOOK(ROLE, PH);                                                                                                        \
         SCHED_FENCE();                                                                                                              \
-        if (!late) { glds_wait_le<WT::W[ROLE][PH]>(); K64_BARRIER(); }                                                              \
+        if (!late) { glds_wait_le<((ABL & 16) ? 63 : (ABL & 32) ? K64RTwoStoreWaits::W[PH] : (ABL & 8) ? K64RSpreadWaits::W[PH] : WT::W[ROLE][PH])>(); K64_BARRIER(); }   \
         K64R_MFMA(PH, ((ROLE != 0 || RES) ? 0 : (BIAS ? 1 : 2)));                                                                  \
-        if (late) { glds_wait_le<WT::W[ROLE][PH]>(); K64_BARRIER(); }                                                               \
+        if (late) { glds_wait_le<((ABL & 48) == 48 ? K64RSplitWaits::W[PH] : (ABL & 16) ? K64RProxyWaits::W[PH] : (ABL & 32) ? WT::W[1][PH] : (ABL & 8) ? K64RSpreadWaits::W[PH] : WT::W[ROLE][PH])>(); K64_BARRIER(); }    \
     } while (0)
 #define K64R_TILE(ROLE) do { K64R_PHASE(ROLE, 0); K64R_PHASE(ROLE, 1); K64R_PHASE(ROLE, 2); K64R_PHASE(ROLE, 3); so ^= STAGE; } while (0)
 
@@ -1807,10 +1857,14 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         else { ni0 = i0; nj0 = j0; pgn = pgc; qgn = qgc; }   // the look-ahead of the last tile re-reads the tile's own operands (never consumed)
         // (t stays a run-time value: with literal K-tile numbers hipcc precomputes a 64-bit DMA address vector per (role, piece) and spills them)
         t = 0; K64R_OPAQUE(t); K64R_TILE(0);
+        if (ABL & 8) {
+            for (++t; t < nk; ++t) K64R_TILE(1);
+        } else {
         for (++t; t < nk - 1; ++t) K64R_TILE(1);
         K64R_OPAQUE(t);
         K64R_TILE(2);
-        pending = true; ei0 = i0; ej0 = j0;
+        }
+        pending = !(ABL & 8); ei0 = i0; ej0 = j0;
         if (!more) break;
         local += per_xcd;
         i0 = ni0; j0 = nj0; pgc = pgn; qgc = qgn;
@@ -1820,10 +1874,16 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     if (RES) { K64R_VMFENCE4(0, rv[0]); K64R_VMFENCE4(0, rv[1]); K64R_VMFENCE4(0, rv[2]); }
     glds_wait_all();
     SCHED_FENCE();
-    K64R_EPIQ(3, ei0, ej0);
+    if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
+#ifndef ANTMMF_EMULATE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_k64_clk[0] = __builtin_readcyclecounter() - clk0; g_k64_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
 #undef K64R_TILE
 #undef K64R_PHASE
 #undef K64R_HOOK
+#undef K64R_SPREAD_STORE
+#undef K64R_SPREAD_BLOCK
+#undef K64R_SPREAD_BLOCK1
 #undef K64R_MFMA
 #undef K64R_READS
 #undef K64R_PIECE
@@ -2247,9 +2307,17 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 56>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     oncer = true;                                                                                                 \
                 }                                                                                                                 \
-                if (g_gemm_variant & 32768) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                if ((g_gemm_variant & 1572864) == 1572864 && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 56>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 1048576) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 40>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 524288) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 24>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 262144) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 8>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if (g_gemm_variant & 32768) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
             }                                                                                                                     \

@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
             const double med = ms[vi][ms[vi].size() / 2], best = ms[vi][0];
             const double fl = 2.0 * tokens * s.J * s.R;
             double mhz = 0;
-            if (getclk && (variants[vi] & 256)) { run(variants[vi], C1); CK(hipDeviceSynchronize()); unsigned long long c2[2] = {0, 0}; getclk(c2); if (c2[1]) mhz = (double)c2[0] / (double)c2[1] * 100.0; }
+            if (getclk) { for (int it = 0; it < 8; ++it) run(variants[vi], C1); CK(hipDeviceSynchronize()); unsigned long long c2[2] = {0, 0}; getclk(c2); if (c2[1]) mhz = (double)c2[0] / (double)c2[1] * 100.0; }
             printf("{\"shape\": \"%s\", \"clock_mhz\": %.0f, \"I\": %ld, \"J\": %d, \"R\": %d, \"epi\": %d, \"variant\": %d, \"pad\": %d, \"ms_med\": %.4f, \"tf_med\": %.1f, \"tf_best\": %.1f, \"maxdiff_vs_v0\": %g}\n",
                    s.tag, mhz, tokens, s.J, s.R, s.bias | (s.res << 1), variants[vi], pad, med, fl / med * 1e-9, fl / best * 1e-9, diff[vi]);
             fflush(stdout);
