@@ -810,11 +810,11 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     static const char* av_env = getenv("ANTMMF_ATTN_VARIANT");
     const int av = av_env ? atoi(av_env) : 0;
     if constexpr (DH == 64) {
-        if (!a.drop_thr && nch > 3 && (av & 4)) {
+        if (!a.drop_thr && (nch == 7 || nch == 9) && (av & 4)) {   // (its padding mask covers the LAST 32-key tile only: the key count must fill the instantiated tile count)
 #define FWD32K(N, HB, KB) do { const size_t lds = (size_t)(32 * N) * 256 + (32 * N) * 4 + 8 * 2 * 68 * 4; set_lds(attn_fwd32_kernel<N, HB, KB>, lds); \
             hipLaunchKernelGGL((attn_fwd32_kernel<N, HB, KB>), grid, block, lds, stream, a); } while (0)
 #define FWD32(N, HB) do { if (av & 2) FWD32K(N, HB, 2); else FWD32K(N, HB, 1); } while (0)   /* variant bit 1: 64-key softmax blocks */
-            if (nch <= 7) { if (a.key_bias) FWD32(7, true); else FWD32(7, false); }
+            if (nch == 7) { if (a.key_bias) FWD32(7, true); else FWD32(7, false); }
             else { if (a.key_bias) FWD32(9, true); else FWD32(9, false); }
 #undef FWD32
 #undef FWD32K

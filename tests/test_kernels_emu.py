@@ -201,6 +201,23 @@ def test_attention_masks(ops):
     kc.case_attention(ops, DEV, B=2, heads=1, Nq=12, Nk=12, bias_kind="inf")
 
 
+@pytest.mark.parametrize("variant", [4, 6])
+def test_attention_fwd32_opt_in(variant):
+    """attn_fwd32_kernel (32 x 32 x 16 MFMA tiles, online softmax over 32- / 64-key blocks; opt-in, ANTMMF_ATTN_VARIANT bits 2 / 1 -- measured slower than the
+    whole-row kernel): forward against the oracle on the key counts that select it (193 - 224 and 257 - 288 keys: 7 or 9 tiles of 32), with and without a key bias, ragged query
+    count (a last 32-query tile with ONE valid row, as the 257-token tower has); the backward of the same case consumes its output and lse."""
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_ATTN_VARIANT'] = '%d';"
+            "import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cpu');"
+            "kc.case_attention(ops, dev, B=1, heads=1, Nq=257, Nk=257, bias_kind='none');"
+            "kc.case_attention(ops, dev, B=2, heads=1, Nq=200, Nk=200, bias_kind='inf');"
+            "kc.case_attention(ops, dev, B=1, heads=2, Nq=33, Nk=270, bias_kind='bert', packed=False);"
+            "print('okfwd32')" % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 

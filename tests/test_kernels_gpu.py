@@ -207,6 +207,25 @@ def test_attention(ops, cfg):
     kc.case_attention(ops, DEV, **cfg)
 
 
+@pytest.mark.parametrize("variant", [4, 6])
+def test_attention_fwd32_opt_in(variant):
+    """The opt-in forward on 32 x 32 x 16 MFMA tiles (ANTMMF_ATTN_VARIANT bit 2; bit 1: 64-key softmax blocks) at the towers' sizes: 257 tokens x 16 heads (ViT-L/14),
+    197 x 12 (ViT-B/16), a masked and a cross case -- forward vs the oracle, its output + lse through the (unchanged) backward kernels."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_ATTN_VARIANT'] = '%d';"
+            "import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cuda:0');"
+            "kc.case_attention(ops, dev, B=2, heads=16, Nq=257, Nk=257, bias_kind='none');"
+            "kc.case_attention(ops, dev, B=2, heads=12, Nq=197, Nk=197, bias_kind='none');"
+            "kc.case_attention(ops, dev, B=3, heads=2, Nq=200, Nk=200, bias_kind='inf');"
+            "kc.case_attention(ops, dev, B=2, heads=2, Nq=33, Nk=270, bias_kind='bert', packed=False);"
+            "print('okfwd32')" % (os.path.join(root, "tests"), os.path.join(root, "ant-multi-modal-framework_amd"), root, variant))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_moco_and_ema(ops):
     kc.case_moco(ops, DEV)
     kc.case_moco(ops, DEV, R=5, Np=1, K=64)

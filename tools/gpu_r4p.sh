@@ -8,13 +8,11 @@ mkdir -p $P
 rocprofv3 --list-avail > $P.avail.txt 2>&1
 grep -o "TA_[A-Z0-9_a-z]*\|TCP_[A-Z0-9_a-z]*\|TD_[A-Z0-9_a-z]*\|SQ_INST_CYCLES[A-Z0-9_a-z]*\|SQ_INSTS_VMEM[A-Z_a-z]*\|SQ_WAIT[A-Z_a-z]*\|SQ_ACTIVE_INST[A-Z_a-z]*" $P.avail.txt | sort -u | tr '\n' ' ' | cut -c1-6000
 echo
-run() { v=$1; name=$2; shift; shift; ANTMMF_GEMM_VARIANT=$v timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/v${v}_$name -o p -- python $GRAFT_REPO_ROOT/tools/gemm_pmc2.py 4096 1024 6 > $P.v${v}_$name.log 2>&1; echo "v$v $name rc=$?"; }
+run() { v=$1; name=$2; shift; shift; ANTMMF_GEMM_VARIANT=$v timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $P/v${v}_$name -o p -- python $GRAFT_REPO_ROOT/tools/gemm_pmc2.py 4096 1024 6 > $P.v${v}_$name.log 2>&1; echo "v$v $name rc=$?"; }
 for v in 8196 40964; do
 run $v sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run $v sq2 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE
-run $v ta1 TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum GRBM_GUI_ACTIVE
-run $v tcp1 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum
-run $v tcp2 TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_WRITE_sum TCP_TOTAL_READ_sum TD_TD_BUSY_sum
+# (TA_* / TCP_* / TD_* passes HANG on this pool until the timeout -- 3 x 300 s lost in round 4: not scheduled)
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
