@@ -57,8 +57,8 @@ M2_TRAIN_GFLOP_PER_PAIR = {"l14": 627.3, "b16": 145.3}  # BASELINE.md section 4 
 # Its numbers mean nothing and its line says so (`"data": "dry run"`).
 DRY_RUN = os.environ.get("ANTMMF_BENCH_DRY_RUN") == "1"
 if DRY_RUN:
-    M2_WORKLOADS["tiny"] = dict(beit_version="base", encoder_embed_dim=128, out_embed_dim=64, encoder_layers=2, beit3_vl_layers=1,
-                                image_size=32, patch_size=8, vocab_size=300, max_text_len=12, encoder_attention_heads=2)
+    M2_WORKLOADS["tiny"] = dict(beit_version="base", encoder_embed_dim=64, out_embed_dim=64, encoder_layers=1, beit3_vl_layers=1,
+                                image_size=16, patch_size=8, vocab_size=300, max_text_len=8, encoder_attention_heads=1)
     M2_TRAIN_GFLOP_PER_PAIR["tiny"] = 0.01
 
 
@@ -552,7 +552,7 @@ def main():
                     "b16": "M2_Encoder ViT-B/16 (beit base, 9+3 layers) ITC train step, 224x224x3 + 77 tokens",
                     "vtp8": "univl (clip arch) video-text train step: 8 clips x 224x224x3 per video + 77 tokens, MIL-NCE over all clips + cross-encoder scores of every text x video pair",
                     "dmae12": "univl (DMAE) video-text train step: 12 frames x 224x224x3 per video + 30 words, MIL-NCE + seqTransf / WTI / NegNCE / TPM-CL",
-                    "tiny": "toy M2 (d = 128, 2 + 1 layers, 32 x 32 images, 12 tokens)"}[a.workload]
+                    "tiny": "toy M2 (d = 64, 1 + 1 layers, 16 x 16 images, 8 tokens)"}[a.workload]
         out = {
             "metric": metric, "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

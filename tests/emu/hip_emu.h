@@ -8,7 +8,13 @@
 // D[4*(l>>4)+r][l&15]).  It is never linked into the product library and never runs on the GPU box's
 // product path; the real-hardware parity tests (-m gpu) remain the authority.
 #pragma once
+#include <array>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
@@ -60,34 +66,48 @@ struct Block {
 struct TLS { dim3 tid, bid, gdim, bdim; Block* blk; Wave* wave; int lane; };
 inline thread_local TLS tls;
 
+// One set of OS threads per LAUNCH (not per workgroup: spawning 256 - 512 threads costs ~10 ms, an elementwise launch of a few hundred workgroups was seconds):
+// the threads walk the workgroups in order; between two workgroups they meet at a gate, thread 0 builds the next workgroup's state (fresh barriers --
+// threads that return early DROP out of a workgroup's barriers -- and zeroed LDS), and they meet again.
 template <typename F>
 void launch(F&& body, dim3 grid, dim3 block, size_t lds) {
     const int nt = (int)(block.x * block.y * block.z);
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                Block blk;
-                blk.nthreads = nt;
-                blk.bar = std::make_unique<std::barrier<>>(nt);
-                for (int w = 0; w < (nt + 63) / 64; ++w) blk.waves.emplace_back(new Wave());
-                blk.dyn.assign(lds + 64, 0);
-                std::vector<std::thread> th;
-                for (int t = 0; t < nt; ++t)
-                    th.emplace_back([&, t] {
-                        tls.tid = dim3((unsigned)t, 0, 0);
-                        tls.bid = dim3(bx, by, bz);
-                        tls.gdim = grid;
-                        tls.bdim = block;
-                        tls.blk = &blk;
-                        tls.wave = blk.waves[t / 64].get();
-                        tls.lane = t % 64;
-                        body();
-                        // a thread that returns early must keep the barriers balanced
-                        tls.wave->bar.arrive_and_drop();
-                        blk.bar->arrive_and_drop();
-                    });
-                for (auto& x : th) x.join();
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    if (nblocks <= 0 || nt <= 0) return;
+    std::unique_ptr<Block> cur;
+    auto make_block = [&] {
+        cur.reset(new Block());
+        cur->nthreads = nt;
+        cur->bar = std::make_unique<std::barrier<>>(nt);
+        for (int w = 0; w < (nt + 63) / 64; ++w) cur->waves.emplace_back(new Wave());
+        cur->dyn.assign(lds + 64, 0);
+    };
+    make_block();
+    std::barrier<> gate(nt);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (long bi = 0; bi < nblocks; ++bi) {
+                if (bi > 0) {
+                    gate.arrive_and_wait();          // every thread is out of the previous workgroup
+                    if (t == 0) make_block();
+                    gate.arrive_and_wait();
+                }
+                Block* blk = cur.get();
+                tls.tid = dim3((unsigned)t, 0, 0);
+                tls.bid = dim3((unsigned)(bi % grid.x), (unsigned)((bi / grid.x) % grid.y), (unsigned)(bi / ((long)grid.x * grid.y)));
+                tls.gdim = grid;
+                tls.bdim = block;
+                tls.blk = blk;
+                tls.wave = blk->waves[t / 64].get();
+                tls.lane = t % 64;
+                body();
+                // a thread that returns early must keep the barriers balanced
+                tls.wave->bar.arrive_and_drop();
+                blk->bar->arrive_and_drop();
             }
+        });
+    for (auto& x : th) x.join();
 }
 inline char* dyn_smem() {
     char* p = tls.blk->dyn.data();
@@ -99,7 +119,25 @@ inline char* dyn_smem() {
 #define blockIdx (emu::tls.bid)
 #define gridDim (emu::tls.gdim)
 #define blockDim (emu::tls.bdim)
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch([&] { kernel(__VA_ARGS__); }, grid, block, lds)
+namespace emu {
+// ANTMMF_EMU_TRACE=1: host seconds, launches and workgroups per kernel, printed at exit (where an emulated test spends its time)
+struct Trace {
+    std::map<std::string, std::array<double, 3>> acc;
+    bool on = std::getenv("ANTMMF_EMU_TRACE") != nullptr;
+    ~Trace() { if (on) for (auto& kv : acc) std::fprintf(stderr, "[emu] %9.3f s %6.0f launches %9.0f workgroups  %s\n", kv.second[0], kv.second[1], kv.second[2], kv.first.c_str()); }
+};
+inline Trace& trace() { static Trace t; return t; }
+template <typename F>
+void traced_launch(const char* name, F&& body, dim3 grid, dim3 block, size_t lds) {
+    Trace& t = trace();
+    if (!t.on) { launch(body, grid, block, lds); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    launch(body, grid, block, lds);
+    auto& a = t.acc[name];
+    a[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); a[1] += 1; a[2] += (double)grid.x * grid.y * grid.z;
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::traced_launch(#kernel, [&] { kernel(__VA_ARGS__); }, grid, block, lds)
 
 static inline void __syncthreads() { emu::tls.blk->bar->arrive_and_wait(); }
 static inline void emu_wave_barrier() { emu::tls.wave->bar.arrive_and_wait(); }
