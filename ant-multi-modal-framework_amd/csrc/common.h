@@ -141,6 +141,39 @@ __device__ __forceinline__ float rows4_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 #endif
+// lane_bit_exchange<K>(a, b, lane): the register pair (a, b) is a one-bit index p (a: p = 0, b: p = 1); exchange that index with bit K of the lane number, i.e. swap
+// element (lane bit K = 0, b) with element (lane bit K = 1, a) of the partner lane l ^ (1 << K).  K = 5 / 4 are v_permlane32_swap / v_permlane16_swap; K = 0 .. 2 one
+// select, one (two for K = 2) DPP move and two selects.  A sequence of these is a bit permutation of (lane, p): how the GEMM epilogue turns "16 rows x 16 B per 16 lanes"
+// into "2 rows x 128 B per 16 lanes" before it stores (gemm_nt_k64r_kernel).
+template <int K>
+__device__ __forceinline__ void lane_bit_exchange(uint32_t& a, uint32_t& b, int lane) {
+#ifdef ANTMMF_EMULATE
+    const bool hi = (lane >> K) & 1;
+    const uint32_t x = hi ? a : b;
+    const uint32_t y = __float_as_uint(__shfl_xor(__uint_as_float(x), 1 << K));
+    if (hi) a = y; else b = y;
+#else
+    if constexpr (K == 5) {
+        const antmmf_u2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (K == 4) {
+        const antmmf_u2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    } else {
+        const bool hi = (lane >> K) & 1;
+        const uint32_t x = hi ? a : b;
+        uint32_t y;
+        if constexpr (K == 0) y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);        // quad_perm [1, 0, 3, 2]: lane ^ 1
+        else if constexpr (K == 1) y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]: lane ^ 2
+        else {                                                                                              // row_half_mirror (l ^ 7) then quad_perm [3, 2, 1, 0] (l ^ 3): lane ^ 4
+            const int t = __builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);
+            y = (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xf, 0xf, true);
+        }
+        a = hi ? y : a;
+        b = hi ? b : y;
+    }
+#endif
+}
 #ifdef ANTMMF_EMULATE
 __device__ __forceinline__ float wave_max(float v) { return emu_wave_max(v); }
 #else

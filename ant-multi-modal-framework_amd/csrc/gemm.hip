@@ -1652,6 +1652,19 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     const uint32_t cvoff = (uint32_t)((l15 * (int)g.ldc + (lane >> 5) * 16 + (grp & 1) * 8) * 2);
     const uint32_t cvoff128 = cvoff + (uint32_t)(128 * (int)g.ldc * 2);   // (ABL 16: the same lane position 128 rows down)
     (void)cvoff128;
+    // the store layout behind the two lane-bit exchanges of K64R_EPIQ: fragment row (l15 & 14) (+ 1 for the second register), 16-byte column chunk 4 l4 + 2 l5 + l0
+    const int trow = l15 & 14, tchunk = ((lane >> 4) & 1) * 4 + (lane >> 5) * 2 + (lane & 1);
+    const uint32_t cvoff_t0 = (uint32_t)((trow * (int)g.ldc + tchunk * 8) * 2), cvoff_t1 = cvoff_t0 + (uint32_t)((int)g.ldc * 2);
+    const uint32_t avoff_t0 = ACT2 ? (uint32_t)((trow * (int)g.ldaux + tchunk * 8) * 2) : 0u, avoff_t1 = avoff_t0 + (ACT2 ? (uint32_t)((int)g.ldaux * 2) : 0u);
+    const uint32_t rvoff_t0 = RES ? (uint32_t)((trow * (int)g.ldr + tchunk * 8) * 2) : 0u, rvoff_t1 = rvoff_t0 + (RES ? (uint32_t)((int)g.ldr * 2) : 0u);
+    (void)cvoff_t0; (void)cvoff_t1; (void)avoff_t0; (void)avoff_t1; (void)rvoff_t0; (void)rvoff_t1;
+    // (ABL 64, timing only: every store instruction writes 8 rows x 128 B -- eight FULL cache lines -- instead of 16 rows x 64 B; same bytes per tile, data in the wrong places)
+    const uint32_t cvoff_fl0 = (uint32_t)(((lane >> 3) * (int)g.ldc + (lane & 7) * 8) * 2), cvoff_fl1 = cvoff_fl0 + (uint32_t)(8 * (int)g.ldc * 2);
+    (void)cvoff_fl0; (void)cvoff_fl1;
+    // (ABL 256 / 512, timing only: 8 rows x 32 B resp. 4 rows x 64 B per 16-lane pass -- what ONE resp. TWO of the lane-bit exchanges would give)
+    const uint32_t cvoff_p32 = (uint32_t)((((lane >> 1) & 7) * (int)g.ldc + (2 * (lane >> 4) + (lane & 1)) * 8) * 2), cvoff_p32b = cvoff_p32 + (uint32_t)(8 * (int)g.ldc * 2);
+    const uint32_t cvoff_p64 = (uint32_t)(((lane >> 2) * (int)g.ldc + (lane & 3) * 8) * 2);
+    (void)cvoff_p32; (void)cvoff_p32b; (void)cvoff_p64;
     const uint32_t rvoff = RES ? (uint32_t)((l15 * (int)g.ldr + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const uint32_t avoff = ACT2 ? (uint32_t)((l15 * (int)g.ldaux + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const int pbg = ((grp & 1) << 1) | (grp >> 1);
@@ -1662,8 +1675,8 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     do {                                                                                                                            \
         _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
             const char* rb = reinterpret_cast<const char*>(g.residual) + ((long)((ti0) + wi * 128 + (2 * (QQ) + ih) * 16) * g.ldr + (tj0) + wj * 64) * 2; \
-            K64R_GLOAD16(rv[QQ][2 * ih], rvoff, rb, 0);                                                                             \
-            K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff, rb, 64);                                                                        \
+            if (ABL & 128) { K64R_GLOAD16(rv[QQ][2 * ih], rvoff, rb, 0); K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff, rb, 64); }        \
+            else { K64R_GLOAD16(rv[QQ][2 * ih], rvoff_t0, rb, 0); K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff_t1, rb, 0); }              \
         }                                                                                                                           \
     } while (0)
 
@@ -1699,6 +1712,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
             const int it = 2 * (QQ) + ih;                                                                                           \
             char* cb = reinterpret_cast<char*>(g.C) + ((long)((ti0) + wi * 128 + it * 16) * g.ldc + (tj0) + wj * 64) * 2;           \
             f2_t t1 = f2_splat(0.f), t2 = f2_splat(0.f);   /* FFN1: row sums of the ROUNDED activation (what fc2 multiplies) */      \
+            u32x4_t ov2[2], av2[2];                                                                                                 \
             _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
                 u32x4_t ov, av;                                                                                                     \
                 _Pragma("unroll") for (int rr = 0; rr < 4; rr += 2) {                                                               \
@@ -1717,18 +1731,43 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
                         ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                               \
                     }                                                                                                               \
                 }                                                                                                                   \
-                if (ACT2) {                                                                                                         \
-                    char* ab = reinterpret_cast<char*>(g.aux) + ((long)((ti0) + wi * 128 + it * 16) * g.ldaux + (tj0) + wj * 64) * 2; \
-                    if (p2 == 0) K64R_GSTORE16(avoff, av, ab, 0); else K64R_GSTORE16(avoff, av, ab, 64);                            \
-                }                                                                                                                   \
                 if (FFN1) {                                                                                                         \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) { const f2_t zr = f2_bf(ov[e]); t1 += zr; t2 += zr * zr; }        \
                 }                                                                                                                   \
-                if (ABL & 1) K64R_KEEP(ov);                                                                                         \
-                else if (ABL & 4) { if (p2 == 0) K64R_GSTORE16_NT(cvoff, ov, cb, 0); else K64R_GSTORE16_NT(cvoff, ov, cb, 64); }         \
-                else if (p2 == 0) K64R_GSTORE16(cvoff, ov, cb, 0); else K64R_GSTORE16(cvoff, ov, cb, 64);                           \
+                ov2[p2] = ov; if (ACT2) av2[p2] = av;                                                                               \
                 SCHED_FENCE();                                                                                                      \
             }                                                                                                                       \
+            /* here a lane holds row l15 of the fragment, columns [8 grp, +8) in ov2[0] and [32 + 8 grp, +8) in ov2[1]: stored like that, each 16-lane pass of a store    \
+               instruction touches 16 cache lines with 16 bytes each.  Two exchanges of the pair index with a lane bit (4: v_permlane16_swap, then 0: one DPP move + three   \
+               selects) turn it into: lane holds fragment row (l15 & 14) + p, 16-byte column chunk 4 l4 + 2 l5 + l0 -- a pass writes 8 lines with 32 contiguous bytes each.   \
+               Measured with the data misplaced, i.e. without any exchange code (profiles/r4_gemm_store_shapes.txt): 16 x 16 B 1238 - 1244 TF, 8 x 32 B 1276 - 1292,           \
+               4 x 64 B 1286 - 1296, 2 whole lines 1292 - 1303; and with the exchanges that each layout needs: all five 1230 - 1238 (their ~ 60 VALU operations per 16 rows are  \
+               not covered by the partner wave's MFMA block), these two: see the same file */                                                                              \
+            if (!(ABL & (128 | 64 | 256 | 512 | 1))) {                                                                              \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                     \
+                    uint32_t xa = ov2[0][e], xb = ov2[1][e];                                                                        \
+                    lane_bit_exchange<4>(xa, xb, lane); lane_bit_exchange<0>(xa, xb, lane);                                         \
+                    ov2[0][e] = xa; ov2[1][e] = xb;                                                                                 \
+                    if (ACT2) {                                                                                                     \
+                        uint32_t ya = av2[0][e], yb = av2[1][e];                                                                    \
+                        lane_bit_exchange<4>(ya, yb, lane); lane_bit_exchange<0>(ya, yb, lane);                                     \
+                        av2[0][e] = ya; av2[1][e] = yb;                                                                             \
+                    }                                                                                                               \
+                }                                                                                                                   \
+            }                                                                                                                       \
+            if (ACT2) {                                                                                                             \
+                char* ab = reinterpret_cast<char*>(g.aux) + ((long)((ti0) + wi * 128 + it * 16) * g.ldaux + (tj0) + wj * 64) * 2;   \
+                if (ABL & 128) { K64R_GSTORE16(avoff, av2[0], ab, 0); K64R_GSTORE16(avoff, av2[1], ab, 64); }                       \
+                else { K64R_GSTORE16(avoff_t0, av2[0], ab, 0); K64R_GSTORE16(avoff_t1, av2[1], ab, 0); }                            \
+            }                                                                                                                       \
+            if (ABL & 1) { K64R_KEEP(ov2[0]); K64R_KEEP(ov2[1]); }                                                                  \
+            else if (ABL & 64) { K64R_GSTORE16(cvoff_fl0, ov2[0], cb, 0); K64R_GSTORE16(cvoff_fl1, ov2[1], cb, 0); }                \
+            else if (ABL & 256) { K64R_GSTORE16(cvoff_p32, ov2[0], cb, 0); K64R_GSTORE16(cvoff_p32b, ov2[1], cb, 0); }              \
+            else if (ABL & 512) { K64R_GSTORE16(cvoff_p64, ov2[0], cb, 0); K64R_GSTORE16(cvoff_p64, ov2[1], cb, 64); }              \
+            else if (ABL & 4) { K64R_GSTORE16_NT(cvoff_t0, ov2[0], cb, 0); K64R_GSTORE16_NT(cvoff_t1, ov2[1], cb, 0); }             \
+            else if (ABL & 128) { K64R_GSTORE16(cvoff, ov2[0], cb, 0); K64R_GSTORE16(cvoff, ov2[1], cb, 64); }                      \
+            else { K64R_GSTORE16(cvoff_t0, ov2[0], cb, 0); K64R_GSTORE16(cvoff_t1, ov2[1], cb, 0); }                                \
+            SCHED_FENCE();                                                                                                          \
             if (FFN1) {   /* close the row over its four lanes; all four write the same 8 bytes (no exec mask inside the asm store) */ \
                 const float r1 = rows4_sum(t1.x + t1.y), r2 = rows4_sum(t2.x + t2.y);                                               \
                 char* pb2 = reinterpret_cast<char*>(g.part) + ((long)(((tj0) + wj * 64) >> 6) * g.I + (ti0) + wi * 128 + it * 16) * 8; \
@@ -1742,7 +1781,14 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #define K64R_INIT(QQ)                                                                                                               \
     do {                                                                                                                            \
         K64R_VMFENCE4(WT::INIT[QQ], rv[QQ]);                                                                                        \
-        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih)                                                                            \
+        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
+            if (!(ABL & 128)) {   /* the vectors were requested in the store layout (8 lines x 32 B per pass): back to "row l15, chunk grp / 4 + grp" */ \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                     \
+                    uint32_t xa = rv[QQ][2 * ih][e], xb = rv[QQ][2 * ih + 1][e];                                                    \
+                    lane_bit_exchange<0>(xa, xb, lane); lane_bit_exchange<4>(xa, xb, lane);                                         \
+                    rv[QQ][2 * ih][e] = xa; rv[QQ][2 * ih + 1][e] = xb;                                                             \
+                }                                                                                                                   \
+            }                                                                                                                       \
             _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
                 const u32x4_t w = rv[QQ][2 * ih + p2];                                                                              \
                 _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                                  \
@@ -1754,6 +1800,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
                 }                                                                                                                   \
                 SCHED_FENCE();                                                                                                      \
             }                                                                                                                       \
+        }                                                                                                                           \
     } while (0)
 #define K64R_PIECE(IDX)                                                                                                             \
     do {                                                                                                                            \
@@ -2298,10 +2345,10 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             const unsigned gridp = (g_gemm_variant & 64) ? t8 : (pwgs < t8 ? pwgs : t8);                                          \
             constexpr int PROD = K64F_ONEBAR | ((E & 2) && E != 4 ? K64F_DIST11 : 0);                                             \
             /* the rolling-epilogue kernel (bias / residual start the accumulators, stores inside the K loop; plain write-back stores).  Same-process A/B    \
-               against the burst epilogue (profiles/r4_gemm_rolling_epilogue_ab.txt): + 1 ... + 3 % on every shape of the step except the small plain one  \
-               (R = J = 1024, no operands: - 2.7 %), which stays on the kernel above.  Variant bit 13 forces it for every R >= 192, bit 14 disables it;     \
-               bits 15 / 17: ablations (no stores / non-temporal stores) */                                                                                \
-            if (E < 4 && !(g_gemm_variant & 16384) && R >= 192 && ((g_gemm_variant & 8192) || E != 0 || R > 1024 || J > 1024)) {  \
+               against the burst epilogue (profiles/r4_gemm_rolling_epilogue_ab.txt, r4_gemm_store_shapes.txt): + 1 ... + 5 % on every shape of the step   \
+               since its stores and residual loads move 32 contiguous bytes per row and pass.  Variant bit 14 disables it, bit 22 selects the first layout  \
+               (16 rows x 16 B per pass); bits 15 / 17 / 18 - 24: timing-only ablations (no stores, non-temporal stores, store shapes and placements) */    \
+            if (E < 4 && !(g_gemm_variant & 16384) && R >= 192) {                                                                 \
                 static bool oncer = false;                                                                                        \
                 if (!oncer) {                                                                                                     \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
@@ -2311,9 +2358,17 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 56>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     oncer = true;                                                                                                 \
                 }                                                                                                                 \
-                if ((g_gemm_variant & 1572864) == 1572864 && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 56>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                if ((g_gemm_variant & 8388608) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 256>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 16777216) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 512>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if (g_gemm_variant & 4194304) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 2097152) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 64>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else if ((g_gemm_variant & 1572864) == 1572864 && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 56>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if ((g_gemm_variant & 1048576) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 40>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if ((g_gemm_variant & 524288) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 24>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if ((g_gemm_variant & 262144) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 8>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
