@@ -153,6 +153,23 @@ __device__ __forceinline__ void stage_key_bias(float* kb, const AttnArgs& a, int
 // ---- forward ----------------------------------------------------------------------------------------
 // DROP: attention-probability dropout compiled in (a separate instantiation: the mask arithmetic in the inner loops costs registers
 // -- with it folded in at run time the no-dropout backward dropped from 3 to 2 waves per SIMD and ran 1.7x slower)
+// Row stores of a transposed output tile (lane (l15, grp): row l15, columns 16 dt + 4 grp + [0, 4) per 16-column tile dt: 8 bytes per tile): the pieces of an even / odd pair of
+// column tiles are exchanged between the lanes l and l ^ 16 (lane_bit_exchange<4> = v_permlane16_swap), after which a lane holds 8 consecutive columns of ONE tile of the pair --
+// one 16-byte store per pair instead of two 8-byte stores (half the store instructions, twice the bytes per row and pass).  Every lane of the wave must call it (cross-lane).
+template <int NDT>
+__device__ __forceinline__ void store_rows_paired(bf16_t* rowp, uint2 (&w)[NDT], int lane, int grp, bool valid, bool al16) {
+#pragma unroll
+    for (int k = 0; k < NDT / 2; ++k) {
+        lane_bit_exchange<4>(w[2 * k].x, w[2 * k + 1].x, lane);
+        lane_bit_exchange<4>(w[2 * k].y, w[2 * k + 1].y, lane);
+        if (valid) {
+            bf16_t* p = rowp + 16 * (2 * k + (grp & 1)) + 4 * (grp & 2);
+            if (al16) *reinterpret_cast<uint4*>(p) = make_uint4(w[2 * k].x, w[2 * k].y, w[2 * k + 1].x, w[2 * k + 1].y);
+            else { *reinterpret_cast<uint2*>(p) = w[2 * k]; *reinterpret_cast<uint2*>(p + 4) = w[2 * k + 1]; }
+        }
+    }
+}
+
 template <int NCH, bool DROP, int DH>  // keys padded to 32 * NCH
 __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
 
     const float scale2 = a.scale * LOG2E;
     const int nqt = (a.Nq + 15) >> 4;
+    const bool o_al16 = !(a.ldo & 7) && !((uintptr_t)a.o & 15);
     // the query fragments of a tile come straight from global memory: the NEXT tile's are requested before the current tile is
     // processed (PMC: 68 % of the wave cycles were spent parked on s_waitcnt with the loads issued at the point of use)
     auto q_ptr = [&](int qt) {
@@ -226,6 +244,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
         bf16x8_t pf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) pf[c] = pack_frag(s[2 * c], s[2 * c + 1]);
+        uint2 ow[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             LDS_FENCE();
@@ -233,10 +252,9 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
-            if (qi < a.Nq)
-                *reinterpret_cast<uint2*>(a.o + ((long)b * a.Nq + qi) * a.ldo + h * DH + 16 * dt + 4 * grp) =
-                    make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
+            ow[dt] = make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
         }
+        store_rows_paired<DT>(a.o + ((long)b * a.Nq + qrow) * a.ldo + h * DH, ow, lane, grp, qi < a.Nq, o_al16);
         if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
     }
 }
@@ -507,6 +525,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq64_kernel(const At
 
     const float scale2 = a.scale * LOG2E, inv_scale2 = 1.0f / scale2;
     const int nqt = (a.Nq + 15) >> 4;
+    const bool dq_al16 = !(a.lddq & 7) && !((uintptr_t)a.dq & 15);
     // (unlike the forward / dK-dV kernels this one loads its tile operands at the point of use: with a one-tile-ahead prefetch hipcc
     // hoists the unrolled LDS fragment reads as well and lands at 256 VGPRs + scratch, i.e. 2 waves per SIMD -- measured slower)
     bf16x8_t nq0 = {}, nq1 = {}, nd0 = {}, nd1 = {};
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq64_kernel(const At
             dsf[c] = pack_frag(ds[0], ds[1]);
         }
         // request the next tile's operands now: the register-hungry score phase is over, the dQ phase (36 MFMAs) covers the latency
+        uint2 gw[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             LDS_FENCE();
@@ -585,10 +605,9 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void attn_bwd_dq64_kernel(const At
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
-            if (qi < a.Nq)
-                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * 64 + 16 * dt + 4 * grp) =
-                    make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
+            gw[dt] = make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
         }
+        store_rows_paired<4>(a.dq + ((long)b * a.Nq + qrow) * a.lddq + h * 64, gw, lane, grp, qi < a.Nq, dq_al16);
     }
 }
 #undef DQ_FETCH
@@ -609,6 +628,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dq_ke
 
     const float scale2 = a.scale * LOG2E, inv_scale2 = 1.0f / scale2;
     const int nqt = (a.Nq + 15) >> 4;
+    const bool dq_al16 = !(a.lddq & 7) && !((uintptr_t)a.dq & 15);
     // (unlike the forward / dK-dV kernels this one loads its tile operands at the point of use: with a one-tile-ahead prefetch hipcc
     // hoists the unrolled LDS fragment reads as well and lands at 256 VGPRs + scratch, i.e. 2 waves per SIMD -- measured slower)
     bf16x8_t nq[KM] = {}, nd[KM] = {};
@@ -683,6 +703,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dq_ke
             }
             dsf[c] = pack_frag(ds[0], ds[1]);
         }
+        uint2 gw[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             LDS_FENCE();
@@ -690,10 +711,9 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dq_ke
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
                 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Ks, c, dt, grp, l15), dsf[c], g, 0, 0, 0);
-            if (qi < a.Nq)
-                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi) * a.lddq + h * DH + 16 * dt + 4 * grp) =
-                    make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
+            gw[dt] = make_uint2(pack_bf2(g[0] * a.scale, g[1] * a.scale), pack_bf2(g[2] * a.scale, g[3] * a.scale));
         }
+        store_rows_paired<DT>(a.dq + ((long)b * a.Nq + qrow) * a.lddq + h * DH, gw, lane, grp, qi < a.Nq, dq_al16);
     }
 }
 
@@ -735,6 +755,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 
     const float scale2 = a.scale * LOG2E;
     const int nkt = (a.Nk + 15) >> 4, nqc = NQP >> 5;
+    const bool dkv_al16 = !(a.lddk & 7) && !(a.lddv & 7) && !((uintptr_t)a.dk & 15) && !((uintptr_t)a.dv & 15);
     // (K / V fragments are loaded at the point of use: a one-tile-ahead prefetch costs 34 VGPRs here -- 128 -> 162, one resident wave
     // per SIMD less -- and measured 11 % slower)
     for (int kt = wave; kt < nkt; kt += ATTN_THREADS / 64) {
@@ -791,15 +812,15 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Qs, c, dt, grp, l15), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (ki < a.Nk) {
+        {
+            uint2 vw[DT], kw[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const long off = h * DH + 16 * dt + 4 * grp;
-                *reinterpret_cast<uint2*>(a.dv + ((long)b * a.Nk + ki) * a.lddv + off) =
-                    make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
-                *reinterpret_cast<uint2*>(a.dk + ((long)b * a.Nk + ki) * a.lddk + off) =
-                    make_uint2(pack_bf2(dk[dt][0] * a.scale, dk[dt][1] * a.scale), pack_bf2(dk[dt][2] * a.scale, dk[dt][3] * a.scale));
+                vw[dt] = make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
+                kw[dt] = make_uint2(pack_bf2(dk[dt][0] * a.scale, dk[dt][1] * a.scale), pack_bf2(dk[dt][2] * a.scale, dk[dt][3] * a.scale));
             }
+            store_rows_paired<DT>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * DH, vw, lane, grp, ki < a.Nk, dkv_al16);
+            store_rows_paired<DT>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * DH, kw, lane, grp, ki < a.Nk, dkv_al16);
         }
     }
 }

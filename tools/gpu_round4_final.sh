@@ -22,4 +22,4 @@ for wl in b16 vtp8 dmae12; do
 done
 if [ -z "$2" ]; then echo "=== PMC traffic"; bash tools/gpu_traffic.sh ${TAG} 1024; fi
 echo "=== loss kernels at the global-batch slab"; timeout 300 python tools/loss_bench.py 2>&1 | grep kernel | tee gpurun_out/${TAG}_loss_bench.jsonl
-echo "=== rolling vs burst epilogue, per shape"; GEMM_BENCH_VARIANTS=16388,4 GEMM_BENCH_NO_TN=1 timeout 600 tools/gemm_bench 1024 3 2>&1 | cut -c1-200 | tee gpurun_out/${TAG}_gemm_bench_rolling_vs_burst.jsonl | cut -c1-120
+echo "=== rolling vs burst epilogue, per shape"; GEMM_BENCH_VARIANTS=16388,4194308,4 GEMM_BENCH_NO_TN=1 timeout 600 tools/gemm_bench 1024 3 2>&1 | tee gpurun_out/${TAG}_gemm_bench_rolling_vs_burst.jsonl | cut -c1-120
