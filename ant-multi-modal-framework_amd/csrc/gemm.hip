@@ -57,6 +57,9 @@ struct GemmArgs {
     const float* rowv;
     const float* colv;
     float* part;   // mode 1: [J / 64][I] float2 (column block major);  mode 3: [I / 128][J]
+    // ---- tail round of the persistent NT kernel split along K (gemm_nt_k64r_kernel): tail_s K-slices per leftover tile, partial tiles -> tail_ws (0 = off)
+    int tail_s, tail_rmax;
+    float* tail_ws;
 };
 
 
@@ -1596,8 +1599,12 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
         i0 = (band * 4 + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
     };
+    // tail round split along K (g.tail_s > 0): the xcount % per_xcd tiles that would run as a last, nearly empty round are left out of the walk; behind it every workgroup
+    // takes one K-slice of one of them (fp32 partial tile -> g.tail_ws, summed + finished by gemm_tail_reduce_kernel)
+    const int tail_r = g.tail_s > 0 ? xcount % per_xcd : 0;
+    const int xcount_main = xcount - tail_r;
     int local = lx;
-    if (local >= xcount) return;
+    if (local >= xcount_main) return;
 #ifndef ANTMMF_EMULATE
     // workgroup 0 records shader-clock and 100-MHz-clock ticks across its run (antmmf_debug_gemm_clock: the effective clock of this launch; two scalar reads)
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1899,7 +1906,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #define K64R_TILE(ROLE) do { K64R_PHASE(ROLE, 0); K64R_PHASE(ROLE, 1); K64R_PHASE(ROLE, 2); K64R_PHASE(ROLE, 3); so ^= STAGE; } while (0)
 
     for (;;) {
-        const bool more = local + per_xcd < xcount;
+        const bool more = local + per_xcd < xcount_main;
         if (more) { tile_origin(local + per_xcd, ni0, nj0); tile_bases(ni0, nj0, pgn, qgn); }
         else { ni0 = i0; nj0 = j0; pgn = pgc; qgn = qgc; }   // the look-ahead of the last tile re-reads the tile's own operands (never consumed)
         // (t stays a run-time value: with literal K-tile numbers hipcc precomputes a 64-bit DMA address vector per (role, piece) and spills them)
@@ -1922,6 +1929,31 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     glds_wait_all();
     SCHED_FENCE();
     if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
+    if (tail_r > 0 && lx < tail_r * g.tail_s) {
+        // one K-slice of one leftover tile, unpipelined (1 - 4 K-tiles: the ring's prologue would cost as much as it saves): K-tile -> stage 0, drain, four phases
+        const int u = lx / g.tail_s, v = lx - u * g.tail_s, kslice = nk / g.tail_s;
+        tile_origin(xcount_main + u, i0, j0);
+        tile_bases(i0, j0, pgc, qgc);
+#pragma unroll
+        for (int a2 = 0; a2 < TI; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < TJ; ++b2) acc[a2][b2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        so = 0;
+        for (int kt = v * kslice; kt < (v + 1) * kslice; ++kt) {
+            wg_barrier_lds_only();   // every wave is done with the stage
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, kt, 0); dma_q(qgc, pq, kt, 0); }
+            glds_wait_all();
+            wg_barrier_lds_only();
+            K64R_READS(0); K64R_MFMA(0, 0); K64R_READS(1); K64R_MFMA(1, 0); K64R_READS(2); K64R_MFMA(2, 0); K64R_READS(3); K64R_MFMA(3, 0);
+        }
+        // fragment layout -> row-major fp32 tile: lane (l15, grp) holds row it 16 + l15, columns jt 16 + 4 ((grp & 1) 2 + (grp >> 1)) + [0, 4)
+        float* slot = g.tail_ws + ((long)(xcd * g.tail_rmax + u) * g.tail_s + v) * (BM * BN) + (long)(wi * 128 + l15) * BN + wj * 64 + 4 * (((grp & 1) << 1) | (grp >> 1));
+#pragma unroll
+        for (int it = 0; it < TI; ++it)
+#pragma unroll
+            for (int jt = 0; jt < TJ; ++jt) *reinterpret_cast<f32x4_t*>(slot + it * 16 * BN + jt * 16) = acc[it][jt];
+    }
 #ifndef ANTMMF_EMULATE
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_k64_clk[0] = __builtin_readcyclecounter() - clk0; g_k64_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #endif
@@ -1937,6 +1969,50 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #undef K64R_INIT
 #undef K64R_EPIQ
 #undef K64R_RESLOAD
+}
+
+// The tail round of gemm_nt_k64r_kernel, second half: sums the tail_s fp32 partial tiles of every leftover tile (in slice order: deterministic), adds bias / residual and
+// stores bf16.  Grid: (8 XCD chunks x tail_rmax leftover tiles) x 16 row blocks; block = 16 rows x 256 columns, a thread = 16 consecutive columns of one row.
+__global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const GemmArgs g, int ntiles, int per_xcd) {
+    const int slot = blockIdx.x >> 4, rb = blockIdx.x & 15;
+    const int xcd = slot / g.tail_rmax, u = slot - xcd * g.tail_rmax;
+    const int tiles_j = g.J / 256, tiles_i = g.I / 256;
+    const int qd = ntiles >> 3, rm = ntiles & 7;
+    const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
+    const int tail_r = xcount % per_xcd;
+    if (u >= tail_r) return;
+    const int wgid = xbase + (xcount - tail_r) + u;
+    const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
+    const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
+    const int i0 = (band * 4 + inb % rows_here) * 256, j0 = (inb / rows_here) * 256;
+    const int row = rb * 16 + (threadIdx.x >> 4), col = (threadIdx.x & 15) * 16;
+    const float* src = g.tail_ws + (long)slot * g.tail_s * 65536 + (long)row * 256 + col;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    for (int sl = 0; sl < g.tail_s; ++sl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)sl * 65536 + 4 * q);
+            v[4 * q] += x.x; v[4 * q + 1] += x.y; v[4 * q + 2] += x.z; v[4 * q + 3] += x.w;
+        }
+    }
+    const long r = i0 + row;
+    const int c = j0 + col;
+    if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += g.bias[c + e];
+    }
+    if (g.residual) {
+        float rr[16];
+        ld8<bf16_t>(g.residual + r * g.ldr + c, *reinterpret_cast<float(*)[8]>(rr));
+        ld8<bf16_t>(g.residual + r * g.ldr + c + 8, *reinterpret_cast<float(*)[8]>(rr + 8));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += rr[e];
+    }
+    bf16_t* dst = reinterpret_cast<bf16_t*>(g.C) + r * g.ldc + c;
+    st8<bf16_t>(dst, *reinterpret_cast<float(*)[8]>(v));
+    st8<bf16_t>(dst + 8, *reinterpret_cast<float(*)[8]>(v + 8));
 }
 
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
@@ -2284,6 +2360,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
     g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
+    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;
     act &= 0xff;
     // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
     // about what lands in aux); gate-holds-act' needs a gate
@@ -2374,7 +2451,29 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                 else if ((g_gemm_variant & 262144) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 8>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if (g_gemm_variant & 32768) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                else {                                                                                                            \
+                    /* tail round split along K (see gemm_tail_reduce_kernel): when the last round of the tile walk would run on <= a quarter of the workgroups */ \
+                    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;                                                           \
+                    if (E < 4 && workspace && !(g_gemm_variant & 33554432) && !(gridp & 7)) {                                     \
+                        const int per_xcd = (int)(gridp >> 3);                                                                    \
+                        const long qd = tiles256 >> 3, rm = tiles256 & 7;                                                         \
+                        const int r0 = (int)(qd % per_xcd), r1 = rm ? (int)((qd + 1) % per_xcd) : r0, rmax = r0 > r1 ? r0 : r1;   \
+                        /* measured (profiles/r4_gemm_tail_split_ab.txt): pays only when the leftover round is nearly empty AND a K-slice is long enough to amortise the    \
+                           partial tile's store, the unpipelined slice and the reduce launch -- >= 16 slices of >= 4 K-tiles (the J = 1024, R = 4096 shapes: + 1.4 ... 2.1 %);   \
+                           with 4 slices (J = 4096) or 1 - 3 K-tiles per slice (R <= 3072) it costs 1 - 3 %.  Variant bit 26 lifts the restriction (tests), bit 25 disables */   \
+                        const bool any_tail = (g_gemm_variant & 67108864) != 0;                                                   \
+                        if (rmax > 0 && rmax * (any_tail ? 4 : 16) <= per_xcd && qd >= 2L * per_xcd) {                            \
+                            int ts = per_xcd / rmax;                                                                              \
+                            const int nk64 = R >> 6;                                                                              \
+                            while (ts > 1 && nk64 % ts) --ts;                                                                     \
+                            if (ts >= (any_tail ? 4 : 16) && nk64 / ts >= (any_tail ? 1 : 4) && workspace_bytes >= 8L * rmax * ts * 65536 * 4) {    \
+                                g.tail_s = ts; g.tail_rmax = rmax; g.tail_ws = workspace;                                         \
+                            }                                                                                                     \
+                        }                                                                                                         \
+                    }                                                                                                             \
+                    hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                    if (g.tail_s) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3(8u * g.tail_rmax * 16u), dim3(256), 0, stream, g, (int)tiles256, (int)(gridp >> 3)); \
+                }                                                                                                                 \
             }                                                                                                                     \
             /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
             else if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);                                                \
@@ -2533,6 +2632,7 @@ static void gemm_ffn_args(GemmArgs& g, const void* P, const void* Q, void* C, in
     g.I = I; g.J = J; g.R = R; g.act = ANTMMF_ACT_NONE; g.c_dtype = ANTMMF_BF16; g.accumulate = 0; g.ksteps_per_split = (R + 63) / 64; g.alpha = 1.0f;
     g.ws = nullptr; g.raster = 1; g.aux_grad = 0; g.gate_grad = 0; g.debug_nostore = 0;
     g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
+    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;
 }
 static bool ffn_shape_ok(int I, int J, int R, long ldp, long ldq, long ldc) {
     return I > 0 && J > 0 && R > 0 && !(J & 7) && !(R & 7) && !(ldp & 7) && !(ldq & 7) && !(ldc & 7);
@@ -2763,6 +2863,13 @@ extern "C" int antmmf_ffn_prepare_w2(const float* W2, const float* gamma, const 
     return antmmf_check_launch();
 }
 
+extern "C" int antmmf_gemm_bf16_ws(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
+                                   int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
+                                   const void* residual, long ldr, void* aux, long ldaux, const void* gate, long ldgate,
+                                   int accumulate, int split_k, float* workspace, long workspace_bytes, hipStream_t stream) {
+    return gemm_impl(P, Q, C, I, J, R, ldp, ldq, ldc, p_rmajor, q_rmajor, c_dtype, alpha, bias, act, residual, ldr, aux, ldaux, gate, ldgate,
+                     accumulate, split_k, workspace, workspace_bytes, stream);
+}
 extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                                 int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                                 const void* residual, long ldr, void* aux, long ldaux, const void* gate, long ldgate,

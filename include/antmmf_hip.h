@@ -153,6 +153,13 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
                      int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                      const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
                      int accumulate, int split_k, antmmf_stream_t stream);
+/* The same GEMM with a caller-owned DEVICE scratch buffer (fp32, >= 64 MiB to be used at all; the contents are undefined afterwards).  With it the persistent NT kernel splits
+ * the tiles of a last, nearly empty round of its tile walk along K over all workgroups (fp32 partial tiles -> workspace, summed in slice order by a second launch:
+ * deterministic); without it (NULL / too small) the call is antmmf_gemm_bf16. */
+int antmmf_gemm_bf16_ws(const void* P, const void* Q, void* C, int I, int J, int R, int64_t ldp, int64_t ldq,
+                        int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
+                        const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
+                        int accumulate, int split_k, float* workspace, int64_t workspace_bytes, antmmf_stream_t stream);
 
 /* ---- wgrad: dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in] (fp32 accumulate; both operands token-major bf16).
  * Large 256-aligned problems run a 4-stage LDS-DMA ring with hardware transpose reads, split over the token range;

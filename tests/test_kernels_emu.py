@@ -188,6 +188,30 @@ def test_gemm_k64_rolling_epilogue():
     assert "okk64r" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_gemm_k64_tail_round_split():
+    """The tail round of the persistent NT kernel split along K (gemm_nt_k64r_kernel + gemm_tail_reduce_kernel): 72 tiles on a 32-workgroup grid = two full rounds of the
+    tile walk + ONE leftover tile per XCD chunk, whose four K-tiles go to the chunk's four workgroups (fp32 partial tiles in the caller's scratch, summed in slice order,
+    bias + residual applied by the reduce launch; variant bit 26 lifts the product's "16 slices of >= 4 K-tiles" rule for this small case).  Against the fp32 product on every tile, leftover tiles included; and the split must really have happened: with the
+    split disabled (variant bit 25) a few results differ in the last bf16 bit (order of the fp32 sum), only inside the eight leftover tiles."""
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
+            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '32'; os.environ['ANTMMF_GEMM_VARIANT'] = str(4 | (1 << 26));"
+            "import kernel_cases as kc; from antmmf.hip import ops, _lib; ops._GEMM_WS_MIN_ROWS = 0;"
+            "g = torch.Generator().manual_seed(11); I, J, R = 4608, 1024, 256;"
+            "X = torch.randn(I, R, generator=g).bfloat16(); W = (torch.randn(J, R, generator=g) * 0.06).bfloat16();"
+            "b = torch.randn(J, generator=g); r = (torch.randn(I, J, generator=g) * 3).bfloat16(); ref = X.float() @ W.float().t() + b + r.float();"
+            "y1 = ops.gemm(X, W, bias=b, residual=r); kc.check('k64r.tail', y1, ref, 2e-2, 1e-2);"
+            "lib = _lib.load(); lib.antmmf_debug_set_gemm_variant(4 | (1 << 25)); y0 = ops.gemm(X, W, bias=b, residual=r); kc.check('k64r.notail', y0, ref, 2e-2, 1e-2);"
+            "d = (y0.float() - y1.float()).abs(); nz = d.nonzero();"
+            "assert 0 < nz.shape[0] < 20000 and float(d.max()) <= 0.26, (nz.shape[0], float(d.max()));"
+            "tiles = set((int(i) // 256, int(j) // 256) for i, j in nz.tolist()); assert len(tiles) <= 8, sorted(tiles);"
+            "print('oktail', nz.shape[0], sorted(tiles))"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
+    assert "oktail" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, quick=not os.environ.get("ANTMMF_SLOW_TESTS"))
 

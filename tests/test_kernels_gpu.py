@@ -226,6 +226,37 @@ def test_attention_fwd32_opt_in(variant):
     assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_gemm_k64_tail_round_split(ops):
+    """The tail round of the persistent NT kernel split along K at the size where the product uses it (263168 x 1024 x 4096: 4112 tiles on 256 workgroups = 16 rounds + 2 leftover
+    tiles per XCD chunk, 16 K-slices of 4 K-tiles each): sampled rows against an fp32 product (rows of leftover tiles included), and against the same call with the split
+    disabled -- different in the last bf16 bit on part of the 16 leftover tiles, identical everywhere else."""
+    from antmmf.hip import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    I, J, R = 257 * 1024, 1024, 4096
+    X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
+    W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
+    b = torch.randn(J, generator=g, device=DEV)
+    r = torch.randn(I, J, generator=g, device=DEV).bfloat16()
+    try:
+        lib.antmmf_debug_set_gemm_variant(4)
+        y1 = ops.gemm(X, W, bias=b, residual=r)
+        lib.antmmf_debug_set_gemm_variant(4 | (1 << 25))
+        y0 = ops.gemm(X, W, bias=b, residual=r)
+    finally:
+        lib.antmmf_debug_set_gemm_variant(4)
+    d = (y0.float() - y1.float()).abs()
+    tiles = torch.unique((d.nonzero() // 256), dim=0)
+    assert 0 < tiles.shape[0] <= 16, tiles.shape            # the split really ran, and only on the leftover tiles
+    rows = torch.unique(torch.cat([tiles[:, 0] * 256 + 7, tiles[:, 0] * 256 + 250, torch.tensor([0, 70000, I - 1], device=DEV)]))
+    ref = X[rows].float() @ W.float().t() + b + r[rows].float()
+    for y in (y1, y0):
+        err = (y[rows].float() - ref).abs()
+        ulp = torch.maximum(ref.abs(), y[rows].float().abs()) * 2.0 ** -8
+        assert bool((err <= ulp * 1.001 + 2e-5).all()), float((err / (ulp + 1e-9)).max())
+
+
 def test_moco_and_ema(ops):
     kc.case_moco(ops, DEV)
     kc.case_moco(ops, DEV, R=5, Np=1, K=64)

@@ -15,6 +15,8 @@
 #include <vector>
 typedef int (*gemm_fn)(const void*, const void*, void*, int, int, int, long, long, long, int, int, int, float, const float*, int, const void*, long,
                        void*, long, const void*, long, int, int, hipStream_t);
+typedef int (*gemm_ws_fn)(const void*, const void*, void*, int, int, int, long, long, long, int, int, int, float, const float*, int, const void*, long,
+                          void*, long, const void*, long, int, int, float*, long, hipStream_t);
 typedef int (*setv_fn)(int);
 typedef int (*wgrad_fn)(const void*, const void*, float*, long, int, int, long, long, long, int, float*, long, hipStream_t);
 __global__ void maxdiff_f32(const float* a, const float* b, long n, unsigned* out, unsigned* outmag) {
@@ -59,6 +61,9 @@ int main(int argc, char** argv) {
     void* h = dlopen(libpath, RTLD_NOW);
     if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
     gemm_fn gemm = (gemm_fn)dlsym(h, "antmmf_gemm_bf16");
+    gemm_ws_fn gemm_ws = (gemm_ws_fn)dlsym(h, "antmmf_gemm_bf16_ws");   // with a 64-MiB scratch: the tail round of the persistent kernel is split along K (variant bit 25 disables)
+    float* tail_ws = nullptr;
+    if (gemm_ws && !getenv("GEMM_BENCH_NO_WS")) { if (hipMalloc(&tail_ws, 64u << 20) != hipSuccess) tail_ws = nullptr; }
     setv_fn setv = (setv_fn)dlsym(h, "antmmf_debug_set_gemm_variant");
     if (!gemm || !setv) { printf("missing symbols\n"); return 1; }
     typedef int (*clk_fn)(unsigned long long*);
@@ -90,6 +95,7 @@ int main(int argc, char** argv) {
         static const bool res_ld0 = getenv("GEMM_BENCH_RES_LD0") != nullptr;
         auto run = [&](int v, uint16_t* out) {
             setv(v);
+            if (tail_ws) return gemm_ws(A, W, out, (int)tokens, s.J, s.R, s.R + pad, s.R + pad, s.J, 0, 0, 1, 1.0f, s.bias ? bias : nullptr, 0, s.res ? Rz : nullptr, res_ld0 ? 0 : s.J, nullptr, 0, nullptr, 0, 0, 1, tail_ws, 64L << 20, 0);
             return gemm(A, W, out, (int)tokens, s.J, s.R, s.R + pad, s.R + pad, s.J, 0, 0, 1, 1.0f, s.bias ? bias : nullptr, 0, s.res ? Rz : nullptr, res_ld0 ? 0 : s.J, nullptr, 0, nullptr, 0, 0, 1, 0);
         };
         std::vector<std::vector<double>> ms(variants.size());
