@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     SCHED_FENCE();
     if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
     if (tail_r > 0 && lx < tail_r * g.tail_s) {
-        // one K-slice of one leftover tile, unpipelined (1 - 4 K-tiles: the ring's prologue would cost as much as it saves): K-tile -> stage 0, drain, four phases
+        // one K-slice of one leftover tile on the two stages as a plain double buffer (a slice is a few K-tiles: the ring's look-ahead logic would not pay)
         const int u = lx / g.tail_s, v = lx - u * g.tail_s, kslice = nk / g.tail_s;
         tile_origin(xcount_main + u, i0, j0);
         tile_bases(i0, j0, pgc, qgc);
@@ -1939,20 +1939,27 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #pragma unroll
             for (int b2 = 0; b2 < TJ; ++b2) acc[a2][b2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         so = 0;
-        for (int kt = v * kslice; kt < (v + 1) * kslice; ++kt) {
-            wg_barrier_lds_only();   // every wave is done with the stage
+        const int k0 = v * kslice, k1 = k0 + kslice;
+        wg_barrier_lds_only();   // every wave is out of the walk's last stage reads
 #pragma unroll
-            for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, kt, 0); dma_q(qgc, pq, kt, 0); }
-            glds_wait_all();
+        for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, k0, 0); dma_q(qgc, pq, k0, 0); }
+        for (int kt = k0; kt < k1; ++kt) {
+            if (kt + 1 < k1) {
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, kt + 1, so ^ STAGE); dma_q(qgc, pq, kt + 1, so ^ STAGE); }
+                glds_wait_le<8>();   // this K-tile's eight pieces have landed; the next one's stay in flight
+            } else glds_wait_all();
             wg_barrier_lds_only();
             K64R_READS(0); K64R_MFMA(0, 0); K64R_READS(1); K64R_MFMA(1, 0); K64R_READS(2); K64R_MFMA(2, 0); K64R_READS(3); K64R_MFMA(3, 0);
+            wg_barrier_lds_only();   // the stage may be overwritten by the K-tile after next
+            so ^= STAGE;
         }
-        // fragment layout -> row-major fp32 tile: lane (l15, grp) holds row it 16 + l15, columns jt 16 + 4 ((grp & 1) 2 + (grp >> 1)) + [0, 4)
-        float* slot = g.tail_ws + ((long)(xcd * g.tail_rmax + u) * g.tail_s + v) * (BM * BN) + (long)(wi * 128 + l15) * BN + wj * 64 + 4 * (((grp & 1) << 1) | (grp >> 1));
+        // partial tile in FRAGMENT order ([wave][it][jt][lane] x 4 floats: every store instruction writes 1 KB of consecutive bytes); gemm_tail_reduce_kernel maps it back
+        float* slot = g.tail_ws + ((long)(xcd * g.tail_rmax + u) * g.tail_s + v) * (BM * BN) + (long)(wave * 32 * 64 + lane) * 4;
 #pragma unroll
         for (int it = 0; it < TI; ++it)
 #pragma unroll
-            for (int jt = 0; jt < TJ; ++jt) *reinterpret_cast<f32x4_t*>(slot + it * 16 * BN + jt * 16) = acc[it][jt];
+            for (int jt = 0; jt < TJ; ++jt) *reinterpret_cast<f32x4_t*>(slot + (it * 4 + jt) * 256) = acc[it][jt];
     }
 #ifndef ANTMMF_EMULATE
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_k64_clk[0] = __builtin_readcyclecounter() - clk0; g_k64_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
@@ -1985,34 +1992,27 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const GemmArgs g,
     const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
     const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
     const int i0 = (band * 4 + inb % rows_here) * 256, j0 = (inb / rows_here) * 256;
-    const int row = rb * 16 + (threadIdx.x >> 4), col = (threadIdx.x & 15) * 16;
-    const float* src = g.tail_ws + (long)slot * g.tail_s * 65536 + (long)row * 256 + col;
-    float v[16];
+    const float* src = g.tail_ws + (long)slot * g.tail_s * 65536;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = 0.f;
-    for (int sl = 0; sl < g.tail_s; ++sl) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 x = *reinterpret_cast<const float4*>(src + (long)sl * 65536 + 4 * q);
-            v[4 * q] += x.x; v[4 * q + 1] += x.y; v[4 * q + 2] += x.z; v[4 * q + 3] += x.w;
+    for (int q = 0; q < 4; ++q) {
+        // element = one accumulator vector of the GEMM kernel's fragment order: [wave][it][jt][lane], 4 consecutive columns of one row
+        const int idx = rb * 1024 + q * 256 + threadIdx.x;
+        const int lane = idx & 63, frag = idx >> 6, jt = frag & 3, it = (frag >> 2) & 7, wave = frag >> 5;
+        const int l15 = lane & 15, grp = lane >> 4;
+        const long r = i0 + (wave >> 2) * 128 + it * 16 + l15;
+        const int c = j0 + (wave & 3) * 64 + jt * 16 + 4 * (((grp & 1) << 1) | (grp >> 1));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < g.tail_s; ++sl) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)sl * 65536 + (long)idx * 4);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
+        if (g.bias) { const float4 b4 = *reinterpret_cast<const float4*>(g.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (g.residual) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(g.residual + r * g.ldr + c);
+            v.x += bf_lo(rr.x); v.y += bf_hi(rr.x); v.z += bf_lo(rr.y); v.w += bf_hi(rr.y);
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + r * g.ldc + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
     }
-    const long r = i0 + row;
-    const int c = j0 + col;
-    if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += g.bias[c + e];
-    }
-    if (g.residual) {
-        float rr[16];
-        ld8<bf16_t>(g.residual + r * g.ldr + c, *reinterpret_cast<float(*)[8]>(rr));
-        ld8<bf16_t>(g.residual + r * g.ldr + c + 8, *reinterpret_cast<float(*)[8]>(rr + 8));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += rr[e];
-    }
-    bf16_t* dst = reinterpret_cast<bf16_t*>(g.C) + r * g.ldc + c;
-    st8<bf16_t>(dst, *reinterpret_cast<float(*)[8]>(v));
-    st8<bf16_t>(dst + 8, *reinterpret_cast<float(*)[8]>(v + 8));
 }
 
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
@@ -2459,7 +2459,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                         const long qd = tiles256 >> 3, rm = tiles256 & 7;                                                         \
                         const int r0 = (int)(qd % per_xcd), r1 = rm ? (int)((qd + 1) % per_xcd) : r0, rmax = r0 > r1 ? r0 : r1;   \
                         /* measured (profiles/r4_gemm_tail_split_ab.txt): pays only when the leftover round is nearly empty AND a K-slice is long enough to amortise the    \
-                           partial tile's store, the unpipelined slice and the reduce launch -- >= 16 slices of >= 4 K-tiles (the J = 1024, R = 4096 shapes: + 1.4 ... 2.1 %);   \
+                           partial tile's store, the short slice loop and the reduce launch -- >= 16 slices of >= 4 K-tiles (the J = 1024, R = 4096 shapes: + 0 ... 2 %);        \
                            with 4 slices (J = 4096) or 1 - 3 K-tiles per slice (R <= 3072) it costs 1 - 3 %.  Variant bit 26 lifts the restriction (tests), bit 25 disables */   \
                         const bool any_tail = (g_gemm_variant & 67108864) != 0;                                                   \
                         if (rmax > 0 && rmax * (any_tail ? 4 : 16) <= per_xcd && qd >= 2L * per_xcd) {                            \
