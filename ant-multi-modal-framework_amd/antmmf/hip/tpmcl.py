@@ -73,6 +73,8 @@ class _PairDots(torch.autograd.Function):
 
 def pair_dots(x, y):
     """x [C, D], y [C, V, D] -> [C, V]: x[c] . y[c, v]."""
+    if y.shape[-2] > TOKEN_WEIGHT_MAX_T:   # its backward (pair_wsum / pair_outer) holds the V weights of a pair in one workgroup: same shape guard as token_weights
+        return torch.einsum("cd,cvd->cv", x.float(), y.float())
     return _PairDots.apply(x, y)
 
 
@@ -94,6 +96,8 @@ class _PairWsum(torch.autograd.Function):
 
 def pair_wsum(w, y):
     """w [C, V], y [C, V, D] -> [C, D]: sum_v w[c, v] y[c, v]."""
+    if y.shape[-2] > TOKEN_WEIGHT_MAX_T:
+        return torch.einsum("cv,cvd->cd", w.float(), y.float())
     return _PairWsum.apply(w, y)
 
 

@@ -285,6 +285,35 @@ def test_softmax_ce(ops):
     kc.case_softmax_ce(ops, DEV)
 
 
+def test_tpmcl_shape_guards(ops):
+    """Beyond the row budget of the fused TPM-CL kernels (token sets > 128, selector rows > 64: e.g. frames x patches video tokens -- configurations the shipped ymls do not use)
+    the wrappers take the same arithmetic as device tensor ops instead of failing: values and gradients against plain torch."""
+    from antmmf.hip import tpmcl
+
+    g = torch.Generator().manual_seed(21)
+    feat = torch.randn(3, 150, 24, generator=g, requires_grad=True)
+    w = torch.randn(1, 24, generator=g, requires_grad=True)
+    b = torch.randn(1, generator=g, requires_grad=True)
+    mask = (torch.rand(3, 150, generator=g) > 0.2).float(); mask[:, 0] = 1
+    p = tpmcl.token_weights(feat, w, b, mask)
+    ref = torch.softmax((feat @ w.t()).squeeze(-1).add(b).masked_fill(mask < 0.5, float("-inf")), -1)
+    torch.testing.assert_close(p, ref, rtol=1e-5, atol=1e-6)
+    p.square().sum().backward()
+    assert feat.grad is not None and w.grad is not None and b.grad is not None
+    x = torch.randn(4, 16, generator=g, requires_grad=True)
+    y = torch.randn(4, 140, 16, generator=g, requires_grad=True)
+    ww = torch.randn(4, 140, generator=g)
+    torch.testing.assert_close(tpmcl.pair_dots(x, y), torch.einsum("cd,cvd->cv", x, y), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(tpmcl.pair_wsum(ww, y), torch.einsum("cv,cvd->cd", ww, y), rtol=1e-5, atol=1e-5)
+    tpmcl.pair_dots(x, y).sum().backward()
+    assert x.grad is not None and y.grad is not None
+    wt = torch.softmax(torch.randn(5, 90, generator=g), -1)
+    keep = tpmcl.tis_keep(wt, 0.3)
+    order = torch.argsort(wt, dim=-1, descending=True)
+    drop = torch.zeros_like(wt).scatter_(-1, order, (torch.cumsum(torch.gather(wt, -1, order), -1) < 0.3).float())
+    assert torch.equal(keep, 1.0 - drop) and 0 < float(drop.sum()) < drop.numel()
+
+
 def test_tpmcl_ops_and_linear_f32(ops):
     """csrc/tpmcl.hip + antmmf.hip.tpmcl on the lane emulator, the split GEMM of linear_f32 on the emulated MFMA GEMM."""
     kc.case_tpmcl_ops(DEV, C=9, V=5, T=7, D=40)
