@@ -1509,11 +1509,12 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 // workgroups reach their epilogues together, none of a CU's eight waves issues MFMAs while its 128-KB tile is converted / stored (6-12 % of
 // the R = 1024 shapes) or while the residual tile is fetched (out-projection: 19 %).  Here no epilogue phase exists:
 //   * phase ph of a K-tile multiplies the wave's rows [32 ph, +32), so after phase q of the LAST K-tile of an output tile the accumulators of
-//     row quarter q are final: quarter q is converted (lane swap -> 8 consecutive columns per lane) and stored inside the LOAD interval of
+//     row quarter q are final: quarter q is converted (lane swap -> 8 consecutive columns per lane, then two exchanges of the register-pair index with lane bits 4
+//     and 0 so that a 16-lane pass of a store writes 32 contiguous bytes of 8 rows instead of 16 bytes of 16 rows: K64R_EPIQ) and stored inside the LOAD interval of
 //     phase q + 1, next to the partner wave's MFMA block; quarter 3 goes out in phase 0 of the NEXT tile's first K-tile;
 //   * bias and residual are what the accumulators START from instead of what is added to the result: as soon as quarter q has been stored its
-//     32 accumulator registers are dead, and the residual vectors of the NEXT tile's quarter q (four 16-B loads per lane, coalesced 64-B row
-//     segments; inline asm, so hipcc neither waits for them nor drains the DMA ring) are requested into that hole.  Three phases (> 1 us) later,
+//     32 accumulator registers are dead, and the residual vectors of the NEXT tile's quarter q (four 16-B loads per lane in the store layout, exchanged
+//     back before use; inline asm, so hipcc neither waits for them nor drains the DMA ring) are requested into that hole.  Three phases (> 1 us) later,
 //     in phase q of the next tile's first K-tile, they are unpacked to fp32, taken back to the fragment layout (the lane swap is its own
 //     inverse), the bias fragment (DMAed into a 256-B LDS strip per wave during the previous tile) is added and the MFMAs accumulate on top:
 //     out = (bias + residual) + sum_r P Q in fp32 -- the same real number as "product first", rounded to bf16 once.  Without a residual the
@@ -1523,6 +1524,8 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 //   * the prologue loads K-tile 0 and the Q half of K-tile 1 (what the steady-state refill schedule does not bring itself), so the first
 //     K-tile issues the same operations as every other; the last tile's look-ahead refills wrap to its own first K-tiles (harmless re-reads,
 //     drained before the kernel ends) instead of the two special wait ladders of the kernel above.
+//   * tail round (g.tail_s > 0): the xcount % per_xcd tiles that would form a last, nearly empty round of the XCD chunk's walk are split along K over the chunk's
+//     workgroups behind the walk (fp32 partial tiles in fragment order -> g.tail_ws, finished by gemm_tail_reduce_kernel).
 // Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual; 5 = bias + activation with TWO outputs (the
 // activation -> C, its derivative or the pre-activation -> aux: the forward of a feed-forward whose activation output is kept for backward; g.act at run time);
 // 21 = the same plus per-row (sum z, sum z^2) of the rounded activation over the wave's 64 columns -> g.part (fc1 of the sub-LN fold, GemmArgs::ffn_mode 1).
