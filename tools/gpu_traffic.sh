@@ -8,7 +8,7 @@ P=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_traffic
 mkdir -p $P
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --batch $BATCH --steps 1 --warmup 1 --no-cpu-baseline > $P.$c.log 2>&1; echo "$c rc=$?"
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --batch $BATCH --steps 1 --warmup 1 --no-cpu-baseline > $P.$c.log 2>&1; echo "$c rc=$?"
 done
 cd $GRAFT_REPO_ROOT
 python - "$TAG" "$BATCH" <<'PY'
@@ -21,7 +21,7 @@ for c in tot:
             k = r["Kernel_Name"]
             if "gemm_" not in k or r["Counter_Name"] != c:
                 continue
-            tot[c] += float(r["Counter_Value"]); n[c] += 1
+            tot[c] += float(r["Counter_Value"]); n[c] += "tail_reduce" not in k   # (the reduce launch of a split tail round belongs to its GEMM call: bytes yes, launch no)
             d = per.setdefault(k.split("(")[0][-44:], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
             d[c] += float(r["Counter_Value"]); d["launches"] += c == "FETCH_SIZE"
 # units: KB; gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (guide); WRITE_SIZE matched the algorithmic bytes of the
