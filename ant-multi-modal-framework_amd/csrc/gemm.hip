@@ -2408,6 +2408,30 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         if (!oncep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64p_kernel<E_, F_>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); oncep = true; } \
         hipLaunchKernelGGL((gemm_nt_k64p_kernel<E_, F_>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);              \
     } while (0)
+// Timing-only ablations of gemm_nt_k64r_kernel (they store wrong data by construction: profiles/r4_gemm_store_cost_ablations.txt, r4_gemm_store_shapes.txt) exist only in a
+// library built with -DANTMMF_GEMM_ABLATIONS (`make ABLATIONS=1`); the product library cannot be talked into them through ANTMMF_GEMM_VARIANT.
+#ifdef ANTMMF_GEMM_ABLATIONS
+#define K64R_ABL_ATTR1(EE, K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<EE, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840)
+#define K64R_ABL_ATTRS(E) do { K64R_ABL_ATTR1((E < 4 ? E : 0), 1); K64R_ABL_ATTR1(0, 8); K64R_ABL_ATTR1(0, 24); K64R_ABL_ATTR1(0, 40); K64R_ABL_ATTR1(0, 56); K64R_ABL_ATTR1(0, 64); \
+                               K64R_ABL_ATTR1(0, 256); K64R_ABL_ATTR1(0, 512); } while (0)
+#define K64R_ABL_GO(EE, K) do { hipLaunchKernelGGL((gemm_nt_k64r_kernel<EE, K>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); } while (0)
+#define K64R_ABL_TRY(E, done)                                                                                                     \
+    do {                                                                                                                          \
+        done = true;                                                                                                              \
+        if ((g_gemm_variant & 8388608) && E == 0) K64R_ABL_GO(0, 256);                                                            \
+        else if ((g_gemm_variant & 16777216) && E == 0) K64R_ABL_GO(0, 512);                                                      \
+        else if ((g_gemm_variant & 2097152) && E == 0) K64R_ABL_GO(0, 64);                                                        \
+        else if ((g_gemm_variant & 1572864) == 1572864 && E == 0 && R == 1024) K64R_ABL_GO(0, 56);                                \
+        else if ((g_gemm_variant & 1048576) && E == 0 && R == 1024) K64R_ABL_GO(0, 40);                                           \
+        else if ((g_gemm_variant & 524288) && E == 0 && R == 1024) K64R_ABL_GO(0, 24);                                            \
+        else if ((g_gemm_variant & 262144) && E == 0 && R == 1024) K64R_ABL_GO(0, 8);                                             \
+        else if (g_gemm_variant & 32768) K64R_ABL_GO((E < 4 ? E : 0), 1);                                                         \
+        else done = false;                                                                                                        \
+    } while (0)
+#else
+#define K64R_ABL_ATTRS(E) do {} while (0)
+#define K64R_ABL_TRY(E, done) do {} while (0)
+#endif
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
@@ -2427,32 +2451,20 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             /* the rolling-epilogue kernel (bias / residual start the accumulators, stores inside the K loop; plain write-back stores).  Same-process A/B    \
                against the burst epilogue (profiles/r4_gemm_rolling_epilogue_ab.txt, r4_gemm_store_shapes.txt): + 1 ... + 5 % on every shape of the step   \
                since its stores and residual loads move 32 contiguous bytes per row and pass.  Variant bit 14 disables it, bit 22 selects the first layout  \
-               (16 rows x 16 B per pass); bits 15 / 17 / 18 - 24: timing-only ablations (no stores, non-temporal stores, store shapes and placements) */    \
+               (16 rows x 16 B per pass); bit 17 non-temporal stores; the timing-only ablations (bits 15, 18 - 24) need -DANTMMF_GEMM_ABLATIONS    */    \
             if (E < 4 && !(g_gemm_variant & 16384) && R >= 192) {                                                                 \
                 static bool oncer = false;                                                                                        \
                 if (!oncer) {                                                                                                     \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 56>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<0, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    K64R_ABL_ATTRS(E);                                                                                            \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
                     oncer = true;                                                                                                 \
                 }                                                                                                                 \
-                if ((g_gemm_variant & 8388608) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 256>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 16777216) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 512>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                bool abl_done = false;                                                                                            \
+                K64R_ABL_TRY(E, abl_done);                                                                                        \
+                if (abl_done) {}                                                                                                  \
                 else if (g_gemm_variant & 4194304) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 2097152) && E == 0) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 64>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 1572864) == 1572864 && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 56>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 1048576) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 40>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 524288) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 24>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if ((g_gemm_variant & 262144) && E == 0 && R == 1024) hipLaunchKernelGGL((gemm_nt_k64r_kernel<0, 8>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if (g_gemm_variant & 32768) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 1>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
                 else {                                                                                                            \
                     /* tail round split along K (see gemm_tail_reduce_kernel): when the last round of the tile walk would run on <= a quarter of the workgroups */ \

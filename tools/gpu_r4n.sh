@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the timing-only variants used here exist only in a library built with `make -C ant-multi-modal-framework_amd/csrc ABLATIONS=1` (rebuild the product library afterwards)
 # round 4: store ablations of the rolling-epilogue GEMM, timing only (wrong values by construction), R = 1024 plain shapes:
 #   270340   one 16 x 32 block stored per K-tile per wave instead of the whole tile at its end (stores spread evenly over the K loop)
 #   532484   the same, but all DMA pieces issued by waves 4 - 7 (waves 0 - 3 store and never wait on vmcnt)

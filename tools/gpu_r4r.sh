@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the timing-only variants used here exist only in a library built with `make -C ant-multi-modal-framework_amd/csrc ABLATIONS=1` (rebuild the product library afterwards)
 # round 4: does the SHAPE of a store instruction matter?  2105348 = rolling epilogue whose stores write 8 rows x 128 B (full cache lines) instead of 16 rows x 64 B (timing only: data misplaced)
 TAG=${1:-r4r}
 mkdir -p gpurun_out; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the timing-only variants used here exist only in a library built with `make -C ant-multi-modal-framework_amd/csrc ABLATIONS=1` (rebuild the product library afterwards)
 # round 4: store-shape ablations (timing only, data misplaced, NO exchange code): per 16-lane pass 16 rows x 16 B (4202500 = the old layout), 8 rows x 32 B (8396804),
 # 4 rows x 64 B (16785412), 2 rows x 128 B (2105348); 8196 = the real thing (five exchanges, 2 rows x 128 B); 40964 = no stores
 TAG=${1:-r4t}
