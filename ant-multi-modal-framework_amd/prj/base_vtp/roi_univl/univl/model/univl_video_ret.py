@@ -17,7 +17,7 @@ from torch import nn
 
 from antmmf.hip import contrastive
 from antmmf.hip import functional as HF
-from antmmf.utils.distributed_utils import all_gather, gather_tensor, get_rank
+from antmmf.utils.distributed_utils import all_gather, gather_tensor, get_rank, get_world_size
 from .moco_utils import MocoUtils
 from .univl_video_base import UnivlVideoBase
 
@@ -154,19 +154,38 @@ class UnivlForVideoTextRetrieval(nn.Module):
             return self._cross_similarity(cap_embed, visual_embed, cap_mask, visual_mask, num_clips)
         return self._score_pairs(*self.module._align_text_to_video_clips(cap_embed, cap_mask, 1), visual_embed, visual_mask).view(-1, 1)
 
-    def forward_stage2(self, vis_input, cap_input, output_dict=None, cal_cross=True):
+    def scheduled_mining_draw(self, device):
+        """The CN-VID schedule's coin (prj/cnvid_vtp/roi_univl/univl/model/univl_video_ret.py:410-420): every rank draws an integer in [0, 100), the MEAN over
+        the ranks / 100 is compared with the trainer's `incre_num` -- so all ranks take the same branch (the two branches issue different collectives).
+        One all-reduce of one float instead of the reference's padded list gather; the draw comes from torch's generator of `device` with the
+        reference's own call, so a seeded single-process run takes the reference's decisions (tests/golden/e2e_cnvid_gate.pt)."""
+        draw = torch.randint(low=0, high=100, size=[1], device=device, dtype=torch.float32)
+        world = get_world_size()
+        if world > 1:
+            torch.distributed.all_reduce(draw)
+        return float(draw) / world / 100.0
+
+    def forward_stage2(self, vis_input, cap_input, output_dict=None, cal_cross=True, incre_num=None):
+        """incre_num None: prj/base_vtp's head -- mine on every training step when `hard_example_mining` is set (univl_video_ret.py:389-401).  A number: the
+        CN-VID head's scheduled gate (prj/cnvid_vtp/.../univl_video_ret.py:398-428) -- mine only when the rank-agreed draw falls below it; the row re-weighting
+        applies on mined and plain steps alike, as there (:438-459)."""
         output_dict = dict(losses={}) if output_dict is None else output_dict
         cap_embed, cap_mask, batch_size = cap_input[0], cap_input[1], cap_input[3]
         visual_embed, visual_mask, num_clips = vis_input[0], vis_input[1], vis_input[3]
-        mining = self.training and self.config.get("hard_example_mining", False)
-        if mining:
+        configured = self.training and self.config.get("hard_example_mining", False)
+        mining = configured
+        if configured:
             l1_simi_clone = output_dict["l1_simi"].clone().detach()
+            if incre_num is not None:
+                mining = self.scheduled_mining_draw(l1_simi_clone.device) < float(incre_num)
+        self._last_mined = bool(mining)
+        if mining:
             l2_simi = self._cross_similarity_hard_mining(vis_input, cap_input, l1_simi_clone)
         else:
             l2_simi = self.get_l2_simi_matrix(cap_embed, cap_mask, visual_embed, visual_mask, num_clips, cal_cross=cal_cross)
         if cal_cross and l2_simi.size(0) == l2_simi.size(1):
             weight = None
-            if mining and self.config.re_weight_method == "median":
+            if configured and self.config.re_weight_method == "median":
                 beg = sum(all_gather(batch_size)[:get_rank()])
                 l1_diag = torch.diagonal(l1_simi_clone[beg:beg + batch_size, beg:beg + batch_size])
                 l1_mean, l1_min = l1_diag.mean(), l1_diag.min()   # ("median" in the reference's config is a mean, :425)
@@ -191,12 +210,12 @@ class UnivlForVideoTextRetrieval(nn.Module):
         output_dict["l3_simi"] = self.reduce_clips(l3_simi, "l2")
         return output_dict
 
-    def forward_stage(self, cap_input, vis_input, cal_cross=True):
+    def forward_stage(self, cap_input, vis_input, cal_cross=True, incre_num=None):
         output_dict = None
         if "stage1" in self.config.training_stage:
             output_dict = self.forward_stage1(vis_input, cap_input, output_dict, cal_cross=cal_cross)
         if "stage2" in self.config.training_stage:
-            output_dict = self.forward_stage2(vis_input, cap_input, output_dict, cal_cross=cal_cross)
+            output_dict = self.forward_stage2(vis_input, cap_input, output_dict, cal_cross=cal_cross, incre_num=incre_num)
         if "stage3" in self.config.training_stage:
             output_dict = self.forward_stage3(vis_input, cap_input, output_dict, cal_cross=cal_cross)
         return output_dict
@@ -207,7 +226,12 @@ class UnivlForVideoTextRetrieval(nn.Module):
             cap_input, vis_input = tuple(sample_list["text_stage1_output"]), tuple(sample_list["visual_stage1_output"])
         else:
             cap_input, vis_input, _, _ = self.module.get_l2_input(img_input, caption_input)
-        return self.forward_stage(cap_input + (caption_input,), vis_input + (img_input,), True)
+        # CN-VID schedule: configs that carry `change_iter` make the trainer write `incre_num` into the batch (antmmf/trainers/base_trainer.py, reference
+        # :552-571); the reference hands it to forward_stage from its pre-training head (prj/cnvid_vtp/.../univl_video_pretrain.py:182-188, default 0.0)
+        incre_num = None
+        if self.config.get("change_iter", None) is not None:
+            incre_num = float(sample_list["incre_num"]) if sample_list is not None and "incre_num" in sample_list else 0.0
+        return self.forward_stage(cap_input + (caption_input,), vis_input + (img_input,), True, incre_num=incre_num)
 
     def get_optimizer_parameters(self, config):
         """Four groups: {pretrained towers, new modules} x {decay, no decay} (reference :482-542)."""

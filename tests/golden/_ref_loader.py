@@ -94,6 +94,8 @@ def load_vtp(project="base_vtp"):
     P = f"{REF}/prj/{project}/roi_univl"
     for n, p in [("roi_univl", P), ("roi_univl.univl", P + "/univl"), ("roi_univl.univl.model", P + "/univl/model")]:
         _pkg(n, p)
+    if project == "cnvid_vtp":   # ships no CLIP-style encoders (its configs pair the model with Video-Swin): the tiny test towers come from base_vtp's files
+        sys.modules["roi_univl.univl.model"].__path__.append(f"{REF}/prj/base_vtp/roi_univl/univl/model")
     src = open(P + "/univl/model/univl_base.py").read()
     ub = types.ModuleType("roi_univl.univl.model.univl_base")
     exec("import torch\n" + src[src.index("def split_encoder_output"):src.index("class UniVlBase")], ub.__dict__)

@@ -21,6 +21,7 @@ Fixtures and the reference symbols that produced them:
   e2e_clip_arch.pt     UnivlForVideoTextRetrieval stage1  univl_video_ret.py:357-387,457-480 (tiny ViT + tiny BERT)
   e2e_clip_stage2.pt   same model, training_stage stage1+stage2 (cross encoder; plain and hard-mining+median reweight); the
                        reference instance's nn.Dropout(0.1) in front of similarity_dense is set to p = 0   univl_video_ret.py:33-144,389-443
+  e2e_cnvid_gate.pt    cnvid_vtp UnivlForVideoTextRetrieval.forward_stage(incre_num): mined / plain decision per (seed, incre_num)   prj/cnvid_vtp/.../univl_video_ret.py:398-428
   e2e_dmae_stage3.pt   dmae_vtp UnivlForVideoTextRetrieval, stage1+stage3 (seqTransf + WTI + NegNCE / CrossEn)   prj/dmae_vtp/.../univl_video_ret.py:457-476
   e2e_clip_moco.pt     same model, with_moco: true (K=64, M=0.5): 2 steps   univl_video_ret.py:262-312, moco_utils.py:13-107
   e2e_m2.pt            VLMo.infer_image / infer_text      prj/M2_Encoder/vlmo/modules/vlmo_module.py:323-405 (tiny dims)
@@ -501,6 +502,45 @@ def gen_e2e_clip_stage2():
     save("e2e_clip_stage2.pt", d)
 
 
+def gen_cnvid_gate():
+    """The scheduled hard-mining gate of the CN-VID project (prj/cnvid_vtp/roi_univl/univl/model/univl_video_ret.py:398-428): the reference's own
+    forward_stage(..., incre_num) run for a grid of (seed, incre_num); recorded: which similarity routine each call took (mined / plain), the draw
+    it made, and the level-2 loss of the plain branch (must equal e2e_clip_stage2.pt's plain loss: same towers, same batch)."""
+    vtp = L.load_vtp("cnvid_vtp")
+    bsz, n_clips = 4, 2
+    batch = tiny_clip_batch(bsz, n_clips, tag="s2")
+    cfg = dict(TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True, hard_example_mining=True, re_sample_method="top_k", re_weight_method="median",
+               change_iter=5000, change_rate=0.15)
+    model = vtp["ret"].UnivlForVideoTextRetrieval(L.AttrDict(cfg))
+    W.fill_module_(model)
+    model.train()
+    model.dropout.p = 0.0
+    calls = []
+    mined, plain = model._cross_similarity_hard_mining, model.get_simi_logits
+    model._cross_similarity_hard_mining = lambda *a, **k: (calls.append(1), mined(*a, **k))[1]
+    model.get_simi_logits = lambda vis, cap, level, cal: (calls.append(0) if level == "l2" else None, plain(vis, cap, level, cal))[1]
+    seeds, incs = list(range(16)), [0.0, 0.15, 0.45, 0.75, 1.0]
+    dec = torch.zeros(len(seeds), len(incs), dtype=torch.long)
+    draws = torch.zeros(len(seeds))
+    loss2_plain = None
+    with torch.no_grad():
+        cap_input, vis_input, _, _ = model.module.get_l2_input(batch["image"], batch["caption"])
+        cap_input, vis_input = cap_input + (batch["caption"],), vis_input + (batch["image"],)
+        for si, s in enumerate(seeds):
+            torch.manual_seed(s)
+            draws[si] = torch.randint(low=0, high=100, size=[1], dtype=torch.float32)[0]
+            for ii, inc in enumerate(incs):
+                del calls[:]
+                torch.manual_seed(s)
+                out = model.forward_stage(cap_input, vis_input, True, incre_num=inc)
+                assert len(calls) == 1, calls
+                dec[si, ii] = calls[0]
+                if calls[0] == 0 and loss2_plain is None:
+                    loss2_plain = out["losses"]["level2_similarity_loss"].clone()
+    assert bool((dec[:, 0] == 0).all()) and 0 < int(dec.sum()) < dec.numel()
+    save("e2e_cnvid_gate.pt", {"seeds": torch.tensor(seeds), "incre_num": torch.tensor(incs, dtype=torch.float64), "mined": dec, "draw": draws, "plain.loss2": loss2_plain})
+
+
 DMAE_E2E = dict(l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="meanP", l3_partial_type=-1, l3_max_frames=4,
                 l3_max_words=12, l3_sim_header_hidden_layer=2)
 
@@ -680,8 +720,8 @@ def gen_gather():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_eval_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "vilbert_biattention", "e2e_clip_stage2", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
+    which = sys.argv[1:] or ["clip_block", "bert_layer", "m2_layer", "dmae_seqtransf", "dmae_wti", "dmae_tpmcl", "metric_recall", "m2_eval_recall", "m2_ckpt_convert", "losses", "e2e_clip", "temporal_head", "vilbert_biattention", "e2e_clip_stage2", "cnvid_gate", "e2e_dmae_stage3", "e2e_clip_moco", "e2e_m2", "gather"]
     fns = dict(m2_eval_recall=gen_m2_eval_recall, vilbert_biattention=gen_vilbert_biattention, temporal_head=gen_temporal_head, dmae_tpmcl=gen_dmae_tpmcl, m2_ckpt_convert=gen_m2_ckpt_convert, metric_recall=gen_metric_recall, dmae_seqtransf=gen_dmae_seqtransf, dmae_wti=gen_dmae_wti, clip_block=gen_clip_block, bert_layer=gen_bert_layer, m2_layer=gen_m2_layer, losses=gen_losses,
-               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
+               e2e_clip=gen_e2e_clip, e2e_clip_moco=gen_e2e_clip_moco, e2e_clip_stage2=gen_e2e_clip_stage2, cnvid_gate=gen_cnvid_gate, e2e_dmae_stage3=gen_e2e_dmae_stage3, e2e_m2=gen_e2e_m2, gather=gen_gather)
     for w in which:
         fns[w]()

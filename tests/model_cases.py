@@ -227,8 +227,10 @@ def case_bert_layer_dropout(dev):
     return dict(checked=n)
 
 
-def case_temporal_head(dev, golden=None):
-    """UnivlForVideo.get_temporal_output ([cls] + clip features through a 3-layer BERT, inputs_embeds path) vs the CPU oracle's
+def case_temporal_head(dev, golden=None, hidden=128, heads=2, bsz=3, n_clips=8):
+    """(hidden / heads / bsz / n_clips other than the defaults: the same check at config 3's REAL width -- d = 768, 12 heads, 8 clips -- against the oracle only;
+    the reference fixture is at the default dims.)
+    UnivlForVideo.get_temporal_output ([cls] + clip features through a 3-layer BERT, inputs_embeds path) vs the CPU oracle's
     BERT restatement on the same weights, forward and input / parameter gradients -- and, with `golden`, vs the run of the reference's own
     BERT modules over the same method body (tests/golden/ops_temporal_head.pt: output, input gradients, every parameter's full gradient)."""
     import roi_univl  # noqa: F401
@@ -236,25 +238,26 @@ def case_temporal_head(dev, golden=None):
     from oracle import towers as otowers
     from roi_univl.univl.model.univl_video_pretrain import UnivlForVideo
 
-    tenc = dict(type="RobertBertEncoder", params=dict(pretrained=False, vocab_size=40, hidden_size=128, intermediate_size=512,
-                                                      num_hidden_layers=3, num_attention_heads=2, max_position_embeddings=40,
-                                                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=128, is_proj=False))
-    model = UnivlForVideo(Configuration(dict(TINY_CLIP_CFG, with_temporal_encoder=True, temporal_encoder=tenc)))
+    tenc = dict(type="RobertBertEncoder", params=dict(pretrained=False, vocab_size=40, hidden_size=hidden, intermediate_size=4 * hidden,
+                                                      num_hidden_layers=3, num_attention_heads=heads, max_position_embeddings=40,
+                                                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, out_dim=hidden, is_proj=False))
+    model = UnivlForVideo(Configuration(dict(TINY_CLIP_CFG, hidden_size=hidden, with_temporal_encoder=True, temporal_encoder=tenc)))
     W.fill_module_(model)
     model = model.to(dev).train()
-    clip = (W.data_tensor("temporal.clip", (3, 8, 128)) * 0.5)
-    w = W.data_tensor("temporal.w", (3, 9, 128))
+    tag = "temporal" if (hidden, bsz, n_clips) == (128, 3, 8) else f"temporal.{hidden}.{bsz}.{n_clips}"
+    clip = (W.data_tensor(tag + ".clip", (bsz, n_clips, hidden)) * 0.5)
+    w = W.data_tensor(tag + ".w", (bsz, n_clips + 1, hidden))
     x = clip.detach().clone().to(dev).requires_grad_(True)
     out = model.get_temporal_output(x)
     (out.float() * w.to(dev)).sum().backward()
     P = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in model.named_parameters() if n.startswith(("temporal_encoder.", "cls_token"))}
     xr = clip.detach().clone().requires_grad_(True)
-    emb_in = torch.cat([P["cls_token"].expand(3, -1, -1), xr], 1)
+    emb_in = torch.cat([P["cls_token"].expand(bsz, -1, -1), xr], 1)
     Pe = {k[len("temporal_encoder.embeddings."):]: v for k, v in P.items() if k.startswith("temporal_encoder.embeddings.")}
     Pe["word_embeddings.weight"] = None
     h = otowers.bert_embeddings(Pe, inputs_embeds=emb_in)
     ref = otowers.bert_encoder({k[len("temporal_encoder.encoder."):]: v for k, v in P.items() if k.startswith("temporal_encoder.encoder.")},
-                               h, torch.zeros(3, 9), 2)
+                               h, torch.zeros(bsz, n_clips + 1), heads)
     (ref * w).sum().backward()
     check("temporal.out", out, ref, 5e-2, 3e-2)
     check("temporal.dclip", x.grad, xr.grad, 1e-1, 5e-2)
@@ -271,6 +274,15 @@ def case_temporal_head(dev, golden=None):
             n += 1
     assert n > 30
     res = dict(checked=n)
+    if golden is None:   # oracle only: directions as well (cosine per parameter against the oracle's gradients)
+        rows = []
+        for k, v in P.items():
+            if v.grad is not None and named[k].grad is not None and float(v.grad.norm()) > 1e-4 * top:
+                a, b = named[k].grad.detach().float().flatten().cpu(), v.grad.flatten()
+                rows.append((float(torch.dot(a, b) / (a.norm() * b.norm())), k))
+        rows.sort()
+        assert rows[0][0] >= 0.995, rows[:4]
+        res["min_cos"] = rows[0]
     if golden is not None:
         g = golden("ops_temporal_head.pt")
         check("temporal.out.ref", out, g["out"], 5e-2, 3e-2)
@@ -390,6 +402,39 @@ def case_univl_stage2(dev, golden, mining=False):
     check("s2.mine.l2_simi", out["l2_simi"], ref["l2_simi"], 5e-2, 3e-2)
     assert abs(float(l2) - float(ref["loss"])) <= 5e-3 * abs(float(ref["loss"])), (float(l2), float(ref["loss"]))
     return dict(loss2=(float(l2), float(ref["loss"])))
+
+
+def case_univl_stage2_cnvid_gate(dev, golden):
+    """The whole product model under the CN-VID schedule (config carries change_iter / change_rate; the batch carries `incre_num` as the trainer writes it):
+    incre_num 0 -> the plain cross-encoder branch WITH the row re-weighting, level-2 loss against the reference's cnvid_vtp class on the same batch
+    (tests/golden/e2e_cnvid_gate.pt "plain.loss2"); incre_num 1 -> the mined branch (every draw / 100 < 1)."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from antmmf.structures.sample import SampleList
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    g, gate = golden("e2e_clip_stage2.pt"), golden("e2e_cnvid_gate.pt")
+    cfg = Configuration(dict(TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True, hard_example_mining=True, re_sample_method="top_k",
+                             re_weight_method="median", change_iter=5000, change_rate=0.15))
+    model = UnivlForVideoTextRetrieval(cfg)
+    W.fill_module_(model)
+    model = model.to(dev).train()
+    model.dropout.p = 0.0
+    img, ids, mask = g["s2.image_data"].to(dev), g["s2.input_ids"].to(dev), g["s2.input_mask"].to(dev)
+    bsz, n_clips = img.shape[0], 2
+    img_input = dict(image_data=img, image_pad_mask=torch.zeros(bsz, img.shape[1], 32, 32, dtype=torch.bool, device=dev),
+                     image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz)
+    cap_input = dict(caption_input_ids=ids, caption_input_mask=mask, caption_raw_input_ids=ids)
+    with torch.no_grad():
+        out = model(img_input, cap_input, sample_list=SampleList(incre_num=0.0))
+        assert model._last_mined is False
+        l2, ref = float(out["losses"]["level2_similarity_loss"]), float(gate["plain.loss2"])
+        assert abs(l2 - ref) <= 2e-3 * abs(ref), (l2, ref)   # the level-2 gate of case_univl_stage2
+        model(img_input, cap_input, sample_list=SampleList(incre_num=1.0))
+        assert model._last_mined is True
+        model(img_input, cap_input)   # no incre_num in the batch: the reference signature's default 0.0 -> never mined
+        assert model._last_mined is False
+    return dict(loss2=(l2, ref))
 
 
 def moco_queue(name, dim, K):

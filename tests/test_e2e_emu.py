@@ -95,6 +95,11 @@ def test_univl_stage2_hard_mining_vs_oracle(golden):
 
 
 @SLOW
+def test_univl_stage2_cnvid_scheduled_gate_vs_reference(golden):
+    print(mc.case_univl_stage2_cnvid_gate(torch.device("cpu"), golden))
+
+
+@SLOW
 @pytest.mark.parametrize("loss_type", ["negNCE", "cross_entropy"])
 def test_dmae_stage3_vs_reference(loss_type):
     import subprocess

@@ -59,6 +59,10 @@ def test_univl_stage2_hard_mining_vs_oracle(golden):
     print(mc.case_univl_stage2(DEV, golden, mining=True))
 
 
+def test_univl_stage2_cnvid_scheduled_gate_vs_reference(golden):
+    print(mc.case_univl_stage2_cnvid_gate(DEV, golden))
+
+
 @pytest.mark.parametrize("loss_type", ["negNCE", "cross_entropy"])
 def test_dmae_stage3_vs_reference(loss_type):
     import subprocess
@@ -175,6 +179,11 @@ def test_vilbert_biattention_vs_reference(golden, head_size):
 
 def test_temporal_head_vs_oracle_and_reference(golden):
     print(mc.case_temporal_head(DEV, golden))
+
+
+def test_temporal_head_real_width_vs_oracle():
+    """T11 at config 3's size: 64 videos x (1 + 8) tokens, d = 768, 12 heads, 3 BERT layers (univl_video_pretrain.py:76-90)"""
+    print(mc.case_temporal_head(DEV, None, hidden=768, heads=12, bsz=64, n_clips=8))
 
 
 def test_dmae_seqtransf_vs_reference(golden):

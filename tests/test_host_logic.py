@@ -432,6 +432,86 @@ def test_dmae_wti_two_ranks_match_reference(golden):
             torch.testing.assert_close(out[r][key], 2.0 * g[ref][sl], rtol=3e-2, atol=3e-2 * float(g[ref].abs().max()))
 
 
+def _tiny_stage2_model(**extra):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "base_vtp"))
+    import model_cases as mc
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    cfg = dict(mc.TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True, hard_example_mining=True, re_sample_method="top_k",
+               re_weight_method="median", **extra)
+    return UnivlForVideoTextRetrieval(Configuration(cfg)).train()
+
+
+def test_cnvid_scheduled_mining_gate_takes_the_reference_decisions(golden, monkeypatch):
+    """prj/cnvid_vtp/roi_univl/univl/model/univl_video_ret.py:398-428: with `incre_num` given, stage 2 mines hard negatives only when the (rank-agreed) draw / 100 falls
+    below it.  tests/golden/e2e_cnvid_gate.pt holds the decisions the REFERENCE class took for 16 seeds x 5 ratios (make_golden.py gen_cnvid_gate); the product draws with the
+    same generator call, so a seeded single-process run must take the same branch every time.  The two similarity routines are stubbed (their parity is
+    test_univl_stage2_*); the row re-weighting runs on both branches as in the reference."""
+    if not os.path.exists(os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")):
+        pytest.skip("emulated kernel library not built")
+    monkeypatch.setenv("ANTMMF_HIP_LIB", os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so"))
+    from antmmf.hip import _lib
+
+    _lib.reset_for_tests()
+    g = golden("e2e_cnvid_gate.pt")
+    model = _tiny_stage2_model(change_iter=5000, change_rate=0.15)
+    calls = []
+    B = 4
+    scores = torch.randn(B, B)
+    monkeypatch.setattr(model, "_cross_similarity_hard_mining", lambda *a, **k: (calls.append(1), scores.clone().requires_grad_(True))[1])
+    monkeypatch.setattr(model, "get_l2_simi_matrix", lambda *a, **k: (calls.append(0), scores.clone().requires_grad_(True))[1])
+    cap_input, vis_input = (None, None, None, B, None), (None, None, None, 2, None)
+    l1 = torch.randn(B, B)
+    try:
+        for si, seed in enumerate(g["seeds"].tolist()):
+            torch.manual_seed(seed)
+            assert abs(model.scheduled_mining_draw(torch.device("cpu")) * 100.0 - float(g["draw"][si])) < 1e-4
+            for ii, inc in enumerate(g["incre_num"].tolist()):
+                del calls[:]
+                torch.manual_seed(seed)
+                out = model.forward_stage2(vis_input, cap_input, {"losses": {}, "l1_simi": l1}, True, incre_num=inc)
+                assert calls == [int(g["mined"][si, ii])] and model._last_mined == bool(g["mined"][si, ii]), (seed, inc, calls)
+                assert torch.isfinite(out["losses"]["level2_similarity_loss"])
+        # no schedule (prj/base_vtp): every training step mines; evaluation never does
+        del calls[:]
+        model.forward_stage2(vis_input, cap_input, {"losses": {}, "l1_simi": l1}, True)
+        model.eval()
+        model.forward_stage2(vis_input, cap_input, {"losses": {}, "l1_simi": l1}, True, incre_num=1.0)
+        assert calls == [1, 0]
+    finally:
+        monkeypatch.undo()
+        _lib.reset_for_tests()
+
+
+def _gate_draw_case(rank, world):
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "ant-multi-modal-framework_amd", "prj", "base_vtp"))
+    import roi_univl  # noqa: F401
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    out = []
+    for step in range(6):
+        torch.manual_seed(1000 * rank + step)   # the ranks' generators are NOT in step: agreement has to come from the collective
+        mine = torch.randint(low=0, high=100, size=[1], dtype=torch.float32)
+        torch.manual_seed(1000 * rank + step)
+        out.append((float(mine), UnivlForVideoTextRetrieval.scheduled_mining_draw(None, torch.device("cpu"))))
+    return out
+
+
+def test_cnvid_gate_draw_is_rank_agreed_two_ranks():
+    """the gate's draw on 2 gloo ranks: both ranks obtain the MEAN of the two local draws / 100 (reference: gather_tensor + torch.mean, :417-420), hence the same branch"""
+    out = _spawn(_gate_draw_case, 29675)
+    for step in range(6):
+        want = (out[0][step][0] + out[1][step][0]) / 2 / 100.0
+        assert abs(out[0][step][1] - want) < 1e-6 and abs(out[1][step][1] - want) < 1e-6, (step, out[0][step], out[1][step])
+    assert any(out[0][s][0] != out[1][s][0] for s in range(6))
+
+
 def test_m2_checkpoint_converters_match_reference(golden):
     """convert_pl_ckpt / convert_deepspeed_ckpt (released-weight loading of the M2 encoder) against the reference's own functions
     (tests/golden/m2_ckpt_convert.pt): position-table growth by area interpolation, truncation, prefix stripping."""
