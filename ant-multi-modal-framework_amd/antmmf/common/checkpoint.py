@@ -149,6 +149,13 @@ class Checkpoint:
             from antmmf.hip.functional import bump_weight_version
 
             bump_weight_version()
+        # modules that cache HOST copies of a parameter / buffer (e.g. DMAE's TokenImportanceSelector threshold: one device read per load, not per step) drop them
+        # here: weights arrive through state_dict()[name].copy_(), which never runs a module's _load_from_state_dict
+        model = getattr(self.trainer, "model", None)
+        for m in (model.modules() if model is not None else ()):
+            hook = getattr(m, "on_weights_loaded", None)
+            if callable(hook):
+                hook()
 
     # ------------------------------------------------------------------ load
     def load_state_dict(self):

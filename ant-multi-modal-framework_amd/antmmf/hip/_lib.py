@@ -70,15 +70,22 @@ _SIGNATURES = {
     "antmmf_negnce_fwd": [P, P, I, I, I, F, F, P, P, P, P, P],
     "antmmf_negnce_bwd": [P, P, P, P, I, I, I, F, F, P, I, P],
     "antmmf_resize_bicubic_u8": [P, L, P, I, I, I, I, I, I, P, P, P, P, I, P],
+    "antmmf_frames_bilinear_norm": [P, I, I, I, I, L, L, L, L, P, I, I, L, L, L, P, P, I, P, P],
+    "antmmf_frames_bilinear_aa_norm": [P, I, I, I, I, L, L, L, L, P, P, I, I, L, L, L, P, P, I, P, P],
+}
+
+# exported by the LAB library only (libantmmf_hip_lab.so, include/antmmf_hip_lab.h; also by the test-side emulator): the sub-LN fold and the A/B switch.
+# Bound when present; the product library has none of them.
+_LAB_SIGNATURES = {
     "antmmf_ffn_prepare_w2": [P, P, P, P, P, P, P, I, I, P],
     "antmmf_ffn_fc1_fwd": [P, P, P, P, P, P, I, I, I, L, L, L, I, F, P, L, P],
     "antmmf_ffn_fc2_fwd": [P, P, P, P, P, P, P, I, I, I, L, L, L, L, P],
     "antmmf_ffn_bwd_rows": [P, P, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, P],
     "antmmf_ffn_fc2_dgrad": [P, P, P, P, P, P, P, I, I, I, L, L, L, L, P, L, P],
     "antmmf_ffn_wgrad_post": [P, P, P, P, P, P, P, P, P, I, I, P],
-    "antmmf_frames_bilinear_norm": [P, I, I, I, I, L, L, L, L, P, I, I, L, L, L, P, P, I, P, P],
-    "antmmf_frames_bilinear_aa_norm": [P, I, I, I, I, L, L, L, L, P, P, I, I, L, L, L, P, P, I, P, P],
+    "antmmf_debug_set_gemm_variant": [I],
 }
+LAB_LIB = os.path.join(os.path.dirname(DEFAULT_LIB), "libantmmf_hip_lab.so")
 
 
 class HipLibraryError(RuntimeError):
@@ -114,6 +121,14 @@ def load():
             raise HipLibraryError(f"{path} does not export {name}") from e
         fn.argtypes = args
         fn.restype = c_int
+    lab = 0
+    for name, args in _LAB_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = args
+            fn.restype = c_int
+            lab += 1
+    lib.antmmf_is_lab = lab == len(_LAB_SIGNATURES)
     be = lib.antmmf_backend()
     if be == 0 and not (os.environ.get("PYTEST_CURRENT_TEST") or os.environ.get("ANTMMF_ALLOW_EMULATOR")):
         # the CPU lane emulator is test infrastructure: the product path never runs on it (ANTMMF_HIP_LIB could point it there)
@@ -128,6 +143,11 @@ def backend():
     """1 = gfx950 device library, 0 = CPU lane emulator."""
     load()
     return _backend
+
+
+def is_lab():
+    """True when the loaded library is the measurement build (A/B switches, sub-LN fold): never on the product path."""
+    return bool(load().antmmf_is_lab)
 
 
 def reset_for_tests():

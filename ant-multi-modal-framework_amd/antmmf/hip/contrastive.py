@@ -147,12 +147,15 @@ class _Rows:
             self.Bp, self.row0 = B, self.rank * B
             self.Bg = self.world * B      # python int
             return
-        if B > max_rows:
-            raise ValueError(f"{B} rows on rank {self.rank} exceed max_rows = {max_rows}")
         self.Bp, self.row0 = int(max_rows), self.rank * int(max_rows)
         mine = torch.full((1,), B, dtype=torch.int64, device=device)
         counts = torch.empty(self.world, dtype=torch.int64, device=device)
         dist.all_gather_into_tensor(counts, mine, group=group)
+        # a rank with MORE rows than the static maximum cannot be padded.  It takes part in the count exchange first, so that EVERY rank sees the violation and fails
+        # with it (device-side assert: no host sync on the good path) instead of the others blocking in the next collective behind a rank that raised alone
+        torch._assert_async((counts <= int(max_rows)).all(), f"a rank holds more rows than max_rows = {max_rows} (contrastive.set_max_rows_per_rank)")
+        if B > max_rows:
+            raise ValueError(f"{B} rows on rank {self.rank} exceed max_rows = {max_rows}")
         self.counts = counts
         self.Bg = counts.sum().to(torch.float32)                        # device scalar: the true global batch
         ar = torch.arange(self.Bp, device=device)

@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 BF = torch.bfloat16
 
@@ -359,8 +359,9 @@ def set_keep_ffn_norm(flag):
 # (z = gelu(u) and gelu'(u) instead of u and LN(z)).  OFF by default: measured on MI355X at the bench size (tools/ffn_fold_bench.py,
 # profiles/r3_ffn_fold_bench_image.jsonl) the removed passes (1.05 + 1.43 ms per image layer) come back one for one as exposed epilogue time of the
 # persistent GEMM kernel (fc1 + 0.92, dgrad + 0.96, fc2 + 0.11, row pass 0.46): its HBM-bound epilogues do not overlap the MFMA loop, so moving bytes
-# from a streaming kernel into them buys nothing (step 1314 vs 1313 pairs/s).  ANTMMF_FFN_FOLD=1 / set_ffn_fold(True) turns it on (parity-tested).
-FFN_FOLD = os.environ.get("ANTMMF_FFN_FOLD", "0") == "1"
+# from a streaming kernel into them buys nothing (step 1314 vs 1313 pairs/s).  Since round 5 its entry points live in the LAB library only
+# (libantmmf_hip_lab.so, include/antmmf_hip_lab.h): set_ffn_fold(True) works when that library is the loaded one (tests, tools/ffn_fold_bench.py) and raises otherwise.
+FFN_FOLD = False
 
 
 # Collector for the one thing the reference does with attention MAPS on this path (univl_video_base.py:131-143: words_importance = sum over layers of the
@@ -370,6 +371,8 @@ KEY_IMPORTANCE = None
 
 def set_ffn_fold(flag):
     global FFN_FOLD
+    if flag and not _lib.is_lab():
+        raise RuntimeError("the sub-LN fold is an experiment of the lab library (make -C csrc lab; ANTMMF_HIP_LIB=.../libantmmf_hip_lab.so): the product library does not export it")
     FFN_FOLD = bool(flag)
 
 

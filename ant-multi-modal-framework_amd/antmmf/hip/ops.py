@@ -326,9 +326,10 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
     # large NT shapes: a per-device 64-MiB scratch lets the persistent kernel split the tiles of a nearly empty last round along K (csrc/gemm.hip, gemm_tail_reduce_kernel)
     ws = None
     if not p_rmajor and not q_rmajor and I >= _GEMM_WS_MIN_ROWS and out.dtype == torch.bfloat16:
-        ws = _GEMM_WS.get(P.device)
+        key = (P.device, _stream())   # per (device, stream): two GEMMs on different streams must not share partial-tile scratch
+        ws = _GEMM_WS.get(key)
         if ws is None:
-            ws = _GEMM_WS[P.device] = torch.empty(_GEMM_WS_FLOATS, dtype=torch.float32, device=P.device)
+            ws = _GEMM_WS[key] = torch.empty(_GEMM_WS_FLOATS, dtype=torch.float32, device=P.device)
     _rc(_lib.load().antmmf_gemm_bf16_ws(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0),
                                         int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias),
                                         ACT_IDS[act] | (0x100 if aux_grad else 0) | (0x200 if gate_is_grad else 0),
@@ -356,7 +357,7 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     if X.shape[0] != tokens or tuple(dW.shape) != (n_out, k_in) or dW.stride(1) != 1:
         raise ValueError("gemm_wgrad_: shape mismatch")
     need = 32 * n_out * k_in
-    key = dW.device
+    key = (dW.device, _stream())      # per (device, stream), as for the NT scratch
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dW.device)

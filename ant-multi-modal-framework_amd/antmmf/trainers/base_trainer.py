@@ -114,11 +114,14 @@ class BaseTrainer:
         self.early_stopping = EarlyStopping(self.monitored_metric, self.patience, self.metric_minimize, self.should_early_stop)
         self.epoch_iterations = len(self.train_batches) if hasattr(self.train_batches, "__len__") else 0
         # ragged per-rank batches (the reference pads + trims on every gather, distributed_utils.py:131-160): with `pad_ragged_batches` the row-sharded
-        # losses pad every rank to the per-rank batch size of the configuration (reference: batch_size is the GLOBAL size, utils/general.py get_batch_size)
+        # losses pad every rank to the per-rank batch size of the configuration (reference: batch_size is the GLOBAL size, utils/general.py get_batch_size).
+        # The maximum is process-wide and also serves the evaluation loader, so it covers the LARGER of batch_size and test_batch_size (ceil: a global size that
+        # does not divide by the world leaves one more row on the first ranks); a rank that still exceeds it fails on every rank together (contrastive._Rows)
         if tp.get("pad_ragged_batches", False) and tp.get("batch_size", None):
             from antmmf.hip import contrastive
 
-            contrastive.set_max_rows_per_rank(max(1, int(tp.batch_size) // get_world_size()))
+            biggest = max(int(tp.batch_size), int(tp.get("test_batch_size", 0) or 0))
+            contrastive.set_max_rows_per_rank(max(1, -(-biggest // get_world_size())))
         self.setup_lr_scheduler()
         self.load_extras()
 

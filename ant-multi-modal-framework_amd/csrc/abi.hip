@@ -7,4 +7,4 @@ extern "C" int antmmf_backend(void) {
     return 1;  // gfx950 device code
 #endif
 }
-extern "C" int antmmf_abi_version(void) { return 1; }
+extern "C" int antmmf_abi_version(void) { return 2; }   // 2: the sub-LN fold entry points moved to the lab library (include/antmmf_hip_lab.h)

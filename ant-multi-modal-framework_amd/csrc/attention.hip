@@ -844,7 +844,8 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     // 64-key softmax blocks.  Measured same-box against the 16 x 16 whole-row kernel at 1024 x 16 heads x 257 tokens (profiles/r4_attn_fwd32_ab.txt): 0.78 - 0.81 ms vs
     // 0.72 - 0.73 ms -- half the LDS instructions and bytes, fewer parked cycles (34 % vs 48 %), but more issue stalls behind the 16-pass MFMAs (35 % vs 24 %) and the same
     // VALU work per score (one 16-cycle v_exp_f32 per score is as long as all the MFMAs of a tile): not faster, so not the default.
-    static const char* av_env = getenv("ANTMMF_ATTN_VARIANT");
+#ifdef ANTMMF_LAB
+    static const char* av_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_VARIANT");
     const int av = av_env ? atoi(av_env) : 0;
     if constexpr (DH == 64) {
         if (!a.drop_thr && (nch == 7 || nch == 9) && (av & 4)) {   // (its padding mask covers the LAST 32-key tile only: the key count must fill the instantiated tile count)
@@ -858,6 +859,7 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
             return antmmf_check_launch();
         }
     }
+#endif
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
     return antmmf_check_launch();

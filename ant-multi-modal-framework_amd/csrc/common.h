@@ -10,6 +10,17 @@
 #endif
 #include <stdint.h>
 
+// ANTMMF_LAB: the measurement build (`make lab` -> libantmmf_hip_lab.so, and the CPU lane emulator of tests/emu).  Only there do the A/B switches exist -- environment
+// variables, antmmf_debug_set_gemm_variant, timing-only kernels, the experiment kernels that measured slower.  The PRODUCT library (plain `make`) reads no environment
+// variable and keeps no dispatch state: every call takes the one measured-best path for its shape.
+#if defined(ANTMMF_GEMM_ABLATIONS) || defined(ANTMMF_EMULATE)
+#define ANTMMF_LAB 1
+#include <cstdlib>
+#define ANTMMF_LAB_ENV(name) getenv(name)
+#else
+#define ANTMMF_LAB_ENV(name) ((const char*)nullptr)
+#endif
+
 #define ANTMMF_OK 0
 #define ANTMMF_EINVAL (-22)
 #define ANTMMF_ELAUNCH (-5)

@@ -47,7 +47,7 @@ struct GemmArgs {
     float* ws;   // split-K workspace [splits][I][J] fp32 (wgrad ring; NULL -> atomics)
     int raster;  // 0: dispatch order; 1: XCD-contiguous chunks + 4x8 patches (experiment knob)
     int aux_grad, gate_grad;  // ANTMMF_ACT_AUX_GRAD: aux receives act'(pre-activation) instead of the pre-activation; ANTMMF_ACT_GATE_GRAD: gate holds act' already
-    int debug_nostore;  // ablations (antmmf_debug_set_gemm_variant bit 11 / 12): the staged epilogue skips its global stores / stores without the nt hint
+    int debug_nostore;  // LAB build only (antmmf_debug_set_gemm_variant bit 11 / 12): the staged epilogue skips its global stores / stores without the nt hint; the product kernels do not read it
     // ---- sub-LN fold (antmmf_ffn_* at the end of this file): the M2 feed-forward's gelu -> LayerNorm(4d) pair lives in the epilogues of its GEMMs
     //   1  fc1:   z = act(acc + bias) -> C,  act'(acc + bias) -> aux,  per-row (sum z, sum z^2) of the ROUNDED z -> part   (k64p; other kernels: a row pass follows)
     //   2  fc2:   C = rstd_i acc - rstd_i mu_i colv_j + bias_j + residual_ij                 rowv = [I][2] (mu, rstd);  Q = W2 gamma,  colv_j = sum_k Q[j][k]
@@ -539,7 +539,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmArgs g) {
         SCHED_FENCE();
     }
     if (!late) wg_barrier_lds_only();  // balance group B's extra leading barrier
-    if (g.raster & 8) {  // experiment: no store tail
+#ifdef ANTMMF_LAB
+    if (g.raster & 8) {  // lab experiment: no store tail
         float sacc = 0.f;
 #pragma unroll
         for (int a2 = 0; a2 < TI; ++a2)
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmArgs g) {
         if (sacc == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = sacc;
         return;
     }
+#endif
     if (g.c_dtype == ANTMMF_BF16 && !(g.ldc & 7)) {
         wg_barrier_lds_only();  // every wave is done with the stage buffers (all DMA pieces were waited for above)
         gemm_epilogue_bf16_staged<TI, TJ, EPI>(g, acc, i0, j0, wi, wj, lane, smem + wave * (TI * 16 * TJ * 32));
@@ -752,12 +754,20 @@ __device__ __forceinline__ void epilogue_store_bf16_staged_raw(const GemmArgs& g
         for (int pass = 0; pass < NRD; ++pass) {
             const int row = pass * ROWS_PER_PASS + lane / SLOTS, ls = lane % SLOTS;
             const int gi = i0 + wi * (16 * TI) + ps * TIP * 16 + row, gj = j0 + wj * (16 * TJ) + ls * 8;
+#ifdef ANTMMF_LAB
             if (gi < g.I && g.debug_nostore != 1) {
+#else
+            if (gi < g.I) {
+#endif
                 bf16_t* dst = C + (long)gi * g.ldc + gj;
                 // non-temporal: the 0.5 GB output streams past an L2 that should keep the operand panels (same-box A/B of the step:
                 // 1203.5 / 1203.6 vs 1193.8 / 1195.4 pairs/s; -1..2 % cycles per tile)
 #ifndef ANTMMF_EMULATE
+#ifdef ANTMMF_LAB
                 if (gj + 8 <= g.J) { if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(dst) = val[pass]; else __builtin_nontemporal_store(val[pass], reinterpret_cast<u32x4_t*>(dst)); }
+#else
+                if (gj + 8 <= g.J) __builtin_nontemporal_store(val[pass], reinterpret_cast<u32x4_t*>(dst));
+#endif
 #else
                 if (gj + 8 <= g.J) *reinterpret_cast<u32x4_t*>(dst) = val[pass];
 #endif
@@ -1481,8 +1491,12 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                         for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rv[q][e]); v[2 * e + 1] += bf_hi(rv[q][e]); }
                     }
                     const u32x4_t ov = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                    if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(C + row * g.ldc + col) = ov;   // (store ablations: variant bits 11 / 12)
+#ifdef ANTMMF_LAB
+                    if (g.debug_nostore == 2) *reinterpret_cast<u32x4_t*>(C + row * g.ldc + col) = ov;   // (store ablations of the lab build: variant bits 11 / 12)
                     else if (g.debug_nostore != 1) K64_NT_STORE16(C + row * g.ldc + col, ov);
+#else
+                    K64_NT_STORE16(C + row * g.ldc + col, ov);
+#endif
                 }
             }
             }
@@ -2181,7 +2195,8 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
                 acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[jt], pb[it], acc[it][jt], 0, 0, 0);
         SCHED_FENCE();
     }
-    if (g.raster & 8) {  // experiment: no store tail
+#ifdef ANTMMF_LAB
+    if (g.raster & 8) {  // lab experiment: no store tail
         float sacc = 0.f;
 #pragma unroll
         for (int a2 = 0; a2 < TI; ++a2)
@@ -2190,6 +2205,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs g) {
         if (sacc == 123.456f) reinterpret_cast<float*>(g.C)[threadIdx.x] = sacc;
         return;
     }
+#endif
     if (g.ws) {
         wg_barrier_lds_only();  // stage buffers are free
         store_partial_f32_staged<TI, TJ>(g.ws + (long)split * g.I * g.J + (long)i0 * g.J + j0, g.J, acc, wi, wj, lane, smem + wave * 16384);
@@ -2329,11 +2345,20 @@ __global__ __launch_bounds__(512) void gemm_tn_k64_kernel(const GemmArgs g) {
     gemm_epilogue<TI, TJ>(g, acc, i0, j0, wi, wj, l15, grp, nk < nk_total);
 }
 
-// Experiment / test knob (tools/gemm_bench, tests), initialised from ANTMMF_GEMM_VARIANT: 0 = the BK = 32 ring kernels of round 1; bit 2 (default) routes
-// the large 256-aligned all-r-contiguous GEMMs to gemm_nt_k64p_kernel; further bits select its A/B forms (see the launch site).
+// LAB build only (`make lab`, tests/emu): the A/B knob of tools/gemm_bench and the kernel tests, initialised from ANTMMF_GEMM_VARIANT: 0 = the BK = 32 ring kernels of
+// round 1; bit 2 (default) routes the large 256-aligned all-r-contiguous GEMMs to the BK = 64 persistent kernels; further bits select A/B forms (see the launch site).
+// The PRODUCT library has neither the variable nor the setter: g_gemm_variant is the constant 4 and every branch on its other bits is compiled out.
+#ifdef ANTMMF_LAB
 static int g_gemm_variant = -1;
-static long g_k64_launches = 0;
 extern "C" int antmmf_debug_set_gemm_variant(int v) { g_gemm_variant = v; return ANTMMF_OK; }
+#define GEMM_VARIANT_INIT() do { if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; } } while (0)
+#define LAB_ONLY(...) __VA_ARGS__
+#else
+static constexpr int g_gemm_variant = 4;
+#define GEMM_VARIANT_INIT() do {} while (0)
+#define LAB_ONLY(...)
+#endif
+static long g_k64_launches = 0;   // launch counter read by the tests (which kernel family served a call); not dispatch state
 extern "C" long antmmf_debug_gemm_k64_launches() { return g_k64_launches; }
 
 // C ABI: see include/antmmf_hip.h for the contract.
@@ -2371,9 +2396,10 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     if (g.gate_grad && !gate) return ANTMMF_EINVAL;
     g.I = I; g.J = J; g.R = R; g.act = act; g.c_dtype = c_dtype; g.accumulate = accumulate; g.alpha = alpha; g.ws = nullptr;
     g.ksteps_per_split = (nk + split_k - 1) / split_k;
-    static const char* raster_env = getenv("ANTMMF_GEMM_RASTER");
+    static const char* raster_env = ANTMMF_LAB_ENV("ANTMMF_GEMM_RASTER");
     g.raster = raster_env ? atoi(raster_env) : 1;
-    g.debug_nostore = g_gemm_variant > 0 ? ((g_gemm_variant & 2048) ? 1 : (g_gemm_variant & 4096) ? 2 : 0) : 0;
+    g.debug_nostore = 0;
+    LAB_ONLY(g.debug_nostore = g_gemm_variant > 0 ? ((g_gemm_variant & 2048) ? 1 : (g_gemm_variant & 4096) ? 2 : 0) : 0;)
     const int splits = (nk + g.ksteps_per_split - 1) / g.ksteps_per_split;
     const long tiles = (long)((I + 127) / 128) * ((J + 127) / 128);
     if (tiles > 0x7fffffffL) return ANTMMF_EINVAL;
@@ -2389,16 +2415,16 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     }
     if (!p_rmajor && !q_rmajor && (R & 63) == 0 && splits == 1) {
         const long tiles256 = (long)((I + 255) / 256) * ((J + 255) / 256);
-        static const char* force = getenv("ANTMMF_GEMM_FORCE_TILE");  // tests only: "256" / "128" / "ring"
+        static const char* force = ANTMMF_LAB_ENV("ANTMMF_GEMM_FORCE_TILE");  // lab / emulator tests only: "256" / "128" / "ring" / "k"
         const bool big = force ? (force[0] == '2' || force[0] == 'r' || force[0] == 'p') : tiles256 >= 512;
-        static const char* persist_env = getenv("ANTMMF_GEMM_PERSIST");  // A/B knob: "0" = one workgroup per tile
+        static const char* persist_env = ANTMMF_LAB_ENV("ANTMMF_GEMM_PERSIST");  // A/B knob: "0" = one workgroup per tile
         const bool persist = force ? force[0] == 'p' : !(persist_env && persist_env[0] == '0');
-        static const char* pwgs_env = getenv("ANTMMF_GEMM_PERSIST_WGS");  // tests only: a small grid makes every workgroup walk several tiles
+        static const char* pwgs_env = ANTMMF_LAB_ENV("ANTMMF_GEMM_PERSIST_WGS");  // lab / emulator tests only: a small grid makes every workgroup walk several tiles
         const unsigned pwgs = pwgs_env ? (unsigned)atoi(pwgs_env) : 256u;
-        static const char* cont_env = getenv("ANTMMF_GEMM_CONT");  // A/B knob: "0" = next-tile prologue as a burst in front of the epilogue
+        static const char* cont_env = ANTMMF_LAB_ENV("ANTMMF_GEMM_CONT");  // A/B knob: "0" = next-tile prologue as a burst in front of the epilogue
         const bool cont = !(cont_env && cont_env[0] == '0');
         const int epi = (aux || gate || act != ANTMMF_ACT_NONE || alpha != 1.0f || c_dtype != ANTMMF_BF16) ? 4 : ((bias ? 1 : 0) | (residual ? 2 : 0));
-        if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; }
+        GEMM_VARIANT_INIT();
         const bool k64p = (g_gemm_variant & 4) && c_dtype == ANTMMF_BF16 && !(ldc & 7) && !(I & 255) && !(J & 255) && R >= 128 &&
                           (!residual || !(ldr & 7)) && (!aux || !(ldaux & 7)) && (!gate || !(ldgate & 7)) &&
                           (force ? force[0] == 'k' : tiles256 >= 512);
@@ -2432,14 +2458,21 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
 #define K64R_ABL_ATTRS(E) do {} while (0)
 #define K64R_ABL_TRY(E, done) do {} while (0)
 #endif
+// (k64p shapes the rolling kernel does not take: the generic epilogue, and R = 128.  The product library serves both with the run-time epilogue form <4>; the lab build
+// keeps the compile-time forms <0 .. 3> of the burst-epilogue kernel for its A/B runs)
+#ifdef ANTMMF_LAB
+#define K64P_FALLBACK(E) K64P_LAUNCH(E, PROD | K64F_PRIO)
+#else
+#define K64P_FALLBACK(E) K64P_LAUNCH(4, K64F_ONEBAR | K64F_PRIO)
+#endif
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
         if (!once) {                                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+            LAB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);) \
+            LAB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 4, 8, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);) \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
             once = true;                                                                                                          \
         }                                                                                                                         \
@@ -2456,16 +2489,16 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                 static bool oncer = false;                                                                                        \
                 if (!oncer) {                                                                                                     \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    LAB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);) \
                     K64R_ABL_ATTRS(E);                                                                                            \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); \
+                    LAB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);) \
                     oncer = true;                                                                                                 \
                 }                                                                                                                 \
                 bool abl_done = false;                                                                                            \
                 K64R_ABL_TRY(E, abl_done);                                                                                        \
                 if (abl_done) {}                                                                                                  \
-                else if (g_gemm_variant & 4194304) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
+                LAB_ONLY(else if (g_gemm_variant & 4194304) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);) \
+                LAB_ONLY(else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);) \
                 else {                                                                                                            \
                     /* tail round split along K (see gemm_tail_reduce_kernel): when the last round of the tile walk would run on <= a quarter of the workgroups */ \
                     g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;                                                           \
@@ -2491,17 +2524,17 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                 }                                                                                                                 \
             }                                                                                                                     \
             /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
-            else if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);                                                \
-            else if (g_gemm_variant & 128) K64P_LAUNCH(E, PROD);                                                                  \
-            else if (g_gemm_variant & 256) K64P_LAUNCH(E, PROD | K64F_PRIO | K64F_CLK);                                           \
-            else K64P_LAUNCH(E, PROD | K64F_PRIO);                                                                                \
+            LAB_ONLY(else if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);)                                      \
+            LAB_ONLY(else if (g_gemm_variant & 128) K64P_LAUNCH(E, PROD);)                                                        \
+            LAB_ONLY(else if (g_gemm_variant & 256) K64P_LAUNCH(E, PROD | K64F_PRIO | K64F_CLK);)                                 \
+            else K64P_FALLBACK(E);                                                                                                \
         }                                                                                                                         \
         else if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                  \
             if (cont) hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256); \
-            else hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);     \
+            LAB_ONLY(else hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), false>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256);) \
         }                                                                                                                         \
         else if (big && !(force && force[0] == '2')) hipLaunchKernelGGL((gemm_nt_ring_kernel<4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
-        else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g); \
+        LAB_ONLY(else if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 4, 8, 4, E>), dim3((unsigned)tiles256), dim3(512), 131072, stream, g);) \
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, 2, 4, 4, E>), grid, block, lds, stream, g);                                \
     } while (0)
         if (k64p && aux && bias && !gate && !residual && act != ANTMMF_ACT_NONE && alpha == 1.0f && R >= 192 && !(g_gemm_variant & 16384)) {
@@ -2529,6 +2562,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             default: LAUNCH_NT(4); break;
         }
 #undef LAUNCH_NT
+#undef K64P_FALLBACK
 #undef K64P_LAUNCH
     }
     else if (!p_rmajor && !q_rmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, stream, g);
@@ -2537,7 +2571,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
              !bias && act == ANTMMF_ACT_NONE && !residual && !aux && !gate && R >= 4096) {
         // wgrad ring: the host-side split_k hint is replaced by "enough workgroups to fill 256 CUs twice"
         const int tiles = (I / 256) * (J / 256), nk32 = R / 32;
-        static const char* wgs_env = getenv("ANTMMF_WGRAD_WGS");  // experiments only
+        static const char* wgs_env = ANTMMF_LAB_ENV("ANTMMF_WGRAD_WGS");  // experiments only
         const int want_wgs = wgs_env ? atoi(wgs_env) : 256;
         int sp = want_wgs / tiles;  // floor: one resident round of workgroups (36 tiles x 8 splits = 288 would need a second, 12 % full round)
         if (sp < 1) sp = 1;
@@ -2550,10 +2584,10 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
         static bool once = false;
         if (!once) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            LAB_ONLY((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);)
             once = true;
         }
-        if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; }
+        GEMM_VARIANT_INIT();
         // BK = 64 schedule (default; variant bit 10 = the BK = 32 ring for A/B): K-tiles of 64 tokens, every split needs >= 2 of them
         int k64_steps = 0, k64_zs = 0;
         if ((g_gemm_variant & 4) && !(g_gemm_variant & 1024) && (R & 63) == 0 && R >= 128) {
@@ -2579,8 +2613,8 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             }
             return antmmf_check_launch();
         }
-        if (g.raster & 16) hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
-        else hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
+        LAB_ONLY(if (g.raster & 16) hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g); else)
+        hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3((unsigned)(tiles * zs)), dim3(512), 131072, stream, g);
         if (use_ws) {
             const long nvec = (long)I * J / 4;
             const int rg = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
@@ -2592,6 +2626,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     return antmmf_check_launch();
 }
 
+#ifdef ANTMMF_LAB   // the sub-LN fold is a measured-neutral option: its entry points (include/antmmf_hip_lab.h) exist in the lab library only
 // =====================================================================================================================================
 // Sub-LN fold: the M2 feed-forward  y = fc2(LayerNorm_4d(gelu(fc1(x)))) + residual  (reference prj/M2_Encoder/vlmo/torchscale/component/
 // feedforward_network.py:117-128: fc1 -> activation_fn -> ffn_layernorm -> fc2) without the two 4d-wide LayerNorm passes.  With z = gelu(u),
@@ -2877,6 +2912,8 @@ extern "C" int antmmf_ffn_prepare_w2(const float* W2, const float* gamma, const 
     hipLaunchKernelGGL(ffn_prepare_w2_kernel, dim3(n_out), dim3(256), 0, stream, W2, gamma, beta, b2, (bf16_t*)W2g, c, b2f, n_ff);
     return antmmf_check_launch();
 }
+
+#endif  // ANTMMF_LAB (sub-LN fold)
 
 extern "C" int antmmf_gemm_bf16_ws(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                                    int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,

@@ -69,9 +69,13 @@ class UnivlVideoBase(nn.Module):
         if self.arch_type == "univl":
             # all-zero token types (reference :125): None spares BertEmbeddings its any() host sync.  In training the reference asks for the attention maps and
             # reduces them to `words_importance` (:131-143): here the tower hands back that reduction itself (modeling_bert.KeyImportance)
-            out = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=None, output_attentions=bool(self.training))
+            # -- ONLY when something will read it: `words_importance` costs one more score pass per BERT layer and its one reader on the reference side is the
+            # pre-training head's attentive masking (univl_video_pretrain.py:194), which is outside this build.  A head that wants it sets
+            # `model.module.want_words_importance = True` (or the config key `words_importance: true`); otherwise the entry stays None
+            want = bool(self.training) and bool(getattr(self, "want_words_importance", False) or self.config.get("words_importance", False))
+            out = text_encoder(input_ids=input_ids, attention_mask=input_mask, token_type_ids=None, output_attentions=want)
             sequence_output, pooled_output = out[0], out[1]
-            if self.training:
+            if want:
                 words_importance = out[2].value.detach()
         else:
             sequence_output, pooled_output = text_encoder(input_ids=input_ids, attention_mask=input_mask)

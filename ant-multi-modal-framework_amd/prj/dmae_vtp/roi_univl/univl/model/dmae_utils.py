@@ -205,9 +205,13 @@ class TokenImportanceSelector(nn.Module):
             self._thresh_f = float(self.thresh)      # read once per (re)load of the buffer: one host sync per model, not per step
         return tpmcl.tis_keep(attn_weight, self._thresh_f)
 
+    def on_weights_loaded(self):
+        """called by Checkpoint._after_weight_load (weights are copied in place there, no load_state_dict): a checkpoint may carry another threshold"""
+        self._thresh_f = None
+
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
-        self._thresh_f = None                        # a checkpoint may carry another threshold: re-read the buffer on the next call
+        self._thresh_f = None                        # plain nn.Module.load_state_dict users: same invalidation
 
     def forward(self, x, attn_weight):
         keep = self.keep_mask(attn_weight)

@@ -14,10 +14,13 @@
  *  - dtype tags: ANTMMF_F32 = 0, ANTMMF_BF16 = 1 (bf16 = upper 16 bits of an IEEE fp32, RNE);
  *  - every function enqueues on `stream` (a hipStream_t; pass torch's current stream) and returns
  *    0, or a negative errno-style code (-22 bad argument, -5 launch failure); nothing throws;
- *  - re-entrant; one process per GPU.  The entry points declared here keep no state between calls (beyond per-kernel launch attributes set once).
- *    The library also exports a few `antmmf_debug_*` symbols that are deliberately NOT declared here: process-global A/B switches
- *    (antmmf_debug_set_gemm_variant; the same knob as the ANTMMF_GEMM_VARIANT environment variable) and launch counters read by the tests and
- *    by tools/gemm_bench.cpp.  They are measurement infrastructure, not ABI: nothing on the product path calls them, and a binding must not.
+ *  - re-entrant; one process per GPU.  The entry points declared here keep no state between calls (beyond per-kernel launch attributes set once),
+ *    and libantmmf_hip.so reads NO environment variable and has no dispatch switch: every call takes the one measured-best kernel for its shape.
+ *    Two read-only probes are exported and deliberately not declared here (antmmf_debug_gemm_k64_launches: a launch counter the tests read;
+ *    antmmf_debug_gemm_clock: shader / wall clock ticks of the last persistent-GEMM launch, read by bench.py) -- measurement, not ABI.
+ *    The A/B switches (ANTMMF_GEMM_VARIANT, antmmf_debug_set_gemm_variant, forced tile sizes), the timing-only ablation kernels, the experiment kernels that
+ *    measured slower and the optional sub-LN fold live in a SEPARATE library, libantmmf_hip_lab.so (`make lab`; include/antmmf_hip_lab.h): tests and tools
+ *    load it explicitly, the product path never does.
  */
 #ifndef ANTMMF_HIP_H
 #define ANTMMF_HIP_H
@@ -295,36 +298,6 @@ int antmmf_ema_update(float* k, const float* q, void* k_shadow_bf16, int64_t n, 
 int antmmf_resize_bicubic_u8(const void* src, int64_t src_bytes, const int64_t* desc, int n_images, int max_h, int max_w,
                              int channels, int out_h, int out_w, const int32_t* coeffs, const int32_t* bounds, void* tmp, void* out,
                              int out_f32, antmmf_stream_t stream);
-
-/* ---- M2 feed-forward with the sub-LayerNorm folded into its GEMMs.  Reference prj/M2_Encoder/vlmo/torchscale/component/
- * feedforward_network.py:117-128: x -> fc1 -> gelu -> ffn_layernorm (over the 4d-wide row) -> fc2 (+ the residual of encoder.py:176-199).
- * With z = act(fc1(x)), (mu_i, rstd_i) the row statistics of z, W2g[j][k] = bf16(W2[j][k] gamma_k), c_j = sum_k W2g[j][k], b2f = b2 + W2 beta:
- *   y_ij = rstd_i (z W2g^T)_ij - rstd_i mu_i c_j + b2f_j + res_ij        -- exactly fc2(LayerNorm(z)) + res; no 4d-wide LayerNorm pass
- * and in backward the LayerNorm's two row means are dot products over d-wide tensors (antmmf_ffn_bwd_rows), so the 4d-wide tensors are touched by
- * GEMM epilogues only.  All matrices bf16 row-major with row strides in elements (multiples of 8); statistics / partial sums fp32.
- * workspace: device scratch for the per-tile partial sums of the large-shape kernel (fc1: n_ff / 64 * tokens * 8 bytes; dgrad: tokens / 128 * n_ff * 4);
- * NULL or too small -> the statistics / column sums are taken by a separate small pass over the stored output instead. */
-/* prepare (once per optimizer step): W2 fp32 [n_out][n_ff] -> W2g bf16, c [n_out], b2f [n_out] (b2 nullable) */
-int antmmf_ffn_prepare_w2(const float* W2, const float* gamma, const float* beta, const float* b2, void* W2g, float* c, float* b2f, int n_out,
-                          int n_ff, antmmf_stream_t stream);
-/* Z = act(X W1^T + b1), DACT = act'(X W1^T + b1) (same row stride ldz), stats[i] = (mean, 1/sqrt(var + eps)) of the ROUNDED row Z[i] */
-int antmmf_ffn_fc1_fwd(const void* X, const void* W1, const float* b1, void* Z, void* DACT, float* stats, int tokens, int n_ff, int n_in,
-                       int64_t ldx, int64_t ldw, int64_t ldz, int act, float eps, float* workspace, int64_t workspace_bytes, antmmf_stream_t stream);
-int antmmf_ffn_fc2_fwd(const void* Z, const void* W2g, const float* colsum_w2g, const float* b2f, const float* stats, const void* RES, void* Y,
-                       int tokens, int n_out, int n_ff, int64_t ldz, int64_t ldw, int64_t ldres, int64_t ldy, antmmf_stream_t stream);
-/* backward row pass: rowv4[i] = (mu, rstd, m1, m2) with m1 = dy_i . c / n_ff, m2 = dy_i . (y_i - b2f - res_i) / n_ff;  dYs = bf16(rstd_i dy_i) (fc2's
- * wgrad operand);  s_col[j] += sum_i rstd_i mu_i dy_ij;  cs_col[j] += sum_i dy_ij (nullable).  n_out <= 2048. */
-int antmmf_ffn_bwd_rows(const void* dY, const void* Y, const void* RES, const float* b2f, const float* colsum_w2g, const float* stats, float* rowv4,
-                        void* dYs, float* s_col, float* cs_col, int tokens, int n_out, int n_ff, int64_t lddy, int64_t ldy, int64_t ldres,
-                        int64_t lddys, antmmf_stream_t stream);
-/* dU = DACT * (rstd_i (dY W2gT^T - m1_i) - zhat_ik rstd_i m2_i), zhat = (Z - mu_i) rstd_i;  W2gT = W2g transposed [n_ff][n_out];  db1[k] += sum_i dU_ik (nullable) */
-int antmmf_ffn_fc2_dgrad(const void* dY, const void* W2gT, const void* Z, const void* DACT, const float* rowv4, void* dU, float* db1, int tokens,
-                         int n_ff, int n_out, int64_t lddy, int64_t ldw, int64_t ldz, int64_t lddu, float* workspace, int64_t workspace_bytes,
-                         antmmf_stream_t stream);
-/* Gm = dYs^T Z (fp32 [n_out][n_ff], from antmmf_gemm_wgrad_bf16 into a zeroed buffer):  dW2 += gamma_k (Gm - s_j) + beta_k cs_j;
- * dgamma_k += sum_j W2[j][k] (Gm[j][k] - s_j);  dbeta_k += sum_j W2[j][k] cs_j   (dgamma / dbeta nullable) */
-int antmmf_ffn_wgrad_post(const float* Gm, const float* W2, const float* gamma, const float* beta, const float* s, const float* cs, float* dW2,
-                          float* dgamma, float* dbeta, int n_out, int n_ff, antmmf_stream_t stream);
 
 /* ---- input pipeline: the video-frame transform in front of the visual tower, for all frames of one video at once:
  * uint8 -> float32 (CustomTransforms.__call__, antmmf/datasets/processors/image_processors.py:520-547) -> bilinear resize to

