@@ -289,9 +289,6 @@ def sumsq_(out, x):
 GEMM_TRACE = None
 
 
-_GEMM_WS = {}
-_GEMM_WS_FLOATS = 16 << 20   # 64 MiB: 8 XCD chunks x leftover tiles x K-slices <= 256 partial tiles of 256 x 256 fp32
-_GEMM_WS_MIN_ROWS = 16384    # (tests lower it)
 
 
 def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat16, alpha=1.0, bias=None, act=None,
@@ -323,13 +320,8 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
     if GEMM_TRACE is not None and _lib.backend() == 1:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    # large NT shapes: a per-device 64-MiB scratch lets the persistent kernel split the tiles of a nearly empty last round along K (csrc/gemm.hip, gemm_tail_reduce_kernel)
+    # (no scratch: since round 5 the persistent NT kernel finishes the leftover tiles of its walk as cells inside the same launch -- csrc/gemm.hip, gemm_nt_k64r_kernel)
     ws = None
-    if not p_rmajor and not q_rmajor and I >= _GEMM_WS_MIN_ROWS and out.dtype == torch.bfloat16:
-        key = (P.device, _stream())   # per (device, stream): two GEMMs on different streams must not share partial-tile scratch
-        ws = _GEMM_WS.get(key)
-        if ws is None:
-            ws = _GEMM_WS[key] = torch.empty(_GEMM_WS_FLOATS, dtype=torch.float32, device=P.device)
     _rc(_lib.load().antmmf_gemm_bf16_ws(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0),
                                         int(p_rmajor), int(q_rmajor), _dt(out), float(alpha), _p(bias),
                                         ACT_IDS[act] | (0x100 if aux_grad else 0) | (0x200 if gate_is_grad else 0),

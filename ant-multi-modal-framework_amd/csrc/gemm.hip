@@ -57,9 +57,9 @@ struct GemmArgs {
     const float* rowv;
     const float* colv;
     float* part;   // mode 1: [J / 64][I] float2 (column block major);  mode 3: [I / 128][J]
-    // ---- tail round of the persistent NT kernel split along K (gemm_nt_k64r_kernel): tail_s K-slices per leftover tile, partial tiles -> tail_ws (0 = off)
-    int tail_s, tail_rmax;
-    float* tail_ws;
+    // ---- tail round of the persistent NT kernel (gemm_nt_k64r_kernel): tail_cells != 0 -> the leftover tiles of an XCD chunk's walk are computed as 16 cells each
+    // (one phase x one Q fragment per wave), spread over all the chunk's workgroups, inside the same launch
+    int tail_cells;
 };
 
 
@@ -966,10 +966,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pring_kernel(const GemmArgs g, in
 #define K64_SETPRIO(n) do {} while (0)
 #define K64_FENCE8(a) do {} while (0)
 #define K64_FENCE4(a) do {} while (0)
+#define K64_TIE2(a) do {} while (0)
 #else
 #define K64_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds0 + (addr)), "n"(OFF))
 #define K64_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define K64_FENCE4(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define K64_TIE2(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]))   /* orders the uses of two more asm-loaded registers behind the preceding fence (volatile asms keep their order) */
 #define K64_FENCE8(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 #endif
 
@@ -1538,8 +1540,13 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 //   * the prologue loads K-tile 0 and the Q half of K-tile 1 (what the steady-state refill schedule does not bring itself), so the first
 //     K-tile issues the same operations as every other; the last tile's look-ahead refills wrap to its own first K-tiles (harmless re-reads,
 //     drained before the kernel ends) instead of the two special wait ladders of the kernel above.
-//   * tail round (g.tail_s > 0): the xcount % per_xcd tiles that would form a last, nearly empty round of the XCD chunk's walk are split along K over the chunk's
-//     workgroups behind the walk (fp32 partial tiles in fragment order -> g.tail_ws, finished by gemm_tail_reduce_kernel).
+//   * tail round (g.tail_cells): the xcount % per_xcd tiles that would form a last, nearly empty round of the XCD chunk's walk (image tower, J = 1024: 4112 tiles on 256
+//     workgroups = 16 rounds + 2 tiles per chunk -- a 17th round on 6 % of the CUs, 5.5 % of the launch) are left out of the walk and computed behind it as CELLS: the
+//     256 x 256 tile is 4 phases x 4 Q fragments per wave, a cell is ONE phase x ONE Q fragment (64 x 64 outputs over the 8 waves, the full K range), so a tile is 16
+//     independent cells and two leftover tiles occupy all 32 workgroups of the chunk for ~ 1 / 10 of a tile time.  No K split: no partial sums, no workspace, no second
+//     launch (round 4's K-split over a second launch recovered <= 2 of the 5.5 %), and the accumulators start from bias + residual and add the K-tiles in the walk's
+//     order, so a cell's outputs are BIT-IDENTICAL to what the walk would have stored.  The cell loop keeps 6 K-tiles of its two 8-KB operand pieces in flight in an
+//     8-slot ring laid over the quarter regions of the two stages (a slot is refilled two barriers after its last read).
 // Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual; 5 = bias + activation with TWO outputs (the
 // activation -> C, its derivative or the pre-activation -> aux: the forward of a feed-forward whose activation output is kept for backward; g.act at run time);
 // 21 = the same plus per-row (sum z, sum z^2) of the rounded activation over the wave's 64 columns -> g.part (fc1 of the sub-LN fold, GemmArgs::ffn_mode 1).
@@ -1610,15 +1617,22 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     const int xcd = blockIdx.x & 7, lx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int qd = ntiles >> 3, rm = ntiles & 7;
     const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
+    // (band height = rows of the tile patch an XCD's 32 workgroups cover at a time: 4 x 8 tiles in the product.  LAB: ANTMMF_GEMM_RASTER bits 5 - 6 select 8 / 16 / 2
+    // rows -- the A/B for "is the weight panel, re-read once per band out of the Infinity Cache, a limiter?", profiles/r5_gemm_patch_shape_ab.txt)
+#ifdef ANTMMF_LAB
+    const int PR = ((g.raster >> 5) & 3) == 1 ? 8 : ((g.raster >> 5) & 3) == 2 ? 16 : ((g.raster >> 5) & 3) == 3 ? 2 : 4;
+#else
+    constexpr int PR = 4;
+#endif
     auto tile_origin = [&](int local, int& i0, int& j0) {
         const int wgid = xbase + local;
-        const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
-        const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
-        i0 = (band * 4 + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
+        const int band = wgid / (PR * tiles_j), inb = wgid - band * PR * tiles_j;
+        const int rows_here = (tiles_i - band * PR) < PR ? (tiles_i - band * PR) : PR;
+        i0 = (band * PR + inb % rows_here) * BM; j0 = (inb / rows_here) * BN;
     };
-    // tail round split along K (g.tail_s > 0): the xcount % per_xcd tiles that would run as a last, nearly empty round are left out of the walk; behind it every workgroup
-    // takes one K-slice of one of them (fp32 partial tile -> g.tail_ws, summed + finished by gemm_tail_reduce_kernel)
-    const int tail_r = g.tail_s > 0 ? xcount % per_xcd : 0;
+    // tail round as cells (g.tail_cells): the xcount % per_xcd tiles that would run as a last, nearly empty round are left out of the walk; behind it the chunk's
+    // workgroups share their 16 cells each (see the header)
+    const int tail_r = g.tail_cells ? xcount % per_xcd : 0;
     const int xcount_main = xcount - tail_r;
     int local = lx;
     if (local >= xcount_main) return;
@@ -1946,37 +1960,70 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     glds_wait_all();
     SCHED_FENCE();
     if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
-    if (tail_r > 0 && lx < tail_r * g.tail_s) {
-        // one K-slice of one leftover tile on the two stages as a plain double buffer (a slice is a few K-tiles: the ring's look-ahead logic would not pay)
-        const int u = lx / g.tail_s, v = lx - u * g.tail_s, kslice = nk / g.tail_s;
-        tile_origin(xcount_main + u, i0, j0);
-        tile_bases(i0, j0, pgc, qgc);
+    if (tail_r > 0 && lx < 16 * tail_r) {
+        // ---- leftover tiles as cells.  Cell c of the chunk = tile c >> 4, phase (c >> 2) & 3, Q fragment c & 3: per wave 2 P fragments (rows wi 128 + 32 ph + [0, 32)) x 1 Q
+        // fragment (columns wj 64 + 16 jt + [0, 16)), i.e. 4 MFMAs per K-tile; operands per K-tile: the P quarter `ph` and the Q quarter `jt` of the tile's stage image
+        // (one 8-row piece each per wave), parked in ring slot t & 7 = (stage (t >> 2) & 1, quarter region t & 3) -- the fragment read offsets of the walk apply as they are.
+        constexpr int DEPTH = 6;   // K-tiles in flight; slot (t + DEPTH) & 7 was last read in iteration t - 2: every wave is past barrier(t - 1), i.e. done with it
+        wg_barrier_lds_only();     // every wave is out of the walk's last stage reads (its DMA pieces were drained above)
+        for (int c = lx; c < 16 * tail_r; c += per_xcd) {
+            const int u = c >> 4, cph = (c >> 2) & 3, cjt = c & 3;
+            tile_origin(xcount_main + u, i0, j0);
+            tile_bases(i0, j0, pgc, qgc);
+            auto cell_issue = [&](int kt) {
+                const int sq = kt & 3;
+                const uint32_t st = (uint32_t)((kt >> 2) & 1) * STAGE;
+                glds16(pgc + (long)cph * 32 * ldpb + (long)kt * 128 + pv[sq & 1], smem + st + (prow0 + 32 * sq) * 128);
+                glds16(qgc + (long)cjt * 16 * ldqb + (long)kt * 128 + qv[sq], smem + st + QOFF + (qrow0 + 16 * sq) * 128);
+            };
+            // accumulators start from bias + residual, as in the walk (same fp32 sum, same order -> same bits)
+            f32x4_t cacc[2];
+            const int ccol = j0 + wj * 64 + cjt * 16 + 4 * pbg;
 #pragma unroll
-        for (int a2 = 0; a2 < TI; ++a2)
+            for (int f = 0; f < 2; ++f) {
+                const long crow = i0 + wi * 128 + (2 * cph + f) * 16 + l15;
+                f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+                if (RES) {
+                    const k64_u2_t rr = *reinterpret_cast<const k64_u2_t*>(g.residual + crow * g.ldr + ccol);
+                    v = (f32x4_t){bf_lo(rr[0]), bf_hi(rr[0]), bf_lo(rr[1]), bf_hi(rr[1])};
+                }
+                if (BIAS) { const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + ccol); v = RES ? v + b4 : b4; }
+                cacc[f] = v;
+            }
 #pragma unroll
-            for (int b2 = 0; b2 < TJ; ++b2) acc[a2][b2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        so = 0;
-        const int k0 = v * kslice, k1 = k0 + kslice;
-        wg_barrier_lds_only();   // every wave is out of the walk's last stage reads
+            for (int kt = 0; kt < DEPTH; ++kt) if (kt < nk) cell_issue(kt);
+            bf16x8_t cp[4], cq[2];
+#define K64R_CELL_ITER(SLOT)                                                                                                        \
+            if (t0 + (SLOT) < nk) {                                                                                                 \
+                const int kt = t0 + (SLOT);                                                                                         \
+                if (kt + DEPTH < nk) { cell_issue(kt + DEPTH); glds_wait_le<2 * DEPTH>(); } else glds_wait_all();                   \
+                K64_BARRIER();                                                                                                      \
+                constexpr uint32_t cst = (uint32_t)(((SLOT) >> 2) & 1) * STAGE;                                                     \
+                constexpr int csq = (SLOT) & 3, k0 = 2 * csq, k1 = 2 * csq + 1;                                                     \
+                K64_READ(cq[0], cst + qbase[csq], csq * 2048);           K64_READ(cq[1], cst + qbase[csq ^ 2], csq * 2048);         \
+                K64_READ(cp[0], cst + pbase[k0 & 3], k0 * 2048);         K64_READ(cp[1], cst + pbase[(k0 & 3) ^ 2], k0 * 2048);     \
+                K64_READ(cp[2], cst + pbase[k1 & 3], k1 * 2048);         K64_READ(cp[3], cst + pbase[(k1 & 3) ^ 2], k1 * 2048);     \
+                K64_FENCE4(cp);                                                                                                     \
+                K64_TIE2(cq);                                                                                                       \
+                SCHED_FENCE();                                                                                                      \
+                cacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cq[0], cp[0], cacc[0], 0, 0, 0);                                  \
+                cacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cq[0], cp[2], cacc[1], 0, 0, 0);                                  \
+                cacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cq[1], cp[1], cacc[0], 0, 0, 0);                                  \
+                cacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cq[1], cp[3], cacc[1], 0, 0, 0);                                  \
+                SCHED_FENCE();                                                                                                      \
+            }
+            for (int t0 = 0; t0 < nk; t0 += 8) {
+                K64R_CELL_ITER(0) K64R_CELL_ITER(1) K64R_CELL_ITER(2) K64R_CELL_ITER(3) K64R_CELL_ITER(4) K64R_CELL_ITER(5) K64R_CELL_ITER(6) K64R_CELL_ITER(7)
+            }
+#undef K64R_CELL_ITER
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, k0, 0); dma_q(qgc, pq, k0, 0); }
-        for (int kt = k0; kt < k1; ++kt) {
-            if (kt + 1 < k1) {
-#pragma unroll
-                for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, kt + 1, so ^ STAGE); dma_q(qgc, pq, kt + 1, so ^ STAGE); }
-                glds_wait_le<8>();   // this K-tile's eight pieces have landed; the next one's stay in flight
-            } else glds_wait_all();
-            wg_barrier_lds_only();
-            K64R_READS(0); K64R_MFMA(0, 0); K64R_READS(1); K64R_MFMA(1, 0); K64R_READS(2); K64R_MFMA(2, 0); K64R_READS(3); K64R_MFMA(3, 0);
-            wg_barrier_lds_only();   // the stage may be overwritten by the K-tile after next
-            so ^= STAGE;
+            for (int f = 0; f < 2; ++f) {
+                const long crow = i0 + wi * 128 + (2 * cph + f) * 16 + l15;
+                const k64_u2_t ov = {pack_bf2(cacc[f][0], cacc[f][1]), pack_bf2(cacc[f][2], cacc[f][3])};
+                *reinterpret_cast<k64_u2_t*>(reinterpret_cast<bf16_t*>(g.C) + crow * g.ldc + ccol) = ov;
+            }
+            K64_BARRIER();   // the next cell's prologue refills slots this cell's last K-tiles were read from
         }
-        // partial tile in FRAGMENT order ([wave][it][jt][lane] x 4 floats: every store instruction writes 1 KB of consecutive bytes); gemm_tail_reduce_kernel maps it back
-        float* slot = g.tail_ws + ((long)(xcd * g.tail_rmax + u) * g.tail_s + v) * (BM * BN) + (long)(wave * 32 * 64 + lane) * 4;
-#pragma unroll
-        for (int it = 0; it < TI; ++it)
-#pragma unroll
-            for (int jt = 0; jt < TJ; ++jt) *reinterpret_cast<f32x4_t*>(slot + (it * 4 + jt) * 256) = acc[it][jt];
     }
 #ifndef ANTMMF_EMULATE
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_k64_clk[0] = __builtin_readcyclecounter() - clk0; g_k64_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
@@ -1993,43 +2040,6 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #undef K64R_INIT
 #undef K64R_EPIQ
 #undef K64R_RESLOAD
-}
-
-// The tail round of gemm_nt_k64r_kernel, second half: sums the tail_s fp32 partial tiles of every leftover tile (in slice order: deterministic), adds bias / residual and
-// stores bf16.  Grid: (8 XCD chunks x tail_rmax leftover tiles) x 16 row blocks; block = 16 rows x 256 columns, a thread = 16 consecutive columns of one row.
-__global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const GemmArgs g, int ntiles, int per_xcd) {
-    const int slot = blockIdx.x >> 4, rb = blockIdx.x & 15;
-    const int xcd = slot / g.tail_rmax, u = slot - xcd * g.tail_rmax;
-    const int tiles_j = g.J / 256, tiles_i = g.I / 256;
-    const int qd = ntiles >> 3, rm = ntiles & 7;
-    const int xbase = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd, xcount = qd + (xcd < rm ? 1 : 0);
-    const int tail_r = xcount % per_xcd;
-    if (u >= tail_r) return;
-    const int wgid = xbase + (xcount - tail_r) + u;
-    const int band = wgid / (4 * tiles_j), inb = wgid - band * 4 * tiles_j;
-    const int rows_here = (tiles_i - band * 4) < 4 ? (tiles_i - band * 4) : 4;
-    const int i0 = (band * 4 + inb % rows_here) * 256, j0 = (inb / rows_here) * 256;
-    const float* src = g.tail_ws + (long)slot * g.tail_s * 65536;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        // element = one accumulator vector of the GEMM kernel's fragment order: [wave][it][jt][lane], 4 consecutive columns of one row
-        const int idx = rb * 1024 + q * 256 + threadIdx.x;
-        const int lane = idx & 63, frag = idx >> 6, jt = frag & 3, it = (frag >> 2) & 7, wave = frag >> 5;
-        const int l15 = lane & 15, grp = lane >> 4;
-        const long r = i0 + (wave >> 2) * 128 + it * 16 + l15;
-        const int c = j0 + (wave & 3) * 64 + jt * 16 + 4 * (((grp & 1) << 1) | (grp >> 1));
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sl = 0; sl < g.tail_s; ++sl) {
-            const float4 x = *reinterpret_cast<const float4*>(src + (long)sl * 65536 + (long)idx * 4);
-            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-        }
-        if (g.bias) { const float4 b4 = *reinterpret_cast<const float4*>(g.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-        if (g.residual) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(g.residual + r * g.ldr + c);
-            v.x += bf_lo(rr.x); v.y += bf_hi(rr.x); v.z += bf_lo(rr.y); v.w += bf_hi(rr.y);
-        }
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + r * g.ldc + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-    }
 }
 
 // fp32 partial tile of a token split -> workspace, staged through the wave's LDS region in two halves so that every store
@@ -2353,6 +2363,8 @@ static int g_gemm_variant = -1;
 extern "C" int antmmf_debug_set_gemm_variant(int v) { g_gemm_variant = v; return ANTMMF_OK; }
 #define GEMM_VARIANT_INIT() do { if (g_gemm_variant < 0) { const char* ve = getenv("ANTMMF_GEMM_VARIANT"); g_gemm_variant = ve ? atoi(ve) : 4; } } while (0)
 #define LAB_ONLY(...) __VA_ARGS__
+static long g_k64_cell_launches = 0;   // launches whose tail round ran as cells (tests: "the cells really ran")
+extern "C" long antmmf_debug_gemm_cell_launches() { return g_k64_cell_launches; }
 #else
 static constexpr int g_gemm_variant = 4;
 #define GEMM_VARIANT_INIT() do {} while (0)
@@ -2388,7 +2400,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
     g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
-    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;
+    g.tail_cells = 0;
     act &= 0xff;
     // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
     // about what lands in aux); gate-holds-act' needs a gate
@@ -2500,27 +2512,18 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                 LAB_ONLY(else if (g_gemm_variant & 4194304) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 128>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);) \
                 LAB_ONLY(else if (g_gemm_variant & 131072) hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 4>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);) \
                 else {                                                                                                            \
-                    /* tail round split along K (see gemm_tail_reduce_kernel): when the last round of the tile walk would run on <= a quarter of the workgroups */ \
-                    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;                                                           \
-                    if (E < 4 && workspace && !(g_gemm_variant & 33554432) && !(gridp & 7)) {                                     \
+                    /* tail round as cells (kernel header): when the leftover tiles of an XCD chunk are so few that their 16 cells each give every workgroup of the chunk at  \
+                       most ONE cell (<= 2 tiles at 32 workgroups per chunk: the image tower's J = 1024 shapes, 16 rounds + 2) and every workgroup walks at least one tile.     \
+                       Lab variant bit 26 lifts the one-cell limit (tests on small grids), bit 25 disables the cells (A/B: bit-identical output either way) */               \
+                    g.tail_cells = 0;                                                                                             \
+                    if (E < 4 && !(g_gemm_variant & 33554432) && !(gridp & 7)) {                                                  \
                         const int per_xcd = (int)(gridp >> 3);                                                                    \
                         const long qd = tiles256 >> 3, rm = tiles256 & 7;                                                         \
                         const int r0 = (int)(qd % per_xcd), r1 = rm ? (int)((qd + 1) % per_xcd) : r0, rmax = r0 > r1 ? r0 : r1;   \
-                        /* measured (profiles/r4_gemm_tail_split_ab.txt): pays only when the leftover round is nearly empty AND a K-slice is long enough to amortise the    \
-                           partial tile's store, the short slice loop and the reduce launch -- >= 16 slices of >= 4 K-tiles (the J = 1024, R = 4096 shapes: + 0 ... 2 %);        \
-                           with 4 slices (J = 4096) or 1 - 3 K-tiles per slice (R <= 3072) it costs 1 - 3 %.  Variant bit 26 lifts the restriction (tests), bit 25 disables */   \
                         const bool any_tail = (g_gemm_variant & 67108864) != 0;                                                   \
-                        if (rmax > 0 && rmax * (any_tail ? 4 : 16) <= per_xcd && qd >= 2L * per_xcd) {                            \
-                            int ts = per_xcd / rmax;                                                                              \
-                            const int nk64 = R >> 6;                                                                              \
-                            while (ts > 1 && nk64 % ts) --ts;                                                                     \
-                            if (ts >= (any_tail ? 4 : 16) && nk64 / ts >= (any_tail ? 1 : 4) && workspace_bytes >= 8L * rmax * ts * 65536 * 4) {    \
-                                g.tail_s = ts; g.tail_rmax = rmax; g.tail_ws = workspace;                                         \
-                            }                                                                                                     \
-                        }                                                                                                         \
+                        if (rmax > 0 && (any_tail || 16 * rmax <= per_xcd) && qd >= per_xcd) { g.tail_cells = 1; LAB_ONLY(++g_k64_cell_launches;) } \
                     }                                                                                                             \
                     hipLaunchKernelGGL((gemm_nt_k64r_kernel<(E < 4 ? E : 0), 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); \
-                    if (g.tail_s) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3(8u * g.tail_rmax * 16u), dim3(256), 0, stream, g, (int)tiles256, (int)(gridp >> 3)); \
                 }                                                                                                                 \
             }                                                                                                                     \
             /* variant bits: 16 = two barriers per phase (the earlier schedule, kept for A/B), 128 = no s_setprio, 256 = clock probe */ \
@@ -2682,7 +2685,7 @@ static void gemm_ffn_args(GemmArgs& g, const void* P, const void* Q, void* C, in
     g.I = I; g.J = J; g.R = R; g.act = ANTMMF_ACT_NONE; g.c_dtype = ANTMMF_BF16; g.accumulate = 0; g.ksteps_per_split = (R + 63) / 64; g.alpha = 1.0f;
     g.ws = nullptr; g.raster = 1; g.aux_grad = 0; g.gate_grad = 0; g.debug_nostore = 0;
     g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
-    g.tail_s = 0; g.tail_rmax = 0; g.tail_ws = nullptr;
+    g.tail_cells = 0;
 }
 static bool ffn_shape_ok(int I, int J, int R, long ldp, long ldq, long ldc) {
     return I > 0 && J > 0 && R > 0 && !(J & 7) && !(R & 7) && !(ldp & 7) && !(ldq & 7) && !(ldc & 7);

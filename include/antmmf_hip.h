@@ -156,9 +156,9 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
                      int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                      const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
                      int accumulate, int split_k, antmmf_stream_t stream);
-/* The same GEMM with a caller-owned DEVICE scratch buffer (fp32, >= 64 MiB to be used at all; the contents are undefined afterwards).  With it the persistent NT kernel splits
- * the tiles of a last, nearly empty round of its tile walk along K over all workgroups (fp32 partial tiles -> workspace, summed in slice order by a second launch:
- * deterministic); without it (NULL / too small) the call is antmmf_gemm_bf16. */
+/* The same GEMM with a caller-owned DEVICE scratch buffer (fp32): used by the r-major / r-major layout (the weight-gradient kernels' token split: partial tiles ->
+ * workspace, summed in split order by a second launch; NULL -> fp32 atomics).  The all-r-contiguous layouts need none: the persistent kernel finishes the leftover
+ * tiles of its tile walk inside the same launch (round 4's K-split through this scratch is gone).  NULL / 0 is always valid. */
 int antmmf_gemm_bf16_ws(const void* P, const void* Q, void* C, int I, int J, int R, int64_t ldp, int64_t ldq,
                         int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                         const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,

@@ -95,6 +95,18 @@ def test_univl_stage2_hard_mining_vs_oracle(golden):
 
 
 @SLOW
+def test_loss_contracts_over_seeded_batches_moco_and_dmae():
+    """(2 batches each on the emulator: plumbing; the GPU suite runs 6)"""
+    import subprocess
+    import sys
+
+    print(mc.case_univl_moco_loss_contract(torch.device("cpu"), k=2))
+    env = dict(os.environ, ANTMMF_HIP_LIB=EMU_LIB, ANTMMF_ALLOW_EMULATOR="1")
+    out = subprocess.run([sys.executable, "-c", mc.case_dmae_stage3_loss_contract("cpu", k=2)], capture_output=True, text=True, timeout=2400, env=env)
+    assert "okdmaek" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@SLOW
 def test_univl_stage2_cnvid_scheduled_gate_vs_reference(golden):
     print(mc.case_univl_stage2_cnvid_gate(torch.device("cpu"), golden))
 

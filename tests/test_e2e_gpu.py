@@ -74,6 +74,20 @@ def test_dmae_stage3_vs_reference(loss_type):
     print(out.stdout[-400:])
 
 
+def test_dmae_stage3_loss_contract_over_seeded_batches():
+    """the 1e-3 contract itself (mean over 6 seeded batches vs the oracle), not the single-batch noise floor"""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, "-c", mc.case_dmae_stage3_loss_contract("cuda:0")], capture_output=True, text=True, timeout=1500, env=dict(os.environ))
+    assert "okdmaek" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    print(out.stdout[-400:])
+
+
+def test_univl_moco_loss_contract_over_seeded_batches():
+    print(mc.case_univl_moco_loss_contract(DEV))
+
+
 def test_dmae_stage3_with_tpmcl_vs_reference():
     import subprocess
     import sys
@@ -122,7 +136,8 @@ for k in o1["losses"]:
     assert float(o1["losses"][k]) == float(o2["losses"][k]), f"{k}: forward must be deterministic"
 l1 = float(o1["losses"]["level1_similarity_loss"])
 assert abs(l1 - math.log(15.0)) < 0.35, l1
-expect = {"vtp8": {"level1_similarity_loss", "level2_similarity_loss"}, "dmae12": {"level1_similarity_loss", "level3_similarity_loss"}}[workload]
+expect = {"vtp8": {"level1_similarity_loss", "level2_similarity_loss"}, "vtp8t": {"level1_similarity_loss", "level3_similarity_loss"},
+          "dmae12": {"level1_similarity_loss", "level3_similarity_loss"}}[workload]
 assert expect <= set(o1["losses"]), set(o1["losses"])
 first = None
 for it in range(4):
@@ -134,9 +149,10 @@ print("okfull", workload, {k: round(float(v), 4) for k, v in o1["losses"].items(
 """
 
 
-@pytest.mark.parametrize("workload", ["vtp8", "dmae12"])
+@pytest.mark.parametrize("workload", ["vtp8", "vtp8t", "dmae12"])
 def test_video_workloads_full_size_step_properties(workload):
-    """BASELINE configs 3 / 4 AT SIZE (full ViT-B/16 + BERT-base towers, 224 x 224 frames, 8 clips + stage-2 cross encoder / 12 frames +
+    """(vtp8t: config 3 WITH its temporal module -- the 4-layer seqTransf transformer over the 8 frame tokens at d = 768 in front of the WTI scores.)
+    BASELINE configs 3 / 4 AT SIZE (full ViT-B/16 + BERT-base towers, 224 x 224 frames, 8 clips + stage-2 cross encoder / 12 frames +
     stage-3 WTI + NegNCE + TPM-CL, B = 8 videos) through the registry model and the product trainer: losses finite, the stage-1 MIL-NCE at
     random init sits at its closed form ln(2B - 1) (uniform similarities; SURVEY 8c measured 2.70888 on the reference), the forward is
     deterministic, a few AdamW steps on the same batch lower the loss.  One process per workload: prj/base_vtp and prj/dmae_vtp both

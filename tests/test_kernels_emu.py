@@ -188,28 +188,33 @@ def test_gemm_k64_rolling_epilogue():
     assert "okk64r" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_gemm_k64_tail_round_split():
-    """The tail round of the persistent NT kernel split along K (gemm_nt_k64r_kernel + gemm_tail_reduce_kernel): 72 tiles on a 32-workgroup grid = two full rounds of the
-    tile walk + ONE leftover tile per XCD chunk, whose four K-tiles go to the chunk's four workgroups (fp32 partial tiles in the caller's scratch, summed in slice order,
-    bias + residual applied by the reduce launch; variant bit 26 lifts the product's "16 slices of >= 4 K-tiles" rule for this small case).  Against the fp32 product on every tile, leftover tiles included; and the split must really have happened: with the
-    split disabled (variant bit 25) a few results differ in the last bf16 bit (order of the fp32 sum), only inside the eight leftover tiles."""
+def test_gemm_k64_tail_round_cells():
+    """The tail round of the persistent NT kernel as CELLS inside the same launch (gemm_nt_k64r_kernel): 72 tiles on a 32-workgroup grid = two full rounds of the tile walk
+    + ONE leftover tile per XCD chunk, whose 16 cells (one phase x one Q fragment per wave, full K range) go to the chunk's four workgroups, four cells each (variant bit
+    26 lifts the product's one-cell-per-workgroup rule for this small grid).  K = 256 (4 K-tiles: shorter than the cell ring's depth) and K = 768 (12: the 8-slot ring
+    wraps).  Against the fp32 product on every tile, and BIT-IDENTICAL to the same call with the cells disabled (variant bit 25: the leftover tiles go through the walk):
+    the cells start their accumulators from bias + residual and add the K-tiles in the walk's order."""
     import sys
 
-    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
+    code = ("import os, sys, ctypes, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
             "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '32'; os.environ['ANTMMF_GEMM_VARIANT'] = str(4 | (1 << 26));"
-            "import kernel_cases as kc; from antmmf.hip import ops, _lib; ops._GEMM_WS_MIN_ROWS = 0;"
-            "g = torch.Generator().manual_seed(11); I, J, R = 4608, 1024, 256;"
-            "X = torch.randn(I, R, generator=g).bfloat16(); W = (torch.randn(J, R, generator=g) * 0.06).bfloat16();"
-            "b = torch.randn(J, generator=g); r = (torch.randn(I, J, generator=g) * 3).bfloat16(); ref = X.float() @ W.float().t() + b + r.float();"
-            "y1 = ops.gemm(X, W, bias=b, residual=r); kc.check('k64r.tail', y1, ref, 2e-2, 1e-2);"
-            "lib = _lib.load(); lib.antmmf_debug_set_gemm_variant(4 | (1 << 25)); y0 = ops.gemm(X, W, bias=b, residual=r); kc.check('k64r.notail', y0, ref, 2e-2, 1e-2);"
-            "d = (y0.float() - y1.float()).abs(); nz = d.nonzero();"
-            "assert 0 < nz.shape[0] < 20000 and float(d.max()) <= 0.26, (nz.shape[0], float(d.max()));"
-            "tiles = set((int(i) // 256, int(j) // 256) for i, j in nz.tolist()); assert len(tiles) <= 8, sorted(tiles);"
-            "print('oktail', nz.shape[0], sorted(tiles))"
+            "import kernel_cases as kc; from antmmf.hip import ops, _lib; lib = _lib.load(); lib.antmmf_debug_gemm_cell_launches.restype = ctypes.c_long;"
+            "g = torch.Generator().manual_seed(11);"
+            "cases = [(4608, 1024, 256, True, True), (4608, 1024, 768, False, False)] + ([(4608, 1024, 768, True, False)] if os.environ.get('ANTMMF_SLOW_TESTS') else []);"
+            "\nfor I, J, R, wb, wr in cases:\n"
+            "    X = torch.randn(I, R, generator=g).bfloat16(); W = (torch.randn(J, R, generator=g) * 0.06).bfloat16()\n"
+            "    b = torch.randn(J, generator=g) if wb else None; r = (torch.randn(I, J, generator=g) * 3).bfloat16() if wr else None\n"
+            "    ref = X.float() @ W.float().t() + (b if wb else 0) + (r.float() if wr else 0)\n"
+            "    lib.antmmf_debug_set_gemm_variant(4 | (1 << 26)); n0 = lib.antmmf_debug_gemm_cell_launches()\n"
+            "    y1 = ops.gemm(X, W, bias=b, residual=r); kc.check('k64r.cells', y1, ref, 2e-2, 1e-2)\n"
+            "    assert lib.antmmf_debug_gemm_cell_launches() == n0 + 1, 'the cell tail did not run'\n"
+            "    lib.antmmf_debug_set_gemm_variant(4 | (1 << 25)); y0 = ops.gemm(X, W, bias=b, residual=r)\n"
+            "    assert lib.antmmf_debug_gemm_cell_launches() == n0 + 1\n"
+            "    assert torch.equal(y0, y1), (R, int((y0 != y1).sum()))\n"
+            "print('okcells')"
             % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
-    assert "oktail" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=2400)
+    assert "okcells" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_gemm_wgrad_ring(ops):

@@ -282,32 +282,59 @@ def test_attention_fwd32_opt_in(variant):
     assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_gemm_k64_tail_round_split(ops, lab):
-    """The tail round of the persistent NT kernel split along K at the size where the product uses it (263168 x 1024 x 4096: 4112 tiles on 256 workgroups = 16 rounds + 2 leftover
-    tiles per XCD chunk, 16 K-slices of 4 K-tiles each): sampled rows against an fp32 product (rows of leftover tiles included), and against the same call with the split
-    disabled -- different in the last bf16 bit on part of the 16 leftover tiles, identical everywhere else."""
+def test_gemm_k64_tail_round_cells(ops, lab):
+    """The tail round of the persistent NT kernel as cells inside the same launch, at the sizes where the product uses it (263168 x 1024: 4112 tiles on 256 workgroups = 16
+    rounds + 2 leftover tiles per XCD chunk -> 32 cells, one per workgroup; K = 4096 and K = 1024, with and without bias + residual): the product library's output is
+    BIT-IDENTICAL to the lab library's with the cells on (same code) and with the cells off (variant bit 25: leftover tiles through the walk) -- the cells start from
+    bias + residual and add the K-tiles in the walk's order -- and rows of the leftover tiles agree with an fp32 product."""
+    import ctypes
+    from antmmf.hip import _lib
+
     lib = lab
+    lib.antmmf_debug_gemm_cell_launches.restype = ctypes.c_long
     g = torch.Generator(device="cuda").manual_seed(9)
-    I, J, R = 257 * 1024, 1024, 4096
-    X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
-    W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
-    b = torch.randn(J, generator=g, device=DEV)
-    r = torch.randn(I, J, generator=g, device=DEV).bfloat16()
-    try:
-        lib.antmmf_debug_set_gemm_variant(4)
-        y1 = ops.gemm(X, W, bias=b, residual=r)
-        lib.antmmf_debug_set_gemm_variant(4 | (1 << 25))
-        y0 = ops.gemm(X, W, bias=b, residual=r)
-    finally:
-        lib.antmmf_debug_set_gemm_variant(4)
-    d = (y0.float() - y1.float()).abs()
-    tiles = torch.unique((d.nonzero() // 256), dim=0)
-    assert 0 < tiles.shape[0] <= 16, tiles.shape            # the split really ran, and only on the leftover tiles
-    rows = torch.unique(torch.cat([tiles[:, 0] * 256 + 7, tiles[:, 0] * 256 + 250, torch.tensor([0, 70000, I - 1], device=DEV)]))
-    ref = X[rows].float() @ W.float().t() + b + r[rows].float()
-    for y in (y1, y0):
-        err = (y[rows].float() - ref).abs()
-        ulp = torch.maximum(ref.abs(), y[rows].float().abs()) * 2.0 ** -8
+    I, J = 257 * 1024, 1024
+    for R, with_br in ((4096, True), (1024, False), (1024, True)):
+        X = torch.randn(I, R, generator=g, device=DEV).bfloat16()
+        W = (torch.randn(J, R, generator=g, device=DEV) * R ** -0.5).bfloat16()
+        b = torch.randn(J, generator=g, device=DEV) if with_br else None
+        r = torch.randn(I, J, generator=g, device=DEV).bfloat16() if with_br else None
+        try:
+            lib.antmmf_debug_set_gemm_variant(4)
+            n0 = lib.antmmf_debug_gemm_cell_launches()
+            y1 = ops.gemm(X, W, bias=b, residual=r)
+            assert lib.antmmf_debug_gemm_cell_launches() == n0 + 1, "the dispatcher did not pick the cell tail"
+            for _ in range(3):
+                assert torch.equal(ops.gemm(X, W, bias=b, residual=r), y1)    # (a DMA piece consumed before it landed would show up as a sporadically different cell)
+            lib.antmmf_debug_set_gemm_variant(4 | (1 << 25))
+            y0 = ops.gemm(X, W, bias=b, residual=r)
+            assert lib.antmmf_debug_gemm_cell_launches() == n0 + 4
+        finally:
+            lib.antmmf_debug_set_gemm_variant(4)
+        assert torch.equal(y0, y1), (R, with_br, int((y0 != y1).sum()))
+        # the product library on the same inputs
+        os.environ.pop("ANTMMF_HIP_LIB", None)
+        _lib.reset_for_tests()
+        try:
+            assert not _lib.is_lab()
+            yp = ops.gemm(X, W, bias=b, residual=r)
+        finally:
+            os.environ["ANTMMF_HIP_LIB"] = _lib.LAB_LIB
+            _lib.reset_for_tests()
+            _lib.load()
+        assert torch.equal(yp, y1)
+        # leftover tiles of XCD chunk x: local ids 512, 513 of its 514 -> global tile ids 514 x + 512 + {0, 1}; rows of those tiles (4 x 8 patches: band = id // 16)
+        rows = []
+        for x in range(8):
+            for u in (512, 513):
+                wg = 514 * x + u
+                band, inb = wg // 16, wg % 16
+                rows_here = min(4, 1028 - 4 * band)
+                rows += [(band * 4 + inb % rows_here) * 256 + 7, (band * 4 + inb % rows_here) * 256 + 250]
+        rows = torch.unique(torch.tensor(rows + [0, 70000, I - 1], device=DEV))
+        ref = X[rows].float() @ W.float().t() + (b if with_br else 0) + (r[rows].float() if with_br else 0)
+        err = (y1[rows].float() - ref).abs()
+        ulp = torch.maximum(ref.abs(), y1[rows].float().abs()) * 2.0 ** -8
         assert bool((err <= ulp * 1.001 + 2e-5).all()), float((err / (ulp + 1e-9)).max())
 
 
