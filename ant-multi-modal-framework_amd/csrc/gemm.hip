@@ -1976,6 +1976,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
                 glds16(pgc + (long)cph * 32 * ldpb + (long)kt * 128 + pv[sq & 1], smem + st + (prow0 + 32 * sq) * 128);
                 glds16(qgc + (long)cjt * 16 * ldqb + (long)kt * 128 + qv[sq], smem + st + QOFF + (qrow0 + 16 * sq) * 128);
             };
+            // (an L2 warm-up of the cell's operand lines in front of this loop -- every line requested once, 4 bytes each, all in flight -- was built and measured: no gain,
+            // profiles/r5_gemm_tail_cells_l2_warmup_ab.jsonl.  The cells are not latency-bound; what the round count promised was never there: the lone 17th round of the
+            // walk runs on an otherwise idle chip and costs far less than a full round)
             // accumulators start from bias + residual, as in the walk (same fp32 sum, same order -> same bits)
             f32x4_t cacc[2];
             const int ccol = j0 + wj * 64 + cjt * 16 + 4 * pbg;

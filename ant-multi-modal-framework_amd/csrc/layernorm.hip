@@ -15,6 +15,7 @@
 // owns a row (<= 16 elements per thread keeps the register count low and the occupancy up), cross-wave sums through LDS.
 // Algorithmic bytes / row: fwd 2*cols*sizeof(T) (+8 B stats); bwd 3*cols*sizeof(T) (+ optional residual-gradient read).
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------ reductions over a "row group" (a wave or a 4-wave workgroup)
 // Workgroup sums go through one of two LDS slots, alternated by the caller (`ph`): ONE barrier per reduction -- a slot is rewritten two
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
     }
 }
 
+#define LN_FWD_ROWS_PER_WAVE 1   /* product default of the wave-per-row forward forms (see ln_fwd_launch) */
 template <typename T>
 static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
                          int cols, float eps, int act, hipStream_t s) {
@@ -357,7 +359,12 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
     // persistent workgroups walking rows with a two-row prefetch, the hardware's own workgroup turnover is 13-15 % faster on the plain
     // kernels (263168 x 1024: 0.220 -> 0.191 ms = 0.95x a torch copy of the same bytes; x 4096: 1.06 -> 0.91 ms) and 5 % on the GELU one
     const long grid_cap = 1L << 20;
-    const int gw = (int)((rows + 3) / 4 < grid_cap ? (rows + 3) / 4 : grid_cap), gb = (int)(rows < grid_cap ? rows : grid_cap);
+    // rows per wave of the wave-per-row forms (the kernel keeps two rows' loads in flight: with half the grid every wave requests BOTH its rows up front and never loops).
+    // LAB: ANTMMF_LN_FWD_RPW selects 1 / 2 / 4 for the A/B (tools/ln_bench.py, profiles/r5_ln_fwd_rows_per_wave_ab.jsonl)
+    static const char* rpw_env = ANTMMF_LAB_ENV("ANTMMF_LN_FWD_RPW");
+    const int rpw = rpw_env ? (atoi(rpw_env) > 0 ? atoi(rpw_env) : 1) : LN_FWD_ROWS_PER_WAVE;
+    const long want_w = (rows + 4L * rpw - 1) / (4L * rpw);
+    const int gw = (int)(want_w < grid_cap ? want_w : grid_cap), gb = (int)(rows < grid_cap ? rows : grid_cap);
     if (nvec <= 64) LN_FWD(1, false, gw);
     else if (nvec <= 128) LN_FWD(2, false, gw);
     else if (nvec <= 256) LN_FWD(1, true, gb);
