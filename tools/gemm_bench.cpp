@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
     if (!gemm || !setv) { printf("missing symbols\n"); return 1; }
     typedef int (*clk_fn)(unsigned long long*);
     clk_fn getclk = (clk_fn)dlsym(h, "antmmf_debug_gemm_clock");
-    const long tokens = 257L * pairs;
+    const long tokens = getenv("GEMM_BENCH_TOKENS") ? atol(getenv("GEMM_BENCH_TOKENS")) : 257L * pairs;   // (GEMM_BENCH_TOKENS=78848: the text tower's row count)
     const int pad = getenv("GEMM_BENCH_PAD") ? atoi(getenv("GEMM_BENCH_PAD")) : 0;  // extra elements in the operands' leading dimension
     struct Shape { const char* tag; int J, R; int bias, res; };
     const Shape shapes[] = {{"fc1", 4096, 1024, 1, 0}, {"fc2", 1024, 4096, 1, 1}, {"qkv", 3072, 1024, 1, 0}, {"out", 1024, 1024, 1, 1},
