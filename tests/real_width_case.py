@@ -91,11 +91,11 @@ def report_rows(rows, pick=()):
     return out
 
 
-def grad_gates(g, max_err=0.15, min_cos=0.99):
+def grad_gates(g, max_err=0.15, min_cos=0.99, min_global=0.999):
     """whole-model direction; every parameter within 15 % of max(its own norm, 1 % of the largest) -- cosine 0.99 is an error of 14 %; parameters carrying >= 1 % of the largest
     norm also by cosine >= 0.99.  (max_err / min_cos: the DMAE case, whose scores route gradients through arg-max selections, states its own.)"""
     bad = []
-    if g["global_cos"] < 0.999:
+    if g["global_cos"] < min_global:
         bad.append("global gradient direction")
     if g["worst_err"][1] > max_err:
         bad.append("gradient error")
@@ -315,13 +315,13 @@ def case_dmae12(dev, which="dmae12"):
     # (the level-3 LOSS of this 2-video batch is reported, not gated: logit scale 100 turns the 4 % score deviations discussed below into 1 - 2 % on the loss; the six-batch
     # contract test tests/model_cases.py::case_dmae_stage3_loss_contract and the reference fixture e2e_dmae_stage3.pt are what hold it)
     # WTI scores are sums of MAXIMA over tokens: a near-tie that bf16 noise flips changes a score by the gap between two candidates, and moves that score's whole gradient from
-    # one token to another (measured on MI355X at this size: scores 4 % of their range, the patch-embedding gradient cosine 0.987, whole-model cosine 0.9994).  Gates: 8e-2 on the scores
-    # (next comment); every parameter within 25 % of max(own norm, 1 % of the largest), large parameters cosine >= 0.98, whole model >= 0.999
+    # one token to another (measured on MI355X at this size: scores 4 % of their range, the patch-embedding gradient cosine 0.987, whole-model cosine 0.9992).  Gates: 8e-2 on the scores
+    # (next comment); every parameter within 25 % of max(own norm, 1 % of the largest), large parameters cosine >= 0.98, whole model >= 0.998 (measured 0.99920 / 0.99995)
     # (scores: the ORACLE under torch's bf16 autocast is itself 2.1 % (vtp8t) / 3.0 % (dmae12) of the score range away from its fp32 self on these batches; this build, whose
     # residual stream through the 4 temporal layers is bf16 as well, 5.4 % / 4.0 %: gate 8 %)
     if rep["l3_simi_max_abs"] > 8e-2 * rep["l3_simi_ref_absmax"]:
         gates.append("l3_simi")
-    gates += grad_gates(rep["grads"], max_err=0.25, min_cos=0.98)
+    gates += grad_gates(rep["grads"], max_err=0.25, min_cos=0.98, min_global=0.998)
     return rep, gates
 
 

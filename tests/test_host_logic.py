@@ -140,6 +140,26 @@ def test_product_kernel_resources():
     assert set(by) <= lab and any(n.startswith("attn_fwd32_kernel") for n in lab)
 
 
+def test_k64r_isa_audit(tmp_path):
+    """tools/k64r_audit.py over the ISA hipcc emits for csrc/gemm.hip TODAY (device-only -S, ~1 min): the rolling-epilogue kernel's residual vectors are loaded by inline
+    asm into registers hipcc believes already written -- any instruction that touches one of them between its load and the counted `s_waitcnt vmcnt(N)` that retires it is
+    silent data corruption on hardware that neither the emulator nor a lucky GPU run shows.  Also: no scratch, no v_accvgpr moves in the four product instantiations."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "gemm_dev.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-S", "--cuda-device-only",
+                           os.path.join(PKG, "csrc", "gemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k64r_audit.py"), str(out)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("k64r<")]
+    assert len(lines) == 4 and all("problems 0" in ln or "no residual loads" in ln for ln in lines), p.stdout
+    assert sum("loads 28 problems 0" in ln for ln in lines) == 2, p.stdout    # the two residual instantiations were really audited
+
+
 def test_hip_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
     from antmmf.hip import _lib, ops
 
