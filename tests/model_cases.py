@@ -512,6 +512,44 @@ def case_univl_moco(dev, golden, with_optimizer=False):
     return res
 
 
+def case_univl_stage2_loss_contract(dev, k=6):
+    """The 1e-3 loss contract on the stage-2 (cross-encoder) step over k seeded batches against the oracle (pinned to the reference's stage-2 run, e2e_clip_stage2.pt): mean
+    relative deviation of the level-1 and of the level-2 loss <= 1e-3; every single batch at the single-batch gates of case_univl_stage2 (1e-3 / 2e-3)."""
+    import roi_univl  # noqa: F401
+    from antmmf.common.configuration import Configuration
+    from oracle import step as ostep
+    from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
+
+    model = UnivlForVideoTextRetrieval(Configuration(dict(TINY_CLIP_CFG, training_stage="stage1+stage2", with_cross_encoder=True)))
+    W.fill_module_(model)
+    model = model.to(dev).train()
+    model.dropout.p = 0.0
+    P = tiny_models.clip_arch_params(stage2=True)
+    bsz, n_clips, rel1, rel2 = 4, 2, [], []
+    for b in range(k):
+        img = W.data_tensor(f"s2k.image.{b}", (bsz, n_clips, 3, 32, 32))
+        lengths = W.data_ints(f"s2k.len.{b}", (bsz,), 3, 13)
+        mask = (torch.arange(12)[None, :] < lengths[:, None]).long()
+        ids = W.data_ints(f"s2k.ids.{b}", (bsz, 12), 1, 300) * mask
+        ids[:, 0] = 101
+        with torch.no_grad():
+            out = model(dict(image_data=img.to(dev), image_pad_mask=torch.zeros(bsz, n_clips, 32, 32, dtype=torch.bool, device=dev), image_n_clips=[n_clips] * bsz,
+                             image_num_frames=[1] * bsz), dict(caption_input_ids=ids.to(dev), caption_input_mask=mask.to(dev), caption_raw_input_ids=ids.to(dev)))
+            r1 = float(ostep.univl_stage1(P, img, ids, mask, n_clips, 2, 8, 2)["loss"])
+            r2 = float(ostep.univl_stage2(P, img, ids, mask, n_clips, 2, 8, 2)["loss"])
+        rel1.append((float(out["losses"]["level1_similarity_loss"]) - r1) / abs(r1))
+        rel2.append((float(out["losses"]["level2_similarity_loss"]) - r2) / abs(r2))
+    m1, m2 = sum(rel1) / k, sum(rel2) / k
+    if os.environ.get("ANTMMF_REAL_WIDTH_OUT"):
+        import json
+
+        with open(os.environ["ANTMMF_REAL_WIDTH_OUT"], "a") as f:
+            f.write(json.dumps(dict(case="stage2_loss_contract", level1_rel=rel1, level2_rel=rel2, mean=[m1, m2])) + "\n")
+    assert abs(m1) <= 1e-3 and max(abs(r) for r in rel1) <= 1e-3, (m1, rel1)
+    assert abs(m2) <= 1e-3 and max(abs(r) for r in rel2) <= 2e-3, (m2, rel2)
+    return dict(mean=(m1, m2), level2_rel=rel2)
+
+
 def case_univl_moco_loss_contract(dev, k=6):
     """north_star's "loss within 1e-3 rel" tested on what it states instead of on one batch's noise floor: the MoCo step's loss on k seeded
     batches against the oracle (pinned to the reference's MoCo run at 1e-5, tests/test_oracle_golden.py) -- the MEAN relative deviation must meet the contract,

@@ -88,6 +88,10 @@ def test_univl_moco_loss_contract_over_seeded_batches():
     print(mc.case_univl_moco_loss_contract(DEV))
 
 
+def test_univl_stage2_loss_contract_over_seeded_batches():
+    print(mc.case_univl_stage2_loss_contract(DEV))
+
+
 def test_dmae_stage3_with_tpmcl_vs_reference():
     import subprocess
     import sys

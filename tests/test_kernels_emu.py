@@ -189,18 +189,18 @@ def test_gemm_k64_rolling_epilogue():
 
 
 def test_gemm_k64_tail_round_cells():
-    """The tail round of the persistent NT kernel as CELLS inside the same launch (gemm_nt_k64r_kernel): 72 tiles on a 32-workgroup grid = two full rounds of the tile walk
-    + ONE leftover tile per XCD chunk, whose 16 cells (one phase x one Q fragment per wave, full K range) go to the chunk's four workgroups, four cells each (variant bit
+    """The tail round of the persistent NT kernel as CELLS inside the same launch (gemm_nt_k64r_kernel): 40 tiles on a 16-workgroup grid = two full rounds of the tile walk
+    + ONE leftover tile per XCD chunk, whose 16 cells (one phase x one Q fragment per wave, full K range) go to the chunk's two workgroups, eight cells each (variant bit
     26 lifts the product's one-cell-per-workgroup rule for this small grid).  K = 256 (4 K-tiles: shorter than the cell ring's depth) and K = 768 (12: the 8-slot ring
     wraps).  Against the fp32 product on every tile, and BIT-IDENTICAL to the same call with the cells disabled (variant bit 25: the leftover tiles go through the walk):
     the cells start their accumulators from bias + residual and add the K-tiles in the walk's order."""
     import sys
 
     code = ("import os, sys, ctypes, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_GEMM_FORCE_TILE'] = 'k';"
-            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '32'; os.environ['ANTMMF_GEMM_VARIANT'] = str(4 | (1 << 26));"
+            "os.environ['ANTMMF_GEMM_PERSIST_WGS'] = '16'; os.environ['ANTMMF_GEMM_VARIANT'] = str(4 | (1 << 26));"
             "import kernel_cases as kc; from antmmf.hip import ops, _lib; lib = _lib.load(); lib.antmmf_debug_gemm_cell_launches.restype = ctypes.c_long;"
             "g = torch.Generator().manual_seed(11);"
-            "cases = [(4608, 1024, 256, True, True), (4608, 1024, 768, False, False)] + ([(4608, 1024, 768, True, False)] if os.environ.get('ANTMMF_SLOW_TESTS') else []);"
+            "cases = [(2560, 1024, 256, True, True), (2560, 1024, 768, False, False)] + ([(4608, 1024, 768, True, False)] if os.environ.get('ANTMMF_SLOW_TESTS') else []);"
             "\nfor I, J, R, wb, wr in cases:\n"
             "    X = torch.randn(I, R, generator=g).bfloat16(); W = (torch.randn(J, R, generator=g) * 0.06).bfloat16()\n"
             "    b = torch.randn(J, generator=g) if wb else None; r = (torch.randn(I, J, generator=g) * 3).bfloat16() if wr else None\n"
