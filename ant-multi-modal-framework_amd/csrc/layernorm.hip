@@ -62,7 +62,11 @@ template <> struct raw8<float> {
 // BLOCK = false: wave per row, lane handles vectors lane + 64 i.  BLOCK = true: workgroup per row, thread handles vectors tid + 256 i.
 // Both walk rows with a grid stride and keep the next row's loads in flight while the current one is reduced.  All per-element
 // arithmetic is on f2_t (two elements per lane per VALU slot).
-template <typename T, int VPL, bool BLOCK, int ACT>
+// ADJ (wave-per-row form, LAB library only): a wave owns two ADJACENT rows (4 KB of contiguous input for 1024 bf16 columns), requests both up front and never loops.  On the
+// bare probe kernel of tools/stream_probe.hip that shape runs at 5.94 TB/s against 5.58 for one row per wave; in THIS kernel (statistics written, gamma / beta read per row)
+// it measured 4 - 9 % SLOWER than one row per wave (profiles/r5_ln_fwd_adjacent_rows_ab.jsonl: 0.200 vs 0.192 ms on 263168 rows, 0.0686 vs 0.0624 on 78848), like two
+// far-apart rows through the grid-stride prefetch (r5_ln_fwd_rows_per_wave_ab.jsonl): the product launches one row per wave
+template <typename T, int VPL, bool BLOCK, int ACT, bool ADJ = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -73,8 +77,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int nvec = cols >> 3;
     const int v0 = BLOCK ? threadIdx.x : lane, vstep = BLOCK ? 256 : 64;
     const float inv_n = 1.0f / (float)cols;
-    const long rstep = BLOCK ? (long)gridDim.x : (long)gridDim.x * 4;
-    long row = BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave;
+    const long rstep = ADJ ? 1L : (BLOCK ? (long)gridDim.x : (long)gridDim.x * 4);
+    long row = ADJ ? ((long)blockIdx.x * 4 + wave) * 2 : (BLOCK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave);
     // two rows in flight ahead of the one being reduced (BLOCK: 8 VGPRs per row and thread): nxa / nxb alternate
     raw8<T> nxa[VPL], nxb[VPL];
     auto fetch = [&](raw8<T> (&nx)[VPL], long r) {
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 for (int e = 0; e < 4; ++e) v[i][e] = f2_splat(0.f);
             }
         }
-        if (row + 2 * rstep < rows) fetch(nx, row + 2 * rstep);
+        if (!ADJ && row + 2 * rstep < rows) fetch(nx, row + 2 * rstep);
         f2_t s2 = f2_splat(0.f);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -132,6 +136,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     };
     if (row < rows) fetch(nxa, row);
     if (row + rstep < rows) fetch(nxb, row + rstep);
+    if (ADJ) {   // exactly this pair
+        if (row < rows) body(nxa, row);
+        if (row + 1 < rows) body(nxb, row + 1);
+        return;
+    }
     for (; row < rows; row += 2 * rstep) {
         body(nxa, row);
         if (row + rstep < rows) body(nxb, row + rstep);
@@ -366,6 +375,10 @@ static int ln_fwd_launch(const void* x, const float* g, const float* b, void* y,
     const long want_w = (rows + 4L * rpw - 1) / (4L * rpw);
     const int gw = (int)(want_w < grid_cap ? want_w : grid_cap), gb = (int)(rows < grid_cap ? rows : grid_cap);
     if (nvec <= 64) LN_FWD(1, false, gw);
+#ifdef ANTMMF_LAB
+    else if (nvec <= 128 && ANTMMF_LAB_ENV("ANTMMF_LN_FWD_ADJ") && ANTMMF_LAB_ENV("ANTMMF_LN_FWD_ADJ")[0] == '1' && act == ANTMMF_ACT_NONE && rows >= 256 && (rows + 7) / 8 <= grid_cap)
+        hipLaunchKernelGGL((ln_fwd_kernel<T, 2, false, ANTMMF_ACT_NONE, true>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, cols, eps, act);   // A/B only
+#endif
     else if (nvec <= 128) LN_FWD(2, false, gw);
     else if (nvec <= 256) LN_FWD(1, true, gb);
     else if (nvec <= 512) {
