@@ -1549,7 +1549,11 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 //     8-slot ring laid over the quarter regions of the two stages (a slot is refilled two barriers after its last read).
 // Requires what gemm_nt_k64p_kernel requires, and R >= 192 (three K-tile roles).  EPI: bit 0 bias, bit 1 residual; 5 = bias + activation with TWO outputs (the
 // activation -> C, its derivative or the pre-activation -> aux: the forward of a feed-forward whose activation output is kept for backward; g.act at run time);
-// 21 = the same plus per-row (sum z, sum z^2) of the rounded activation over the wave's 64 columns -> g.part (fc1 of the sub-LN fold, GemmArgs::ffn_mode 1).
+// 21 = the same plus per-row (sum z, sum z^2) of the rounded activation over the wave's 64 columns -> g.part (fc1 of the sub-LN fold, GemmArgs::ffn_mode 1);
+// 8 = out = acc * gate (the dgrad through an activation whose derivative the forward stored, gate_grad; round 5): the gate vectors of row quarter q are requested ONE phase
+// before that quarter is stored (quarter 0 in phase 0 of the last K-tile, quarter q + 1 right behind the store of quarter q), in the store layout like the residual vectors,
+// taken back to the fragment layout and multiplied into the accumulators right in front of the conversion -- one quarter's vectors (16 VGPRs) are alive at a time (two phases
+// of lead = two quarters in flight put the kernel at 256 VGPRs + 24 B of scratch).
 #ifdef ANTMMF_EMULATE
 #define K64R_GLOAD16(dst, voff, sbase, OFF) dst = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sbase) + (voff) + (OFF))
 #define K64R_GSTORE16(voff, val, sbase, OFF) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(sbase) + (voff) + (OFF)) = (val)
@@ -1582,6 +1586,9 @@ template <> struct K64RWaits<2> { static constexpr int W[3][4] = {{40, 41, 42, 1
 template <> struct K64RWaits<21> { static constexpr int W[3][4] = {{49, 49, 50, 7}, {8, 9, 10, 7}, {9, 20, 31, 38}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 48; };   // 8 stores + 2 row-sum stores per quarter
 template <> struct K64RWaits<5> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };
 template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
+// EPI 8 (out = acc * gate, round 5): INIT[q] = the wait in front of the multiplication of row quarter q by its gate vectors, requested one phase earlier (only the two DMA
+// pieces of the phase in between are younger; tools/k64r_ladder.py ladder_gate)
+template <> struct K64RWaits<8> { static constexpr int W[3][4] = {{40, 37, 38, 7}, {8, 9, 10, 7}, {12, 21, 30, 35}}; static constexpr int INIT[4] = {2, 2, 2, 2}; static constexpr int BIASW = 0; };
 
 // ABL 8 (timing only, EPI 0, R = 1024): every K-tile stores ONE 16-row x 32-column block of the tile (out of the running sums: wrong values, right bytes,
 // addresses and instruction count) in phase 1, nothing at the tile boundary: what a kernel whose rows finish at staggered K positions would pay for its stores.
@@ -1599,8 +1606,10 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     ANTMMF_DYN_LDS(char, smem);
     constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
     constexpr int STAGE = 65536, QOFF = 32768, BIASOFF = 2 * STAGE;
-    constexpr bool BIAS = EPI & 1, RES = (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
+    constexpr bool GATE = EPI == 8, BIAS = !GATE && (EPI & 1), RES = !GATE && (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
     using WT = K64RWaits<EPI>;
+    const bf16_t* const rsrc = GATE ? g.gate : g.residual;   // what the "residual" vector loads fetch: the residual tile, or the gate tile
+    const long rld = GATE ? g.ldgate : g.ldr;
     const int lane = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
@@ -1694,7 +1703,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     const int trow = l15 & 14, tchunk = ((lane >> 4) & 1) * 4 + (lane >> 5) * 2 + (lane & 1);
     const uint32_t cvoff_t0 = (uint32_t)((trow * (int)g.ldc + tchunk * 8) * 2), cvoff_t1 = cvoff_t0 + (uint32_t)((int)g.ldc * 2);
     const uint32_t avoff_t0 = ACT2 ? (uint32_t)((trow * (int)g.ldaux + tchunk * 8) * 2) : 0u, avoff_t1 = avoff_t0 + (ACT2 ? (uint32_t)((int)g.ldaux * 2) : 0u);
-    const uint32_t rvoff_t0 = RES ? (uint32_t)((trow * (int)g.ldr + tchunk * 8) * 2) : 0u, rvoff_t1 = rvoff_t0 + (RES ? (uint32_t)((int)g.ldr * 2) : 0u);
+    const uint32_t rvoff_t0 = (RES || GATE) ? (uint32_t)((trow * (int)rld + tchunk * 8) * 2) : 0u, rvoff_t1 = rvoff_t0 + ((RES || GATE) ? (uint32_t)((int)rld * 2) : 0u);
     (void)cvoff_t0; (void)cvoff_t1; (void)avoff_t0; (void)avoff_t1; (void)rvoff_t0; (void)rvoff_t1;
     // (ABL 64, timing only: every store instruction writes 8 rows x 128 B -- eight FULL cache lines -- instead of 16 rows x 64 B; same bytes per tile, data in the wrong places)
     const uint32_t cvoff_fl0 = (uint32_t)(((lane >> 3) * (int)g.ldc + (lane & 7) * 8) * 2), cvoff_fl1 = cvoff_fl0 + (uint32_t)(8 * (int)g.ldc * 2);
@@ -1703,7 +1712,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     const uint32_t cvoff_p32 = (uint32_t)((((lane >> 1) & 7) * (int)g.ldc + (2 * (lane >> 4) + (lane & 1)) * 8) * 2), cvoff_p32b = cvoff_p32 + (uint32_t)(8 * (int)g.ldc * 2);
     const uint32_t cvoff_p64 = (uint32_t)(((lane >> 2) * (int)g.ldc + (lane & 3) * 8) * 2);
     (void)cvoff_p32; (void)cvoff_p32b; (void)cvoff_p64;
-    const uint32_t rvoff = RES ? (uint32_t)((l15 * (int)g.ldr + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
+    const uint32_t rvoff = (RES || GATE) ? (uint32_t)((l15 * (int)rld + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const uint32_t avoff = ACT2 ? (uint32_t)((l15 * (int)g.ldaux + (lane >> 5) * 16 + (grp & 1) * 8) * 2) : 0u;
     const int pbg = ((grp & 1) << 1) | (grp >> 1);
     u32x4_t rv[4][4] = {};   // residual vectors of row quarter q, in flight between the store of the previous tile's quarter q and this tile's phase q
@@ -1712,7 +1721,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #define K64R_RESLOAD(QQ, ti0, tj0)                                                                                                  \
     do {                                                                                                                            \
         _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
-            const char* rb = reinterpret_cast<const char*>(g.residual) + ((long)((ti0) + wi * 128 + (2 * (QQ) + ih) * 16) * g.ldr + (tj0) + wj * 64) * 2; \
+            const char* rb = reinterpret_cast<const char*>(rsrc) + ((long)((ti0) + wi * 128 + (2 * (QQ) + ih) * 16) * rld + (tj0) + wj * 64) * 2; \
             if (ABL & 128) { K64R_GLOAD16(rv[QQ][2 * ih], rvoff, rb, 0); K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff, rb, 64); }        \
             else { K64R_GLOAD16(rv[QQ][2 * ih], rvoff_t0, rb, 0); K64R_GLOAD16(rv[QQ][2 * ih + 1], rvoff_t1, rb, 0); }              \
         }                                                                                                                           \
@@ -1840,6 +1849,29 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
             }                                                                                                                       \
         }                                                                                                                           \
     } while (0)
+    // accumulators of row quarter QQ *= gate (vectors in the store layout -> row layout -> fragment layout, exactly as K64R_INIT takes the residual back)
+#define K64R_GATEMUL(QQ)                                                                                                            \
+    do {                                                                                                                            \
+        K64R_VMFENCE4(WT::INIT[QQ], rv[QQ]);                                                                                        \
+        _Pragma("unroll") for (int ih = 0; ih < 2; ++ih) {                                                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                         \
+                uint32_t xa = rv[QQ][2 * ih][e], xb = rv[QQ][2 * ih + 1][e];                                                        \
+                lane_bit_exchange<0>(xa, xb, lane); lane_bit_exchange<4>(xa, xb, lane);                                             \
+                rv[QQ][2 * ih][e] = xa; rv[QQ][2 * ih + 1][e] = xb;                                                                 \
+            }                                                                                                                       \
+            _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                      \
+                const u32x4_t w = rv[QQ][2 * ih + p2];                                                                              \
+                _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                                                  \
+                    const uint32_t lo = w[rr >> 1], hi = w[2 + (rr >> 1)];                                                          \
+                    const float flo = (rr & 1) ? bf_hi(lo) : bf_lo(lo), fhi = (rr & 1) ? bf_hi(hi) : bf_lo(hi);                     \
+                    const k64_u2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(flo), __float_as_uint(fhi), false, false); \
+                    acc[2 * (QQ) + ih][2 * p2][rr] *= __uint_as_float(sw[0]);                                                       \
+                    acc[2 * (QQ) + ih][2 * p2 + 1][rr] *= __uint_as_float(sw[1]);                                                   \
+                }                                                                                                                   \
+                SCHED_FENCE();                                                                                                      \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    } while (0)
 #define K64R_PIECE(IDX)                                                                                                             \
     do {                                                                                                                            \
         int kk = t + (IDX < 4 ? 1 : 2);                                                                                             \
@@ -1907,7 +1939,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #define K64R_HOOK(ROLE, PH)                                                                                                         \
     do {                                                                                                                            \
         if (ROLE == 0 && PH == 0) {                                                                                                 \
-            if (pending) K64R_EPIQ(3, ei0, ej0);                                                                                    \
+            if (pending) { if (GATE) K64R_GATEMUL(3); K64R_EPIQ(3, ei0, ej0); }                                                     \
             if (RES) K64R_RESLOAD(3, i0, j0);                                                                                       \
             if (BIAS) {                                                                                                             \
                 if (!RES) K64R_VMWAIT(WT::BIASW);   /* with a residual the wait in front of K64R_INIT(0) is the stronger one */      \
@@ -1919,7 +1951,13 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         }                                                                                                                           \
         if (ROLE == 0 && RES) K64R_INIT(PH);                                                                                        \
         if (ROLE == 2 && PH == 0 && BIAS) dma_bias(nj0);                                                                            \
-        if (ROLE == 2 && PH >= 1) { K64R_EPIQ(PH - 1, i0, j0); if (RES) K64R_RESLOAD(PH - 1, ni0, nj0); }             \
+        if (GATE && ROLE == 2 && PH == 0) K64R_RESLOAD(0, i0, j0);                                                                  \
+        if (ROLE == 2 && PH >= 1) {                                                                                                 \
+            if (GATE) K64R_GATEMUL(PH - 1);                                                                                         \
+            K64R_EPIQ(PH - 1, i0, j0);                                                                                              \
+            if (RES) K64R_RESLOAD(PH - 1, ni0, nj0);                                                                                \
+            if (GATE) K64R_RESLOAD(PH, i0, j0);                                                                                     \
+        }                                                                                                                           \
         if ((ABL & 8) && PH == 1) K64R_SPREAD_STORE(ROLE);                                                                              \
     } while (0)
 #define K64R_PHASE(ROLE, PH)                                                                                                        \
@@ -1959,6 +1997,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     if (RES) { K64R_VMFENCE4(0, rv[0]); K64R_VMFENCE4(0, rv[1]); K64R_VMFENCE4(0, rv[2]); }
     glds_wait_all();
     SCHED_FENCE();
+    if (GATE) K64R_GATEMUL(3);   // (its wait allows 2 younger operations: none are in flight any more)
     if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
     if (tail_r > 0 && lx < 16 * tail_r) {
         // ---- leftover tiles as cells.  Cell c of the chunk = tile c >> 4, phase (c >> 2) & 3, Q fragment c & 3: per wave 2 P fragments (rows wi 128 + 32 ph + [0, 32)) x 1 Q
@@ -2041,6 +2080,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #undef K64R_READS
 #undef K64R_PIECE
 #undef K64R_INIT
+#undef K64R_GATEMUL
 #undef K64R_EPIQ
 #undef K64R_RESLOAD
 }
@@ -2558,6 +2598,14 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             ++g_k64_launches;
             const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);
             const unsigned gridp = pwgs < t8 ? pwgs : t8;
+            // round 5: on the rolling-epilogue kernel (gate vectors requested two phases ahead of each row quarter's store, multiplied into the accumulators in front of the
+            // conversion); the burst form with all 16 gate vectors up front stays for R < 192 and, in the lab library, as the A/B (variant bit 14)
+            if (R >= 192 && !(g_gemm_variant & 16384)) {
+                static bool once8 = false;
+                if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once8 = true; }
+                g.tail_cells = 0;
+                hipLaunchKernelGGL((gemm_nt_k64r_kernel<8, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+            } else
             K64P_LAUNCH(8, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
         } else
         switch (epi) {

@@ -18,7 +18,7 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def audit(lines, name):
+def audit(lines, name, gate=False):
     K = [l.strip() for l in lines]
     # instructions written by the kernel's inline asm sit between ;;#ASMSTART / ;;#ASMEND: the residual loads under audit are those (round 5: the cell tail behind the
     # walk adds compiler-generated loads of its own -- a bias vector, 8-byte residual pieces -- which hipcc tracks itself)
@@ -47,10 +47,14 @@ def audit(lines, name):
     back = [(i, labels[m.group(1)]) for i, l in enumerate(text) for m in [re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)] if m and m.group(1) in labels and labels[m.group(1)] < i]
     tile_back = max(back, key=lambda p: p[0] - p[1])   # the widest backward branch = the tile loop
     end_i, head_i = tile_back
-    assert len(loads) == 28, (name, len(loads))   # 12 prologue + 4 (T0) + 12 (TE)
-    groups = [("prologue q%d" % q, loads[4 * q:4 * q + 4], 0, False) for q in range(3)]
-    groups.append(("T0 q3", loads[12:16], INIT[3], False))
-    groups += [("TE q%d" % q, loads[16 + 4 * q:20 + 4 * q], INIT[q], True) for q in range(3)]
+    if gate:   # EPI 8: 16 gate loads in the last K-tile (quarter q one phase ahead of its store), each retired by vmcnt(2); quarter 3 is consumed behind the back edge
+        assert len(loads) == 16, (name, len(loads))
+        groups = [("TE gate q%d" % q, loads[4 * q:4 * q + 4], 2, q == 3) for q in range(4)]
+    else:
+        assert len(loads) == 28, (name, len(loads))   # 12 prologue + 4 (T0) + 12 (TE)
+        groups = [("prologue q%d" % q, loads[4 * q:4 * q + 4], 0, False) for q in range(3)]
+        groups.append(("T0 q3", loads[12:16], INIT[3], False))
+        groups += [("TE q%d" % q, loads[16 + 4 * q:20 + 4 * q], INIT[q], True) for q in range(3)]
     for tag, idxs, n, wraps in groups:
         dest = set()
         for i in idxs:
@@ -88,10 +92,10 @@ def audit(lines, name):
 if __name__ == "__main__":
     S = open(sys.argv[1]).read().split("\n")
     total = 0
-    for e in range(4):
+    for e in (0, 1, 2, 3, 8):
         st = [i for i, l in enumerate(S) if l.startswith("_Z19gemm_nt_k64r_kernelILi%dE" % e)]
         if not st:
             continue
         en = [i for i, l in enumerate(S) if i > st[0] and ".amdhsa_kernel" in l][0]
-        total += audit(S[st[0]:en], "k64r<%d>" % e)
+        total += audit(S[st[0]:en], "k64r<%d>" % e, gate=(e == 8))
     sys.exit(1 if total else 0)

@@ -52,6 +52,47 @@ def ladder(res, bias, nks=(3, 4, 5, 6, 9), tiles=3, stores=4):
     return waits, inits, biasw
 
 
+def ladder_gate(nks=(3, 4, 5, 6, 9), tiles=3, stores=4):
+    """EPI 8 (out = acc * gate, round 5): no bias, no residual.  The gate vectors of row quarter q (4 loads) are requested ONE phase before the store of that quarter, into
+    the registers the previous quarter's vectors have just left (two quarters in flight -- two phases of lead -- put the kernel at 256 VGPRs + 24 B of scratch):
+        TE ph 0: gate loads q0
+        TE ph q + 1 (q = 0 .. 2): [wait q] multiply + 4 stores q, gate loads q + 1
+        T0 ph 0 of the next tile: [wait q3] multiply + 4 stores q3
+    Returns W[(role, ph)] and GINIT[q] = operations issued behind quarter q's last gate load at the point where it is consumed."""
+    waits, ginit = {}, {}
+    for nk in nks:
+        ops, pos, gl = [], {}, {}
+
+        def role(t):
+            return "T0" if t == 0 else ("TE" if t == nk - 1 else "TR")
+        gt = 0
+        for tile in range(tiles):
+            for t in range(nk):
+                k = role(t)
+                for ph in range(4):
+                    for idx in (2 * ph, 2 * ph + 1):
+                        pos[(gt, idx)] = len(ops); ops.append("piece")
+
+                    def consume(q, tl):
+                        if (tl, q) in gl:
+                            ginit[q] = min(ginit.get(q, 99), len(ops) - 1 - gl[(tl, q)])
+
+                    def load(q, tl):
+                        ops.extend(["gateload"] * 4); gl[(tl, q)] = len(ops) - 1
+                    if k == "T0" and ph == 0 and tile > 0:
+                        consume(3, tile - 1); ops.extend(["store"] * stores)
+                    if k == "TE":
+                        if ph == 0:
+                            load(0, tile)
+                        else:
+                            consume(ph - 1, tile); ops.extend(["store"] * stores); load(ph, tile)
+                    need = {0: (gt - 1, 1), 1: (gt - 1, 2), 2: (gt - 1, 3), 3: (gt, 0)}[ph]
+                    if need in pos:
+                        waits[(k, ph)] = min(waits.get((k, ph), 99), len(ops) - 1 - pos[need])
+                gt += 1
+    return waits, ginit
+
+
 if __name__ == "__main__":
     for (res, bias) in ((0, 0), (0, 1), (1, 0), (1, 1)):
         w, i, b = ladder(res, bias)
@@ -63,3 +104,7 @@ if __name__ == "__main__":
     print("EPI=5 (bias + activation, two outputs: 8 stores per row quarter)")
     print("   W = {" + ", ".join("{" + ", ".join(str(w[(k, ph)]) for ph in range(4)) + "}" for k in ("T0", "TR", "TE")) + "}   (T0, TR, TE)")
     print("   BIASW = %d" % b["T0"])
+    w, gi = ladder_gate()
+    print("EPI=8 (gate: out = acc * gate)")
+    print("   W = {" + ", ".join("{" + ", ".join(str(w[(k, ph)]) for ph in range(4)) + "}" for k in ("T0", "TR", "TE")) + "}   (T0, TR, TE)")
+    print("   GINIT = {%s}" % ", ".join(str(gi[q]) for q in range(4)))
