@@ -85,7 +85,7 @@ _LAB_SIGNATURES = {
     "antmmf_ffn_wgrad_post": [P, P, P, P, P, P, P, P, P, I, I, P],
     "antmmf_debug_set_gemm_variant": [I],
 }
-_LAB_PROBES = ("antmmf_debug_gemm_cell_launches",)   # read-only counters of the lab build (restype long; bound by the tests that read them)
+_LAB_PROBES = ("antmmf_debug_gemm_cell_launches", "antmmf_debug_attn_fused_launches")   # read-only counters of the lab build (restype long; bound by the tests that read them)
 LAB_LIB = os.path.join(os.path.dirname(DEFAULT_LIB), "libantmmf_hip_lab.so")
 
 

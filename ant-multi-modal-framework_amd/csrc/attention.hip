@@ -825,6 +825,269 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
     }
 }
 
+// ---- backward in ONE kernel (head size 64, 128 < Nk <= 272, no dropout: the 257-token image towers) -----------------------------------------------------
+// Why: at these lengths the backward is closer to its HBM floor than to the MFMA peak -- the two kernels above read Q, K, V, dO, O TWICE and form the
+// scores, dP and the exponentials twice (13 tensor passes, 14 flop units, 2 exponentials per score); one kernel needs 8 passes, 10 units, 1 exponential.
+// How: a workgroup owns one (b, h) with Q, dO AND K token tiles resident in LDS.  Wave w owns the key tiles w and w + 8 (dK / dV accumulators in registers
+// for the whole kernel, as in attn_bwd_dkv_kernel) and walks the queries in 32-query chunks; per chunk it forms S, dP, P, dS for its 32 keys ONCE, feeds
+// dV / dK, and leaves dS^T (bf16) in a double-buffered LDS tile [key][32 queries].  After ONE workgroup barrier per chunk the eight waves each
+// contract one 16 x 16 tile of that chunk's dQ^T (head-dim tile w & 3, query tile w >> 2) over ALL keys straight out of that tile (transposing LDS reads)
+// and store it: dQ is never accumulated across waves -- no atomics, no fp32 dQ buffer, a fixed summation order (bit-reproducible).
+// The 17th key tile of the 257-token towers (ONE valid key) belongs to no wave: before the main loop its score blocks are spread over the waves by chunk
+// (P and dS^T for that tile go to LDS), then waves 0 - 3 contract dV and waves 4 - 7 dK of that tile, one head-dim tile each, over all queries -- again
+// no cross-wave sums.  Its dS^T stays in LDS as the ninth key slice of every chunk's dQ contraction.
+// LDS: (2 NQP + 288) x 128 B token tiles + 2 x 16 KB dS^T + 1 KB per chunk for the extra tile + 8 NQP B row statistics = 151 KB at 257 x 257: one
+// workgroup (8 waves, up to 256 VGPRs each) per CU.
+// dS^T tile: key rows of 64 B (32 queries), 8-B slot s = 4 * (query tile) + (4-query group), XOR-swizzled so that both the 8-B row writes of a score block
+// (16 consecutive keys x one slot) and the transposing reads (8 consecutive keys x 4 slots of one query tile) sweep all banks.
+__device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
+__device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
+static inline size_t attn_fused_lds_bytes(int Nq, int Nk) {
+    const int nqp = ((Nq + 31) / 32) * 32;
+    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
+}
+static inline bool attn_fused_ok(const AttnArgs& a) {
+    return !a.drop_thr && a.Nk > 128 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;
+}
+
+// one score block: 16 queries (tile at q0) x the 16 keys of (kf, vf): p = softmax probabilities, ds = p * (dP - D).  Lane: key l15, queries q0 + 4 grp + r.
+#define FUSED_SCORE_BLOCK(KF, VF, KBIAS, P, DSV)                                                              \
+    do {                                                                                                      \
+        f32x4_t sa_ = {l4.x, l4.y, l4.z, l4.w}, da_ = {d4.x, d4.y, d4.z, d4.w};                               \
+        sa_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, (KF)[0], sa_, 0, 0, 0);                            \
+        sa_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, (KF)[1], sa_, 0, 0, 0);                            \
+        da_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa0, (VF)[0], da_, 0, 0, 0);                            \
+        da_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa1, (VF)[1], da_, 0, 0, 0);                            \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                    \
+            const float pr_ = FUSED_EXP(__builtin_fmaf(sa_[r_], scale2, (KBIAS)));                            \
+            (P)[r_] = pr_;                                                                                    \
+            (DSV)[r_] = pr_ * da_[r_];                                                                        \
+        }                                                                                                     \
+    } while (0)
+
+// NKS: 32-key slices of the resident key tiles (compile time: the dQ contraction is straight-line code); HASE: a 17th key tile exists; FULL: all sixteen resident
+// tiles exist (no per-wave validity tests); NQC: number of query chunks when known at compile time (the extra tile's contraction), 0 = run-time loop.
+// ABL (lab library only, TIMING-ONLY, wrong results): 1 no dQ contraction, 2 no per-chunk barrier, 4 the exponential replaced by its argument, 8 no dV / dK contraction,
+// 16 no D = rowsum(dO o O) pass in the prologue, 32 no extra key tile -- what each part of the kernel costs, same box, same process.
+template <int NKS, bool HASE, bool FULL, int NQC, int ABL = 0>
+__global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const AttnArgs a, int NQP) {
+    ANTMMF_DYN_LDS(char, smem);
+    const int nkt = (a.Nk + 15) >> 4, nkr = nkt < 16 ? nkt : 16, nqc = NQC ? NQC : NQP >> 5;   // key tiles, resident key tiles, query chunks
+    char* Qs = smem;
+    char* Ds = Qs + NQP * 128;
+    char* Ks = Ds + NQP * 128;
+    char* Sb = Ks + 288 * 128;
+    char* Se = Sb + 2 * 16384;
+    float* lse_s = reinterpret_cast<float*>(Se + (HASE ? nqc * 1024 : 0));
+    float* dsum_s = lse_s + NQP;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, grp = lane >> 4;
+#ifdef ANTMMF_EMULATE
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: everything decided per wave below is a uniform branch, not an exec mask
+#endif
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * 64;
+    const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * 64;
+    const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
+    stage_rows2<64, 288>(Qs, qbase, a.ldq, Ds, dobase, a.lddo, a.Nq, NQP);
+    stage_rows<64, 288>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, 288);
+    for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {   // (as attn_bwd_dkv_kernel: both negated, accumulator start values; padding queries: p = 0)
+        float d = 0.f, l = INFINITY;
+        if (i < a.Nq) {
+            l = a.lse[((long)b * a.heads + h) * a.Nq + i];
+            l = l == -INFINITY ? INFINITY : l / a.scale;
+            if constexpr (!(ABL & 16)) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    float x[8], y[8];
+                    ld8<bf16_t>(dobase + (long)i * a.lddo + v * 8, x);
+                    ld8<bf16_t>(obase + (long)i * a.ldo + v * 8, y);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += x[e] * y[e];
+                }
+            }
+        }
+        lse_s[i] = -l;
+        dsum_s[i] = -d;
+    }
+    __syncthreads();
+
+#define FUSED_EXP(x) ((ABL & 4) ? (x) : EXP2F(x))
+    const float scale2 = a.scale * LOG2E;
+    const bool dkv_al16 = !(a.lddk & 7) && !(a.lddv & 7) && !((uintptr_t)a.dk & 15) && !((uintptr_t)a.dv & 15);
+
+    // ---- the key tile beyond the sixteen resident ones
+    if constexpr (HASE && !(ABL & 32)) {
+        char* Pe = Sb;   // (the dS^T double buffer is free until the main loop)
+        const int ki = 256 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
+        const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
+        const bf16x8_t kfE[2] = {frag_rows<64>(Ks, 256 + l15, grp), frag_rows<64>(Ks, 256 + l15, 4 + grp)};
+        const bf16x8_t vfE[2] = {load_frag_global(vp), load_frag_global(vp + 32)};
+        const float kbE = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        for (int c = wave; c < nqc; c += ATTN_THREADS / 64) {   // (query tiles of pure padding: lse_s = -inf -> p = dS = 0 out of the same code)
+            float p[2][4], ds[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int q0 = 32 * c + 16 * hh;
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + 4 * grp);
+                const float4 d4 = *reinterpret_cast<const float4*>(dsum_s + q0 + 4 * grp);
+                const bf16x8_t qa0 = frag_rows<64>(Qs, q0 + l15, grp), qa1 = frag_rows<64>(Qs, q0 + l15, 4 + grp);
+                const bf16x8_t oa0 = frag_rows<64>(Ds, q0 + l15, grp), oa1 = frag_rows<64>(Ds, q0 + l15, 4 + grp);
+                FUSED_SCORE_BLOCK(kfE, vfE, kbE, p[hh], ds[hh]);
+            }
+            union { bf16x8_t f; uint4 u; } pc, dc;
+            pc.f = pack_frag(p[0], p[1]);
+            dc.f = pack_frag(ds[0], ds[1]);
+            *reinterpret_cast<uint2*>(Pe + c * 1024 + ds_off(l15, grp)) = make_uint2(pc.u.x, pc.u.y);
+            *reinterpret_cast<uint2*>(Pe + c * 1024 + ds_off(l15, 4 + grp)) = make_uint2(pc.u.z, pc.u.w);
+            *reinterpret_cast<uint2*>(Se + c * 1024 + ds_off(l15, grp)) = make_uint2(dc.u.x, dc.u.y);
+            *reinterpret_cast<uint2*>(Se + c * 1024 + ds_off(l15, 4 + grp)) = make_uint2(dc.u.z, dc.u.w);
+        }
+        wg_barrier_lds_only();
+        {   // waves 0 - 3: dV of that tile, head-dim tile `wave`; waves 4 - 7: dK, head-dim tile `wave - 4`; the contraction runs over all queries
+            const int dt = wave & 3;
+            const bool is_k = wave >= 4;
+            const char* tok = is_k ? Qs : Ds;
+            const char* src = is_k ? Se : Pe;
+            f32x4_t g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#define FUSED_E_STEP(C, ACC)                                                                                         \
+            do {                                                                                                      \
+                union { bf16x8_t f; uint4 u; } bc_;                                                                   \
+                const uint2 lo_ = *reinterpret_cast<const uint2*>(src + (C) * 1024 + ds_off(l15, grp));               \
+                const uint2 hi_ = *reinterpret_cast<const uint2*>(src + (C) * 1024 + ds_off(l15, 4 + grp));           \
+                bc_.u = make_uint4(lo_.x, lo_.y, hi_.x, hi_.y);                                                       \
+                ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(tok, (C), dt, grp, l15), bc_.f, ACC, 0, 0, 0); \
+            } while (0)
+            if constexpr (NQC > 0) {
+#pragma unroll
+                for (int c = 0; c < NQC; ++c) { if (c & 1) FUSED_E_STEP(c, g1); else FUSED_E_STEP(c, g0); }
+            } else {
+                for (int c = 0; c < nqc; ++c) FUSED_E_STEP(c, g0);
+            }
+#undef FUSED_E_STEP
+            const float sc = is_k ? a.scale : 1.0f;
+            if (ki < a.Nk) {
+                bf16_t* dst = (is_k ? a.dk + ((long)b * a.Nk + ki) * a.lddk : a.dv + ((long)b * a.Nk + ki) * a.lddv) + h * 64 + 16 * dt + 4 * grp;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2((g0[0] + g1[0]) * sc, (g0[1] + g1[1]) * sc), pack_bf2((g0[2] + g1[2]) * sc, (g0[3] + g1[3]) * sc));
+            }
+        }
+        wg_barrier_lds_only();
+    }
+
+    // ---- resident key tiles of this wave: `wave` (exists whenever this kernel runs: more than 128 keys) and `wave + 8`
+    const int kt[2] = {wave, wave + 8};
+    const bool tvb = FULL || kt[1] < nkr;
+    bf16x8_t kf[2][2], vf[2][2];
+    float kbias[2];
+    f32x4_t dk[2][4], dv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ki = kt[j] * 16 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
+        const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
+        kf[j][0] = frag_rows<64>(Ks, ki, grp);      // (rows >= Nk are zero)
+        kf[j][1] = frag_rows<64>(Ks, ki, 4 + grp);
+        vf[j][0] = load_frag_global(vp);
+        vf[j][1] = load_frag_global(vp + 32);
+        kbias[j] = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+    }
+    if (!FULL && !tvb && kt[1] < 2 * NKS) {   // the missing half of the last 32-key slice: its dS^T rows are read by the dQ contraction and never written
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(kt[1] * 16 + l15, grp)) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(kt[1] * 16 + l15, 4 + grp)) = make_uint2(0u, 0u);
+        }
+    }
+    const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
+    const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
+
+    // one 32-query chunk C.  NH = 2: both 16-query tiles hold queries; NH = 1: the second one is pure padding (no score work, zero dS^T rows)
+#define FUSED_CHUNK(C, NH)                                                                                                                  \
+    do {                                                                                                                                    \
+        char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
+        float p_[2][2][4], ds_[2][2][4];   /* [tile][query tile][r] */                                                                      \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                                                  \
+            if (hh < (NH)) {                                                                                                                \
+                const int q0 = 32 * (C) + 16 * hh;                                                                                          \
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + 4 * grp);                                                   \
+                const float4 d4 = *reinterpret_cast<const float4*>(dsum_s + q0 + 4 * grp);                                                  \
+                const bf16x8_t qa0 = frag_rows<64>(Qs, q0 + l15, grp), qa1 = frag_rows<64>(Qs, q0 + l15, 4 + grp);                          \
+                const bf16x8_t oa0 = frag_rows<64>(Ds, q0 + l15, grp), oa1 = frag_rows<64>(Ds, q0 + l15, 4 + grp);                          \
+                FUSED_SCORE_BLOCK(kf[0], vf[0], kbias[0], p_[0][hh], ds_[0][hh]);                                                           \
+                if (tvb) FUSED_SCORE_BLOCK(kf[1], vf[1], kbias[1], p_[1][hh], ds_[1][hh]);                                                  \
+                else { _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[1][hh][r] = 0.f; ds_[1][hh][r] = 0.f; } }                         \
+            } else {                                                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                               \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[j][hh][r] = 0.f; ds_[j][hh][r] = 0.f; }                              \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        bf16x8_t pf_[2], dsf_[2];                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                                     \
+            pf_[j] = pack_frag(p_[j][0], p_[j][1]);                                                                                         \
+            dsf_[j] = pack_frag(ds_[j][0], ds_[j][1]);                                                                                      \
+            if (j == 0 || tvb) {                                                                                                            \
+                union { bf16x8_t f; uint4 u; } dc_;                                                                                         \
+                dc_.f = dsf_[j];                                                                                                            \
+                const int key_ = kt[j] * 16 + l15;                                                                                          \
+                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, grp)) = make_uint2(dc_.u.x, dc_.u.y);                                          \
+                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, 4 + grp)) = make_uint2(dc_.u.z, dc_.u.w);                                      \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        if constexpr (!(ABL & 8)) _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                        \
+            const bf16x8_t fo_ = frag_tokens<64>(Ds, (C), dt, grp, l15), fq_ = frag_tokens<64>(Qs, (C), dt, grp, l15);                      \
+            dv[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[0], dv[0][dt], 0, 0, 0);                                           \
+            dk[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[0], dk[0][dt], 0, 0, 0);                                          \
+            if (tvb) {                                                                                                                      \
+                dv[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[1], dv[1][dt], 0, 0, 0);                                       \
+                dk[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[1], dk[1][dt], 0, 0, 0);                                      \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in sb_ */                             \
+        if (!(ABL & 1) && qqt < (NH)) {                                                                                                     \
+            f32x4_t g0_ = {0.f, 0.f, 0.f, 0.f}, g1_ = {0.f, 0.f, 0.f, 0.f};                                                                 \
+            _Pragma("unroll") for (int kc = 0; kc < NKS; ++kc) {                                                                            \
+                const bf16x4_t lo_ = lds_read_tr16(sb_ + ds_off(32 * kc + rr, s_q)), hi_ = lds_read_tr16(sb_ + ds_off(32 * kc + 16 + rr, s_q)); \
+                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                      \
+                if (kc & 1) g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g1_, 0, 0, 0);       \
+                else g0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g0_, 0, 0, 0);              \
+            }                                                                                                                               \
+            if constexpr (HASE) {                                                                                                           \
+                const bf16x4_t lo_ = lds_read_tr16(Se + (C) * 1024 + ds_off(rr, s_q));                                                      \
+                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], 0, 0, 0, 0};                                                          \
+                g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, 8, qdt, grp, l15), bf_, g1_, 0, 0, 0);                    \
+            }                                                                                                                               \
+            const int qi_ = 32 * (C) + 16 * qqt + l15;                                                                                      \
+            if (qi_ < a.Nq)                                                                                                                 \
+                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi_) * a.lddq + h * 64 + 16 * qdt + 4 * grp) =                           \
+                    make_uint2(pack_bf2((g0_[0] + g1_[0]) * a.scale, (g0_[1] + g1_[1]) * a.scale),                                          \
+                               pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
+        }                                                                                                                                   \
+    } while (0)
+
+    const int nqc2 = (a.Nq + 15) >> 5;   // chunks whose second query tile holds queries
+    int c = 0;
+    for (; c < nqc2; ++c) FUSED_CHUNK(c, 2);
+    for (; c < nqc; ++c) FUSED_CHUNK(c, 1);
+#undef FUSED_CHUNK
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !tvb) continue;
+        const int ki = kt[j] * 16 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
+        uint2 vw[4], kw[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vw[dt] = make_uint2(pack_bf2(dv[j][dt][0], dv[j][dt][1]), pack_bf2(dv[j][dt][2], dv[j][dt][3]));
+            kw[dt] = make_uint2(pack_bf2(dk[j][dt][0] * a.scale, dk[j][dt][1] * a.scale), pack_bf2(dk[j][dt][2] * a.scale, dk[j][dt][3] * a.scale));
+        }
+        store_rows_paired<4>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * 64, vw, lane, grp, ki < a.Nk, dkv_al16);
+        store_rows_paired<4>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * 64, kw, lane, grp, ki < a.Nk, dkv_al16);
+    }
+}
+#undef FUSED_SCORE_BLOCK
+#undef FUSED_EXP
+
 // ---- C ABI --------------------------------------------------------------------------------------------
 static bool attn_args_ok(const AttnArgs& a, int dh) {
     return (dh == 64 || dh == 128) && a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0 && a.Nk <= 288 && a.Nq <= 288 && !(a.ldq & 7) && !(a.ldk & 7) &&
@@ -865,10 +1128,46 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     return antmmf_check_launch();
 }
 
+#ifdef ANTMMF_LAB
+static long g_attn_fused_launches = 0;   // backward calls served by the one-kernel path (tests: "that kernel really ran")
+extern "C" long antmmf_debug_attn_fused_launches() { return g_attn_fused_launches; }
+#endif
 template <int DH>
 static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
     const int nch = (a.Nk + 31) / 32;
     const dim3 grid((unsigned)(a.B * a.heads)), block(ATTN_THREADS);
+    if constexpr (DH == 64) {
+        bool fused = attn_fused_ok(a);
+#ifdef ANTMMF_LAB
+        static const char* bv_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_VARIANT");   // bit 3: the two-kernel backward everywhere (same-box A/B)
+        if (bv_env && (atoi(bv_env) & 8)) fused = false;
+#endif
+        if (fused) {
+#ifdef ANTMMF_LAB
+            ++g_attn_fused_launches;
+#endif
+            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk);
+            const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16;
+#define BWDF(NKS, HASE, FULL, NQC) do { set_lds(attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC>, lds); \
+            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC>), grid, block, lds, stream, a, nqp); } while (0)
+#ifdef ANTMMF_LAB
+            static const char* abl_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_FUSED_ABL");   // timing-only ablations of the 257-token kernel (wrong results)
+            const int abl = abl_env ? atoi(abl_env) : 0;
+#define BWDA(A) do { set_lds(attn_bwd_fused64_kernel<8, true, true, 9, A>, lds); \
+            hipLaunchKernelGGL((attn_bwd_fused64_kernel<8, true, true, 9, A>), grid, block, lds, stream, a, nqp); return antmmf_check_launch(); } while (0)
+            if (abl && nkt > 16 && nqp == 288) {
+                switch (abl) { case 1: BWDA(1); case 2: BWDA(2); case 3: BWDA(3); case 4: BWDA(4); case 8: BWDA(8); case 16: BWDA(16); case 32: BWDA(32); case 15: BWDA(15); default: break; }
+            }
+#undef BWDA
+#endif
+            if (nkt > 16) { if (nqp == 288) BWDF(8, true, true, 9); else BWDF(8, true, true, 0); }
+            else if (nkt == 16) BWDF(8, false, true, 0);
+            else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0); else BWDF(7, false, false, 0); }
+            else { if (nkt > 10) BWDF(6, false, false, 0); else BWDF(5, false, false, 0); }
+#undef BWDF
+            return antmmf_check_launch();
+        }
+    }
 #define BWDQ_K(KERN, LDS) do { set_lds(KERN, LDS); hipLaunchKernelGGL(KERN, grid, block, LDS, stream, a); } while (0)
 #define BWDQ(N) do { const size_t lds = (size_t)(32 * N) * (4 * DH) + (32 * N) * 4; \
         if constexpr (DH == 64) { if (a.drop_thr) BWDQ_K((attn_bwd_dq64_kernel<N, true>), lds); else BWDQ_K((attn_bwd_dq64_kernel<N, false>), lds); } \

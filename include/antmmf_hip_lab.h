@@ -20,6 +20,8 @@ extern "C" {
 int antmmf_debug_set_gemm_variant(int bits);
 /* launches of the persistent NT kernel whose tail round ran as cells (tests: "the cells really ran") */
 long antmmf_debug_gemm_cell_launches(void);
+/* attention backward calls served by the one-kernel path attn_bwd_fused64_kernel (tests: "that kernel really ran") */
+long antmmf_debug_attn_fused_launches(void);
 
 /* ---- M2 feed-forward with the sub-LayerNorm folded into its GEMMs.  Reference prj/M2_Encoder/vlmo/torchscale/component/
  * feedforward_network.py:117-128: x -> fc1 -> gelu -> ffn_layernorm (over the 4d-wide row) -> fc2 (+ the residual of encoder.py:176-199).

@@ -254,6 +254,26 @@ def test_attention_fwd32_opt_in(variant):
     assert "okfwd32" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_attention_backward_one_kernel(ops):
+    """attn_bwd_fused64_kernel (head size 64, 128 < keys <= 272, no dropout): the 257-token towers (a 17th key tile with ONE valid key, a last chunk with one valid query),
+    even / odd numbers of resident key tiles (a missing half slice), masked keys incl. -inf, cross lengths either way, the largest size; the shorter cases above keep
+    exercising the two-kernel backward."""
+    import ctypes
+    from antmmf.hip import _lib
+    lib = _lib.load()
+    lib.antmmf_debug_attn_fused_launches.restype = ctypes.c_long
+    n0 = lib.antmmf_debug_attn_fused_launches()
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=257, Nk=257, bias_kind="none")
+    kc.case_attention(ops, DEV, B=2, heads=1, Nq=200, Nk=200, bias_kind="inf")
+    kc.case_attention(ops, DEV, B=1, heads=2, Nq=33, Nk=270, bias_kind="bert", packed=False)
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=150, Nk=130, bias_kind="bert", packed=False)
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=20, Nk=256, bias_kind="none", packed=False)
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=288, Nk=272, bias_kind="inf", packed=False)
+    assert lib.antmmf_debug_attn_fused_launches() == n0 + 6, "the one-kernel backward did not run"
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=40, Nk=128, bias_kind="none", packed=False)   # (at the boundary: two kernels)
+    assert lib.antmmf_debug_attn_fused_launches() == n0 + 6
+
+
 def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 

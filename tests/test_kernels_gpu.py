@@ -258,9 +258,51 @@ def test_gemm_persistent_uneven_rounds(ops):
     dict(B=2, heads=8, Nq=100, Nk=100, bias_kind="none", head_dim=128),               # ViLBERT: 8 heads x 128, 100 regions
     dict(B=3, heads=8, Nq=37, Nk=100, bias_kind="bert", packed=False, head_dim=128),  # text queries over image regions, additive mask
     dict(B=2, heads=2, Nq=288, Nk=257, bias_kind="inf", packed=False, head_dim=128),  # the largest tiles (147 KB of LDS)
+    # the one-kernel backward (head size 64, 128 < keys <= 272; the 197- and 257-token cases above run on it too): masks on the 17-tile case, a missing half slice,
+    # cross lengths either way, the tile boundary, the largest size
+    dict(B=2, heads=16, Nq=257, Nk=257, bias_kind="bert"),
+    dict(B=3, heads=2, Nq=200, Nk=200, bias_kind="inf"),
+    dict(B=2, heads=2, Nq=33, Nk=270, bias_kind="bert", packed=False),
+    dict(B=2, heads=3, Nq=150, Nk=130, bias_kind="bert", packed=False),
+    dict(B=2, heads=2, Nq=20, Nk=256, bias_kind="none", packed=False),
+    dict(B=2, heads=2, Nq=288, Nk=272, bias_kind="inf", packed=False),
+    dict(B=2, heads=2, Nq=64, Nk=129, bias_kind="none", packed=False),
 ])
 def test_attention(ops, cfg):
     kc.case_attention(ops, DEV, **cfg)
+
+
+def test_attention_backward_one_kernel_runs_and_repeats():
+    """attn_bwd_fused64_kernel at the ViT-L/14 tower's shape (16 heads x 257 tokens, packed qkv rows): the lab library's counter says that kernel served the call, two calls
+    give BIT-IDENTICAL gradients (dQ is contracted over all keys by one wave in a fixed order: no atomics), and they agree with the two-kernel backward (lab variant bit 3,
+    separate process) to bf16 rounding of the outputs."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, ctypes, torch; sys.path[:0] = [%r, %r, %r];"
+            "from antmmf.hip import ops, _lib; lib = _lib.load(); lib.antmmf_debug_attn_fused_launches.restype = ctypes.c_long; dev = torch.device('cuda:0');"
+            "g = torch.Generator(device='cuda').manual_seed(3); B, N, h = 8, 257, 16;"
+            "qkv = torch.randn(B, N, 3 * h * 64, generator=g, device=dev).bfloat16(); q, k, v = qkv[..., :h * 64], qkv[..., h * 64:2 * h * 64], qkv[..., 2 * h * 64:];"
+            "o, lse = ops.attention_fwd(q, k, v, h, 0.125); do = torch.randn(B, N, h * 64, generator=g, device=dev).bfloat16();"
+            "n0 = lib.antmmf_debug_attn_fused_launches(); r1 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125); r2 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125);"
+            "n1 = lib.antmmf_debug_attn_fused_launches(); torch.cuda.synchronize();"
+            "assert all(torch.equal(a, b) for a, b in zip(r1, r2));"
+            "torch.save([t.cpu() for t in r1], sys.argv[1]); print('fused_launches', n1 - n0)"
+            % (os.path.join(root, "tests"), os.path.join(root, "ant-multi-modal-framework_amd"), root))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        outs = {}
+        for variant, want in (("0", 2), ("8", 0)):
+            f = os.path.join(td, "g%s.pt" % variant)
+            out = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=900, env=dict(lab_env(), ANTMMF_ATTN_VARIANT=variant))
+            assert "fused_launches %d" % want in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+            outs[variant] = torch.load(f)
+        for a, b, name in zip(outs["0"], outs["8"], ("dq", "dk", "dv")):
+            a, b = a.float(), b.float()
+            assert torch.isfinite(a).all()
+            err = (a - b).abs().max().item()
+            assert err <= 2.0 ** -6 * b.abs().max().item(), (name, err, b.abs().max().item())   # both round fp32 sums of the same products to bf16 (different summation orders)
 
 
 @pytest.mark.parametrize("variant", [4, 6])
