@@ -842,9 +842,9 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 // (16 consecutive keys x one slot) and the transposing reads (8 consecutive keys x 4 slots of one query tile) sweep all banks.
 __device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
 __device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
-static inline size_t attn_fused_lds_bytes(int Nq, int Nk) {
+static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool persist = false) {
     const int nqp = ((Nq + 31) / 32) * 32;
-    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
+    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;   // (persist: same footprint)
 }
 static inline bool attn_fused_ok(const AttnArgs& a) {
     return !a.drop_thr && a.Nk > 128 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;
@@ -865,12 +865,101 @@ static inline bool attn_fused_ok(const AttnArgs& a) {
         }                                                                                                     \
     } while (0)
 
+// LDS-DMA of one 1-KB piece (8 token rows x 128 B) of a swizzled token tile: lane i lands at piece base + 16 i = row 8 piece + (i >> 3), physical slot i & 7, so it
+// FETCHES the logical slot (i & 7) ^ swz(row) of that row.  Rows past the end re-read the last valid row (finite values: everything they feed is multiplied by a
+// probability that is exactly 0).  The DMA is issued from inline asm on purpose: with the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of every later ds_read
+// while a piece is in flight (it cannot tell that the rows differ) -- the pieces requested here are read only after the next item's opening wait + barrier.
+__device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, const bf16_t* __restrict__ src, long ld, int n_valid, int piece, int lane) {
+    const int row = 8 * piece + (lane >> 3), slot = (lane & 7) ^ attn_swz<64>(row);
+    const bf16_t* g = src + (long)(row < n_valid ? row : n_valid - 1) * ld + slot * 8;
+#ifdef ANTMMF_EMULATE
+    (void)tile_lds;
+    std::memcpy(tile + piece * 1024 + lane * 16, g, 16);
+#else
+    (void)tile;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(tile_lds + piece * 1024);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(g) : "memory");
+#endif
+}
+
+// one 32-query chunk C of attn_bwd_fused64_kernel.  NH = 2: both 16-query tiles hold queries; NH = 1: the second one is pure padding (no score work, zero dS^T rows).
+// BEFORE / AFTER: statements run by every wave before / after the chunk's workgroup barrier (the persistent form's prefetch of the next item).
+#define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
+    do {                                                                                                                                    \
+        char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
+        float p_[2][2][4], ds_[2][2][4];   /* [tile][query tile][r] */                                                                      \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                                                  \
+            if (hh < (NH)) {                                                                                                                \
+                const int q0 = 32 * (C) + 16 * hh;                                                                                          \
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + 4 * grp);                                                   \
+                const float4 d4 = *reinterpret_cast<const float4*>(dsum_s + q0 + 4 * grp);                                                  \
+                const bf16x8_t qa0 = frag_rows<64>(Qs, q0 + l15, grp), qa1 = frag_rows<64>(Qs, q0 + l15, 4 + grp);                          \
+                const bf16x8_t oa0 = frag_rows<64>(Ds, q0 + l15, grp), oa1 = frag_rows<64>(Ds, q0 + l15, 4 + grp);                          \
+                FUSED_SCORE_BLOCK(kf[0], vf[0], kbias[0], p_[0][hh], ds_[0][hh]);                                                           \
+                if (tvb) FUSED_SCORE_BLOCK(kf[1], vf[1], kbias[1], p_[1][hh], ds_[1][hh]);                                                  \
+                else { _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[1][hh][r] = 0.f; ds_[1][hh][r] = 0.f; } }                         \
+            } else {                                                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                               \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[j][hh][r] = 0.f; ds_[j][hh][r] = 0.f; }                              \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        bf16x8_t pf_[2], dsf_[2];                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                                     \
+            pf_[j] = pack_frag(p_[j][0], p_[j][1]);                                                                                         \
+            dsf_[j] = pack_frag(ds_[j][0], ds_[j][1]);                                                                                      \
+            if (j == 0 || tvb) {                                                                                                            \
+                union { bf16x8_t f; uint4 u; } dc_;                                                                                         \
+                dc_.f = dsf_[j];                                                                                                            \
+                const int key_ = kt[j] * 16 + l15;                                                                                          \
+                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, grp)) = make_uint2(dc_.u.x, dc_.u.y);                                          \
+                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, 4 + grp)) = make_uint2(dc_.u.z, dc_.u.w);                                      \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        if constexpr (!(ABL & 8)) _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                        \
+            const bf16x8_t fo_ = frag_tokens<64>(Ds, (C), dt, grp, l15), fq_ = frag_tokens<64>(Qs, (C), dt, grp, l15);                      \
+            dv[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[0], dv[0][dt], 0, 0, 0);                                           \
+            dk[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[0], dk[0][dt], 0, 0, 0);                                          \
+            if (tvb) {                                                                                                                      \
+                dv[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[1], dv[1][dt], 0, 0, 0);                                       \
+                dk[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[1], dk[1][dt], 0, 0, 0);                                      \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        BEFORE;                                                                                                                             \
+        if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in sb_; nobody reads this chunk's Q / dO rows any more */ \
+        AFTER;                                                                                                                              \
+        if (!(ABL & 1) && qqt < (NH)) {                                                                                                     \
+            f32x4_t g0_ = {0.f, 0.f, 0.f, 0.f}, g1_ = {0.f, 0.f, 0.f, 0.f};                                                                 \
+            _Pragma("unroll") for (int kc = 0; kc < NKS; ++kc) {                                                                            \
+                const bf16x4_t lo_ = lds_read_tr16(sb_ + ds_off(32 * kc + rr, s_q)), hi_ = lds_read_tr16(sb_ + ds_off(32 * kc + 16 + rr, s_q)); \
+                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                      \
+                if (kc & 1) g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g1_, 0, 0, 0);       \
+                else g0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g0_, 0, 0, 0);              \
+            }                                                                                                                               \
+            if constexpr (HASE) {                                                                                                           \
+                const bf16x4_t lo_ = lds_read_tr16(Se + (C) * 1024 + ds_off(rr, s_q));                                                      \
+                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], 0, 0, 0, 0};                                                          \
+                g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, 8, qdt, grp, l15), bf_, g1_, 0, 0, 0);                    \
+            }                                                                                                                               \
+            const int qi_ = 32 * (C) + 16 * qqt + l15;                                                                                      \
+            if (qi_ < a.Nq)                                                                                                                 \
+                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi_) * a.lddq + h * 64 + 16 * qdt + 4 * grp) =                           \
+                    make_uint2(pack_bf2((g0_[0] + g1_[0]) * a.scale, (g0_[1] + g1_[1]) * a.scale),                                          \
+                               pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
+        }                                                                                                                                   \
+    } while (0)
+
 // NKS: 32-key slices of the resident key tiles (compile time: the dQ contraction is straight-line code); HASE: a 17th key tile exists; FULL: all sixteen resident
 // tiles exist (no per-wave validity tests); NQC: number of query chunks when known at compile time (the extra tile's contraction), 0 = run-time loop.
+// PERSIST: one workgroup per CU walks the items (b, h) blockIdx.x, blockIdx.x + gridDim.x, ... and hides the NEXT item's loads behind this item's arithmetic --
+// with 151 KB of LDS there is no second workgroup on the CU to do that (timing-only ablations of the non-persistent form, profiles/r5_attn_bwd_one_kernel_v1_*:
+// 1.87 ms of which ~ 1.3 ms remain with the dQ / dV / dK contractions, the exponentials and the barriers all removed).  Q and dO of the next item arrive by LDS-DMA
+// chunk by chunk INTO THE ROWS THE CURRENT ITEM HAS JUST FINISHED WITH (chunk c's rows are dead after the chunk's barrier), its D = rowsum(dO o O) and lse row
+// statistics are formed four rows per wave and chunk from coalesced loads into a second statistics buffer, and its K tile is requested right after the last dQ
+// contraction, in front of this item's dK / dV stores.
 // ABL (lab library only, TIMING-ONLY, wrong results): 1 no dQ contraction, 2 no per-chunk barrier, 4 the exponential replaced by its argument, 8 no dV / dK contraction,
 // 16 no D = rowsum(dO o O) pass in the prologue, 32 no extra key tile -- what each part of the kernel costs, same box, same process.
-template <int NKS, bool HASE, bool FULL, int NQC, int ABL = 0>
-__global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const AttnArgs a, int NQP) {
+template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0>
+__global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const AttnArgs a, int NQP, int n_items) {
     ANTMMF_DYN_LDS(char, smem);
     const int nkt = (a.Nk + 15) >> 4, nkr = nkt < 16 ? nkt : 16, nqc = NQC ? NQC : NQP >> 5;   // key tiles, resident key tiles, query chunks
     char* Qs = smem;
@@ -878,44 +967,128 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     char* Ks = Ds + NQP * 128;
     char* Sb = Ks + 288 * 128;
     char* Se = Sb + 2 * 16384;
-    float* lse_s = reinterpret_cast<float*>(Se + (HASE ? nqc * 1024 : 0));
-    float* dsum_s = lse_s + NQP;
-    const int lane = threadIdx.x & 63, l15 = lane & 15, grp = lane >> 4;
+    float* stats = reinterpret_cast<float*>(Se + (HASE ? nqc * 1024 : 0));   // [lse | dsum][NQP], both negated: accumulator start values
+    const int lane_w = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
+    const uint32_t lds0 = 0;
 #else
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: everything decided per wave below is a uniform branch, not an exec mask
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #endif
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * 64;
-    const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * 64;
-    const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
-    stage_rows2<64, 288>(Qs, qbase, a.ldq, Ds, dobase, a.lddo, a.Nq, NQP);
-    stage_rows<64, 288>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, 288);
-    for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {   // (as attn_bwd_dkv_kernel: both negated, accumulator start values; padding queries: p = 0)
-        float d = 0.f, l = INFINITY;
-        if (i < a.Nq) {
-            l = a.lse[((long)b * a.heads + h) * a.Nq + i];
-            l = l == -INFINITY ? INFINITY : l / a.scale;
-            if constexpr (!(ABL & 16)) {
-#pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    float x[8], y[8];
-                    ld8<bf16_t>(dobase + (long)i * a.lddo + v * 8, x);
-                    ld8<bf16_t>(obase + (long)i * a.ldo + v * 8, y);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) d += x[e] * y[e];
-                }
-            }
-        }
-        lse_s[i] = -l;
-        dsum_s[i] = -d;
-    }
-    __syncthreads();
-
-#define FUSED_EXP(x) ((ABL & 4) ? (x) : EXP2F(x))
     const float scale2 = a.scale * LOG2E;
     const bool dkv_al16 = !(a.lddk & 7) && !(a.lddv & 7) && !((uintptr_t)a.dk & 15) && !((uintptr_t)a.dv & 15);
+#define FUSED_EXP(x) ((ABL & 4) ? (x) : EXP2F(x))
+    // ---- persistent form: requests for an item's operands
+    // K tile: 36 pieces over the 8 waves
+#define FUSED_DMA_K(ITEM)                                                                                                                    \
+    do {                                                                                                                                    \
+        const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                             \
+        for (int pc_ = wave; pc_ < 36; pc_ += ATTN_THREADS / 64)                                                                            \
+            attn_dma_piece(Ks, lds0 + (uint32_t)(Ks - smem), a.k + (long)b_ * a.Nk * a.ldk + h_ * 64, a.ldk, a.Nk, pc_, lane);              \
+    } while (0)
+    // chunk C of Q (waves 0 - 3) and dO (waves 4 - 7): one piece per wave
+#define FUSED_DMA_QD(ITEM, C)                                                                                                                \
+    do {                                                                                                                                    \
+        const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                             \
+        if (wave < 4) attn_dma_piece(Qs, lds0, a.q + (long)b_ * a.Nq * a.ldq + h_ * 64, a.ldq, a.Nq, 4 * (C) + wave, lane);                 \
+        else attn_dma_piece(Ds, lds0 + (uint32_t)(Ds - smem), a.d_o + (long)b_ * a.Nq * a.lddo + h_ * 64, a.lddo, a.Nq, 4 * (C) + wave - 4, lane); \
+    } while (0)
+    // what an item needs in REGISTERS, requested while the previous item's dK / dV stores drain: its O rows in the staging pattern of the token tiles (thread -> row id >> 3,
+    // 16-B slot id & 7, id = thread + 512 i) for D = rowsum(dO o O) -- dO comes out of the landed LDS tile --, its lse row, the V fragments and key biases of this wave's tiles
+    uint4 po[5];
+    float pl = -INFINITY;
+    bf16x8_t vfn[2][2] = {}, vfEn[2] = {};
+    float kbn[2] = {0.f, 0.f}, kbEn = 0.f;
+#define FUSED_PREFETCH_REGS(ITEM)                                                                                                            \
+    do {                                                                                                                                    \
+        const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                                                                  \
+            const int id_ = wave * 64 + lane + i_ * ATTN_THREADS, row_ = id_ >> 3;                                                          \
+            po[i_] = make_uint4(0, 0, 0, 0);                                                                                                \
+            if (!(ABL & 16) && row_ < a.Nq) po[i_] = *reinterpret_cast<const uint4*>(a.o + ((long)b_ * a.Nq + row_) * a.ldo + h_ * 64 + (id_ & 7) * 8); \
+        }                                                                                                                                   \
+        pl = -INFINITY;                                                                                                                     \
+        if (wave * 64 + lane < a.Nq) pl = a.lse[((long)b_ * a.heads + h_) * a.Nq + wave * 64 + lane];                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                                  \
+            const int ki_ = (wave + 8 * j_) * 16 + (lane & 15), krow_ = ki_ < a.Nk ? ki_ : a.Nk - 1;                                        \
+            const bf16_t* vp_ = a.v + ((long)b_ * a.Nk + krow_) * a.ldv + h_ * 64 + (lane >> 4) * 8;                                        \
+            vfn[j_][0] = load_frag_global(vp_); vfn[j_][1] = load_frag_global(vp_ + 32);                                                    \
+            kbn[j_] = ki_ < a.Nk ? (a.key_bias ? a.key_bias[(long)b_ * a.Nk + ki_] : 0.f) : -INFINITY;   /* (x log2 e at the point of use: no wait here) */ \
+        }                                                                                                                                   \
+        if constexpr (HASE) {                                                                                                               \
+            const int ki_ = 256 + (lane & 15), krow_ = ki_ < a.Nk ? ki_ : a.Nk - 1;                                                         \
+            const bf16_t* vp_ = a.v + ((long)b_ * a.Nk + krow_) * a.ldv + h_ * 64 + (lane >> 4) * 8;                                        \
+            vfEn[0] = load_frag_global(vp_); vfEn[1] = load_frag_global(vp_ + 32);                                                          \
+            kbEn = ki_ < a.Nk ? (a.key_bias ? a.key_bias[(long)b_ * a.Nk + ki_] : 0.f) : -INFINITY;                                         \
+        }                                                                                                                                   \
+    } while (0)
+
+    int item = blockIdx.x;
+    if constexpr (PERSIST) {
+        const int lane = lane_w;
+        if (item < n_items) {
+            FUSED_DMA_K(item);
+            for (int c = 0; c < nqc; ++c) FUSED_DMA_QD(item, c);
+            FUSED_PREFETCH_REGS(item);
+        }
+    }
+    do {   // (the non-persistent form is launched with one workgroup per item: no loop in its code)
+    // every per-lane LDS offset below derives from this copy of the lane number, opaque per item: hoisted out of the ITEM loop they would all stay live across the
+    // whole kernel (measured: 256 VGPRs + 312 B of scratch); recomputed per item they cost a few VALU instructions in 40 k cycles
+    int lane_o = lane_w;
+#ifndef ANTMMF_EMULATE
+    if constexpr (PERSIST) asm volatile("" : "+v"(lane_o));
+#endif
+    const int lane = lane_o, l15 = lane & 15, grp = lane >> 4;
+    const int b = item / a.heads, h = item % a.heads;
+    const int nxt = item + gridDim.x;
+    const bool has_next = PERSIST && nxt < n_items;
+    float* lse_s = stats;
+    float* dsum_s = lse_s + NQP;
+    if constexpr (PERSIST) {
+        glds_wait_all();         // this wave's pieces of the item, its register prefetch (and everything older) have landed ...
+        wg_barrier_lds_only();   // ... and so have the other waves' pieces
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {   // D = rowsum(dO o O): eight lanes per row, dO from the LDS tile
+            const int id = wave * 64 + lane + i * ATTN_THREADS, row = id >> 3 < NQP ? id >> 3 : NQP - 1, slot = id & 7;
+            const uint4 dw4 = *reinterpret_cast<const uint4*>(Ds + row * 128 + ((slot ^ attn_swz<64>(row)) << 4));
+            const uint32_t ow[4] = {po[i].x, po[i].y, po[i].z, po[i].w}, dw[4] = {dw4.x, dw4.y, dw4.z, dw4.w};
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d += bf_lo(dw[e]) * bf_lo(ow[e]) + bf_hi(dw[e]) * bf_hi(ow[e]);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (slot == 0 && (id >> 3) < NQP) dsum_s[id >> 3] = -d;
+        }
+        if (wave * 64 + lane < NQP) lse_s[wave * 64 + lane] = pl == -INFINITY ? -INFINITY : -(pl / a.scale);   // raw-score units, negated; fully masked / padding query: -inf -> p = 0
+        wg_barrier_lds_only();
+    } else {
+        const bf16_t* qbase = a.q + (long)b * a.Nq * a.ldq + h * 64;
+        const bf16_t* dobase = a.d_o + (long)b * a.Nq * a.lddo + h * 64;
+        const bf16_t* obase = a.o + (long)b * a.Nq * a.ldo + h * 64;
+        stage_rows2<64, 288>(Qs, qbase, a.ldq, Ds, dobase, a.lddo, a.Nq, NQP);
+        stage_rows<64, 288>(Ks, a.k + (long)b * a.Nk * a.ldk + h * 64, a.ldk, a.Nk, 288);
+        for (int i = threadIdx.x; i < NQP; i += ATTN_THREADS) {   // (as attn_bwd_dkv_kernel; padding queries: p = 0)
+            float d = 0.f, l = INFINITY;
+            if (i < a.Nq) {
+                l = a.lse[((long)b * a.heads + h) * a.Nq + i];
+                l = l == -INFINITY ? INFINITY : l / a.scale;
+                if constexpr (!(ABL & 16)) {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        float x[8], y[8];
+                        ld8<bf16_t>(dobase + (long)i * a.lddo + v * 8, x);
+                        ld8<bf16_t>(obase + (long)i * a.ldo + v * 8, y);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d += x[e] * y[e];
+                    }
+                }
+            }
+            lse_s[i] = -l;
+            dsum_s[i] = -d;
+        }
+        __syncthreads();
+    }
 
     // ---- the key tile beyond the sixteen resident ones
     if constexpr (HASE && !(ABL & 32)) {
@@ -923,8 +1096,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         const int ki = 256 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
         const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
         const bf16x8_t kfE[2] = {frag_rows<64>(Ks, 256 + l15, grp), frag_rows<64>(Ks, 256 + l15, 4 + grp)};
-        const bf16x8_t vfE[2] = {load_frag_global(vp), load_frag_global(vp + 32)};
-        const float kbE = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        bf16x8_t vfE[2];
+        float kbE;
+        if constexpr (PERSIST) { vfE[0] = vfEn[0]; vfE[1] = vfEn[1]; kbE = kbEn * LOG2E; }
+        else {
+            vfE[0] = load_frag_global(vp); vfE[1] = load_frag_global(vp + 32);
+            kbE = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        }
         for (int c = wave; c < nqc; c += ATTN_THREADS / 64) {   // (query tiles of pure padding: lse_s = -inf -> p = dS = 0 out of the same code)
             float p[2][4], ds[2][4];
 #pragma unroll
@@ -985,11 +1163,14 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     for (int j = 0; j < 2; ++j) {
         const int ki = kt[j] * 16 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
         const bf16_t* vp = a.v + ((long)b * a.Nk + krow) * a.ldv + h * 64 + grp * 8;
-        kf[j][0] = frag_rows<64>(Ks, ki, grp);      // (rows >= Nk are zero)
+        kf[j][0] = frag_rows<64>(Ks, ki, grp);      // (rows >= Nk: zero, or a copy of the last row in the persistent form -- their probabilities are 0 either way)
         kf[j][1] = frag_rows<64>(Ks, ki, 4 + grp);
-        vf[j][0] = load_frag_global(vp);
-        vf[j][1] = load_frag_global(vp + 32);
-        kbias[j] = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        if constexpr (PERSIST) { vf[j][0] = vfn[j][0]; vf[j][1] = vfn[j][1]; kbias[j] = kbn[j] * LOG2E; }
+        else {
+            vf[j][0] = load_frag_global(vp);
+            vf[j][1] = load_frag_global(vp + 32);
+            kbias[j] = ki < a.Nk ? (a.key_bias ? a.key_bias[(long)b * a.Nk + ki] * LOG2E : 0.f) : -INFINITY;
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     }
@@ -1003,74 +1184,21 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
     const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
 
-    // one 32-query chunk C.  NH = 2: both 16-query tiles hold queries; NH = 1: the second one is pure padding (no score work, zero dS^T rows)
-#define FUSED_CHUNK(C, NH)                                                                                                                  \
-    do {                                                                                                                                    \
-        char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
-        float p_[2][2][4], ds_[2][2][4];   /* [tile][query tile][r] */                                                                      \
-        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                                                  \
-            if (hh < (NH)) {                                                                                                                \
-                const int q0 = 32 * (C) + 16 * hh;                                                                                          \
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + 4 * grp);                                                   \
-                const float4 d4 = *reinterpret_cast<const float4*>(dsum_s + q0 + 4 * grp);                                                  \
-                const bf16x8_t qa0 = frag_rows<64>(Qs, q0 + l15, grp), qa1 = frag_rows<64>(Qs, q0 + l15, 4 + grp);                          \
-                const bf16x8_t oa0 = frag_rows<64>(Ds, q0 + l15, grp), oa1 = frag_rows<64>(Ds, q0 + l15, 4 + grp);                          \
-                FUSED_SCORE_BLOCK(kf[0], vf[0], kbias[0], p_[0][hh], ds_[0][hh]);                                                           \
-                if (tvb) FUSED_SCORE_BLOCK(kf[1], vf[1], kbias[1], p_[1][hh], ds_[1][hh]);                                                  \
-                else { _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[1][hh][r] = 0.f; ds_[1][hh][r] = 0.f; } }                         \
-            } else {                                                                                                                        \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                               \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) { p_[j][hh][r] = 0.f; ds_[j][hh][r] = 0.f; }                              \
-            }                                                                                                                               \
-        }                                                                                                                                   \
-        bf16x8_t pf_[2], dsf_[2];                                                                                                           \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                                     \
-            pf_[j] = pack_frag(p_[j][0], p_[j][1]);                                                                                         \
-            dsf_[j] = pack_frag(ds_[j][0], ds_[j][1]);                                                                                      \
-            if (j == 0 || tvb) {                                                                                                            \
-                union { bf16x8_t f; uint4 u; } dc_;                                                                                         \
-                dc_.f = dsf_[j];                                                                                                            \
-                const int key_ = kt[j] * 16 + l15;                                                                                          \
-                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, grp)) = make_uint2(dc_.u.x, dc_.u.y);                                          \
-                *reinterpret_cast<uint2*>(sb_ + ds_off(key_, 4 + grp)) = make_uint2(dc_.u.z, dc_.u.w);                                      \
-            }                                                                                                                               \
-        }                                                                                                                                   \
-        if constexpr (!(ABL & 8)) _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                        \
-            const bf16x8_t fo_ = frag_tokens<64>(Ds, (C), dt, grp, l15), fq_ = frag_tokens<64>(Qs, (C), dt, grp, l15);                      \
-            dv[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[0], dv[0][dt], 0, 0, 0);                                           \
-            dk[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[0], dk[0][dt], 0, 0, 0);                                          \
-            if (tvb) {                                                                                                                      \
-                dv[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo_, pf_[1], dv[1][dt], 0, 0, 0);                                       \
-                dk[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[1], dk[1][dt], 0, 0, 0);                                      \
-            }                                                                                                                               \
-        }                                                                                                                                   \
-        if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in sb_ */                             \
-        if (!(ABL & 1) && qqt < (NH)) {                                                                                                     \
-            f32x4_t g0_ = {0.f, 0.f, 0.f, 0.f}, g1_ = {0.f, 0.f, 0.f, 0.f};                                                                 \
-            _Pragma("unroll") for (int kc = 0; kc < NKS; ++kc) {                                                                            \
-                const bf16x4_t lo_ = lds_read_tr16(sb_ + ds_off(32 * kc + rr, s_q)), hi_ = lds_read_tr16(sb_ + ds_off(32 * kc + 16 + rr, s_q)); \
-                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                      \
-                if (kc & 1) g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g1_, 0, 0, 0);       \
-                else g0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g0_, 0, 0, 0);              \
-            }                                                                                                                               \
-            if constexpr (HASE) {                                                                                                           \
-                const bf16x4_t lo_ = lds_read_tr16(Se + (C) * 1024 + ds_off(rr, s_q));                                                      \
-                const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], 0, 0, 0, 0};                                                          \
-                g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, 8, qdt, grp, l15), bf_, g1_, 0, 0, 0);                    \
-            }                                                                                                                               \
-            const int qi_ = 32 * (C) + 16 * qqt + l15;                                                                                      \
-            if (qi_ < a.Nq)                                                                                                                 \
-                *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi_) * a.lddq + h * 64 + 16 * qdt + 4 * grp) =                           \
-                    make_uint2(pack_bf2((g0_[0] + g1_[0]) * a.scale, (g0_[1] + g1_[1]) * a.scale),                                          \
-                               pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
-        }                                                                                                                                   \
-    } while (0)
-
     const int nqc2 = (a.Nq + 15) >> 5;   // chunks whose second query tile holds queries
     int c = 0;
-    for (; c < nqc2; ++c) FUSED_CHUNK(c, 2);
-    for (; c < nqc; ++c) FUSED_CHUNK(c, 1);
-#undef FUSED_CHUNK
+    if constexpr (PERSIST) {
+        // (measured and not kept, profiles/r5_attn_bwd_one_kernel_l2_warmup_ab.txt: one dword per 64-B half row of the NEXT item's K, V and O requested during chunk 2, so
+        // that the K tile's DMA and the register prefetch at the item boundary find their lines in L2: 1.69 -> 1.80 ms)
+#define FUSED_POST(C) do { if (has_next) FUSED_DMA_QD(nxt, (C)); } while (0)
+        for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, FUSED_POST(c));
+        for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, FUSED_POST(c));
+#undef FUSED_POST
+        wg_barrier_lds_only();   // every wave is through its last dQ contraction: K and the dS^T buffers are free
+        if (has_next) FUSED_DMA_K(nxt);
+    } else {
+        for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, (void)0);
+        for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, (void)0);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (j == 1 && !tvb) continue;
@@ -1084,7 +1212,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         store_rows_paired<4>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * 64, vw, lane, grp, ki < a.Nk, dkv_al16);
         store_rows_paired<4>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * 64, kw, lane, grp, ki < a.Nk, dkv_al16);
     }
+    if constexpr (PERSIST) { if (has_next) FUSED_PREFETCH_REGS(nxt); }   // (behind the stores: the accumulators' registers are free now; all of it lands under the K tile's latency)
+    } while (PERSIST && (item += gridDim.x) < n_items);
+#undef FUSED_DMA_K
+#undef FUSED_DMA_QD
+#undef FUSED_PREFETCH_REGS
 }
+#undef FUSED_CHUNK
 #undef FUSED_SCORE_BLOCK
 #undef FUSED_EXP
 
@@ -1146,24 +1280,40 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
 #ifdef ANTMMF_LAB
             ++g_attn_fused_launches;
 #endif
-            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk);
-            const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16;
-#define BWDF(NKS, HASE, FULL, NQC) do { set_lds(attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC>, lds); \
-            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC>), grid, block, lds, stream, a, nqp); } while (0)
+            const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16, n_items = a.B * a.heads;
+            // all sixteen resident key tiles present (the 197- / 257-token towers): the persistent form, one workgroup per CU walking the items
+            const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk, true) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
+            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk, persist);
+            unsigned pwgs = 256u;
+#ifdef ANTMMF_LAB
+            static const char* pw_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_PERSIST_WGS");   // lab / emulator tests: a small grid makes every workgroup walk several items
+            if (pw_env) pwgs = (unsigned)atoi(pw_env);
+#endif
+            const dim3 pgrid(persist ? ((unsigned)n_items < pwgs ? (unsigned)n_items : pwgs) : (unsigned)n_items);
+#define BWDF(NKS, HASE, FULL, NQC, PERS, ABL) do { set_lds(attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL>, lds); \
+            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL>), pgrid, block, lds, stream, a, nqp, n_items); } while (0)
 #ifdef ANTMMF_LAB
             static const char* abl_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_FUSED_ABL");   // timing-only ablations of the 257-token kernel (wrong results)
             const int abl = abl_env ? atoi(abl_env) : 0;
-#define BWDA(A) do { set_lds(attn_bwd_fused64_kernel<8, true, true, 9, A>, lds); \
-            hipLaunchKernelGGL((attn_bwd_fused64_kernel<8, true, true, 9, A>), grid, block, lds, stream, a, nqp); return antmmf_check_launch(); } while (0)
-            if (abl && nkt > 16 && nqp == 288) {
-                switch (abl) { case 1: BWDA(1); case 2: BWDA(2); case 3: BWDA(3); case 4: BWDA(4); case 8: BWDA(8); case 16: BWDA(16); case 32: BWDA(32); case 15: BWDA(15); default: break; }
+            if (abl && persist && nkt > 16 && nqp == 288) {
+                switch (abl) {
+                    case 1: BWDF(8, true, true, 9, true, 1); return antmmf_check_launch();
+                    case 2: BWDF(8, true, true, 9, true, 2); return antmmf_check_launch();
+                    case 4: BWDF(8, true, true, 9, true, 4); return antmmf_check_launch();
+                    case 8: BWDF(8, true, true, 9, true, 8); return antmmf_check_launch();
+                    case 16: BWDF(8, true, true, 9, true, 16); return antmmf_check_launch();
+                    case 32: BWDF(8, true, true, 9, true, 32); return antmmf_check_launch();
+                    case 15: BWDF(8, true, true, 9, true, 15); return antmmf_check_launch();
+                    default: break;
+                }
             }
-#undef BWDA
 #endif
-            if (nkt > 16) { if (nqp == 288) BWDF(8, true, true, 9); else BWDF(8, true, true, 0); }
-            else if (nkt == 16) BWDF(8, false, true, 0);
-            else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0); else BWDF(7, false, false, 0); }
-            else { if (nkt > 10) BWDF(6, false, false, 0); else BWDF(5, false, false, 0); }
+            if (persist) {
+                if (nkt > 16) BWDF(8, true, true, 9, true, 0);
+                else if (nkt == 16) BWDF(8, false, true, 0, true, 0);
+                else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0, true, 0); else BWDF(7, false, false, 0, true, 0); }
+                else { if (nkt > 10) BWDF(6, false, false, 0, true, 0); else BWDF(5, false, false, 0, true, 0); }
+            } else BWDF(8, true, true, 0, false, 0);
 #undef BWDF
             return antmmf_check_launch();
         }

@@ -274,6 +274,25 @@ def test_attention_backward_one_kernel(ops):
     assert lib.antmmf_debug_attn_fused_launches() == n0 + 6
 
 
+def test_attention_backward_one_kernel_persistent_walk():
+    """The persistent form of attn_bwd_fused64_kernel (all sixteen resident key tiles present) on a grid of TWO workgroups (lab knob), so each walks several (b, h) items:
+    the next item's Q / dO pieces land in the rows the current item has finished with, its row statistics go to the second buffer, its K tile is requested after the last
+    dQ contraction -- five items of the 257-token shape with a key mask (3 + 2), cross lengths with a 17th key tile (not persistent: run-time chunk count), exactly sixteen key tiles, nine
+    and thirteen key tiles (a wave without a second tile; a missing half slice)."""
+    import sys
+
+    code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_ATTN_PERSIST_WGS'] = '2';"
+            "import kernel_cases as kc; from antmmf.hip import ops; dev = torch.device('cpu');"
+            "kc.case_attention(ops, dev, B=5, heads=1, Nq=257, Nk=257, bias_kind='bert');"
+            "kc.case_attention(ops, dev, B=2, heads=2, Nq=33, Nk=270, bias_kind='bert', packed=False);"
+            "kc.case_attention(ops, dev, B=3, heads=1, Nq=20, Nk=256, bias_kind='none', packed=False);"
+            "kc.case_attention(ops, dev, B=3, heads=1, Nq=150, Nk=130, bias_kind='bert', packed=False);"
+            "kc.case_attention(ops, dev, B=3, heads=1, Nq=197, Nk=197, bias_kind='inf');"
+            "print('okwalk')" % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=2400)
+    assert "okwalk" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 

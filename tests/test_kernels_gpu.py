@@ -273,7 +273,8 @@ def test_attention(ops, cfg):
 
 
 def test_attention_backward_one_kernel_runs_and_repeats():
-    """attn_bwd_fused64_kernel at the ViT-L/14 tower's shape (16 heads x 257 tokens, packed qkv rows): the lab library's counter says that kernel served the call, two calls
+    """attn_bwd_fused64_kernel at the ViT-L/14 tower's shape (16 heads x 257 tokens, packed qkv rows; 640 (b, h) items on the 256 persistent workgroups: two or three items
+    each, the next one's operands prefetched into the rows the current one has finished with): the lab library's counter says that kernel served the call, two calls
     give BIT-IDENTICAL gradients (dQ is contracted over all keys by one wave in a fixed order: no atomics), and they agree with the two-kernel backward (lab variant bit 3,
     separate process) to bf16 rounding of the outputs."""
     import subprocess
@@ -282,7 +283,7 @@ def test_attention_backward_one_kernel_runs_and_repeats():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import os, sys, ctypes, torch; sys.path[:0] = [%r, %r, %r];"
             "from antmmf.hip import ops, _lib; lib = _lib.load(); lib.antmmf_debug_attn_fused_launches.restype = ctypes.c_long; dev = torch.device('cuda:0');"
-            "g = torch.Generator(device='cuda').manual_seed(3); B, N, h = 8, 257, 16;"
+            "g = torch.Generator(device='cuda').manual_seed(3); B, N, h = 40, 257, 16;"
             "qkv = torch.randn(B, N, 3 * h * 64, generator=g, device=dev).bfloat16(); q, k, v = qkv[..., :h * 64], qkv[..., h * 64:2 * h * 64], qkv[..., 2 * h * 64:];"
             "o, lse = ops.attention_fwd(q, k, v, h, 0.125); do = torch.randn(B, N, h * 64, generator=g, device=dev).bfloat16();"
             "n0 = lib.antmmf_debug_attn_fused_launches(); r1 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125); r2 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125);"

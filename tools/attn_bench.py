@@ -33,8 +33,9 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     out = []
-    B, h = 1024, 16
-    for N in (257, 77):
+    # ATTN_BENCH_SHAPES="1024x16x257,1024x12x197": batch x heads x tokens per entry (default: the two towers of the ViT-L/14 step)
+    shapes = [tuple(int(x) for x in sp.split("x")) for sp in os.environ.get("ATTN_BENCH_SHAPES", "1024x16x257,1024x16x77").split(",")]
+    for B, h, N in shapes:
         qkv = torch.randn(B, N, 3 * h * 64, device=dev).to(torch.bfloat16)
         q, k, v = qkv[..., :h * 64], qkv[..., h * 64:2 * h * 64], qkv[..., 2 * h * 64:]
         dqkv = torch.empty_like(qkv)
