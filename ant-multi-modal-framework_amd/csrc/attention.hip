@@ -935,13 +935,13 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
             _Pragma("unroll") for (int kc = 0; kc < NKS; ++kc) {                                                                            \
                 const bf16x4_t lo_ = lds_read_tr16(sb_ + ds_off(32 * kc + rr, s_q)), hi_ = lds_read_tr16(sb_ + ds_off(32 * kc + 16 + rr, s_q)); \
                 const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                                      \
-                if (kc & 1) g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g1_, 0, 0, 0);       \
-                else g0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, kc, qdt, grp, l15), bf_, g0_, 0, 0, 0);              \
+                if (kc & 1) g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FUSED_KT(kc), bf_, g1_, 0, 0, 0);                                 \
+                else g0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FUSED_KT(kc), bf_, g0_, 0, 0, 0);                                        \
             }                                                                                                                               \
             if constexpr (HASE) {                                                                                                           \
                 const bf16x4_t lo_ = lds_read_tr16(Se + (C) * 1024 + ds_off(rr, s_q));                                                      \
                 const bf16x8_t bf_ = {lo_[0], lo_[1], lo_[2], lo_[3], 0, 0, 0, 0};                                                          \
-                g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<64>(Ks, 8, qdt, grp, l15), bf_, g1_, 0, 0, 0);                    \
+                g1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FUSED_KT(8), bf_, g1_, 0, 0, 0);                                              \
             }                                                                                                                               \
             const int qi_ = 32 * (C) + 16 * qqt + l15;                                                                                      \
             if (qi_ < a.Nq)                                                                                                                 \
@@ -1186,6 +1186,18 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     }
     const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
     const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
+    // KREG: the K^T fragments of this wave's head-dim tile -- the same for every chunk -- in registers (36 VGPRs): 18 transposing reads less per chunk, and the K tile is
+    // free as soon as every wave holds its fragments, so the NEXT item's K is requested here, under the whole main loop, instead of at the item boundary where nothing hides
+    // it (1.69 -> 1.57 ms, profiles/r5_attn_bwd_one_kernel_k_in_registers_ab.txt; ABL bit 7 switches it OFF: the A/B)
+    constexpr bool KREG = PERSIST && !(ABL & 128);
+    bf16x8_t ktf[KREG ? 9 : 1];
+    if constexpr (KREG) {
+#pragma unroll
+        for (int kc = 0; kc < NKS + (HASE ? 1 : 0); ++kc) ktf[kc] = frag_tokens<64>(Ks, kc < NKS ? kc : 8, qdt, grp, l15);
+        wg_barrier_lds_only();
+        if (has_next) FUSED_DMA_K(nxt);
+    }
+#define FUSED_KT(KC) (KREG ? ktf[KREG ? ((KC) < NKS ? (KC) : NKS) : 0] : frag_tokens<64>(Ks, (KC), qdt, grp, l15))
 
     const int nqc2 = (a.Nq + 15) >> 5;   // chunks whose second query tile holds queries
     int c = 0;
@@ -1197,7 +1209,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, FUSED_POST(c));
 #undef FUSED_POST
         wg_barrier_lds_only();   // every wave is through its last dQ contraction: K and the dS^T buffers are free
-        if (has_next) FUSED_DMA_K(nxt);
+        if (!KREG && has_next) FUSED_DMA_K(nxt);
     } else {
         for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, (void)0);
         for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, (void)0);
@@ -1217,6 +1229,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     }
     if constexpr (PERSIST) { if (has_next) FUSED_PREFETCH_REGS(nxt); }   // (behind the stores: the accumulators' registers are free now; all of it lands under the K tile's latency)
     } while (PERSIST && (item += gridDim.x) < n_items);
+#undef FUSED_KT
 #undef FUSED_DMA_K
 #undef FUSED_DMA_QD
 #undef FUSED_PREFETCH_REGS
@@ -1307,6 +1320,7 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                     case 16: BWDF(8, true, true, 9, true, 16); return antmmf_check_launch();
                     case 32: BWDF(8, true, true, 9, true, 32); return antmmf_check_launch();
                     case 15: BWDF(8, true, true, 9, true, 15); return antmmf_check_launch();
+                    case 128: BWDF(8, true, true, 9, true, 128); return antmmf_check_launch();
                     default: break;
                 }
             }
