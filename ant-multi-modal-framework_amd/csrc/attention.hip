@@ -33,7 +33,7 @@
 // are recomputed in both backward kernels), in practice bounded by the softmax VALU work (~10 VALU slots per score) --
 // and, at these lengths, nearer to an HBM floor than to either: a 257-token head moves 2*64*N bytes per tensor pass against
 // 4*N*N*64 flop, i.e. N / 2 = 128 flop per byte where the part needs ~ 470.  Forward: 4 passes (0.41 ms of the 0.75 measured
-// at 1024 x 16 x 257), two-kernel backward: 13 passes (1.32 of 2.06 ms), one-kernel backward below: 8 passes (0.81 of 1.67 ms).
+// at 1024 x 16 x 257), two-kernel backward: 13 passes (1.32 of 2.07 ms), one-kernel backward below: 8 passes (0.81 of 1.55 ms).
 // Algorithmic HBM bytes per (b, h): fwd 2*64*(2Nq + 2Nk) + 4Nq.
 #include "common.h"
 #include <cstdlib>
