@@ -845,9 +845,9 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 // (16 consecutive keys x one slot) and the transposing reads (8 consecutive keys x 4 slots of one query tile) sweep all banks.
 __device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
 __device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
-static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool persist = false) {
+static inline size_t attn_fused_lds_bytes(int Nq, int Nk) {
     const int nqp = ((Nq + 31) / 32) * 32;
-    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;   // (persist: same footprint)
+    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
 }
 static inline bool attn_fused_ok(const AttnArgs& a) {
     return !a.drop_thr && a.Nk > 128 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;
@@ -1298,8 +1298,8 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
 #endif
             const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16, n_items = a.B * a.heads;
             // all sixteen resident key tiles present (the 197- / 257-token towers): the persistent form, one workgroup per CU walking the items
-            const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk, true) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
-            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk, persist);
+            const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
+            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk);
             unsigned pwgs = 256u;
 #ifdef ANTMMF_LAB
             static const char* pw_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_PERSIST_WGS");   // lab / emulator tests: a small grid makes every workgroup walk several items
@@ -1376,6 +1376,8 @@ extern "C" int antmmf_attention_bwd_hd(const void* q, const void* k, const void*
     a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !attn_args_ok(a, head_dim) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))
         return ANTMMF_EINVAL;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o | (uintptr_t)o) & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7))
+        return ANTMMF_EINVAL;   // 16-byte operand vectors (and LDS-DMA pieces), 8-byte gradient stores
     return head_dim == 64 ? attn_bwd_launch<64>(a, stream) : attn_bwd_launch<128>(a, stream);
 }
 

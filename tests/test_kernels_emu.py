@@ -293,6 +293,17 @@ def test_attention_backward_one_kernel_persistent_walk():
     assert "okwalk" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_attention_backward_rejects_misaligned_operands(ops):
+    """16-byte operand vectors / LDS-DMA pieces: a q view that starts 8 bytes into an allocation is ANTMMF_EINVAL, not a fault."""
+    B, N, h = 1, 130, 1
+    buf = torch.zeros(B * N * 64 + 8, dtype=torch.bfloat16)
+    q_bad = buf[4:4 + B * N * 64].view(B, N, 64)
+    k = torch.zeros(B, N, 64, dtype=torch.bfloat16); v = torch.zeros_like(k); o = torch.zeros_like(k); d_o = torch.zeros_like(k)
+    lse = torch.zeros(B, h, N)
+    with pytest.raises(RuntimeError, match="code -22"):
+        ops.attention_bwd(q_bad, k, v, o, lse, d_o, h, 0.125)
+
+
 def test_attention_cross_multichunk(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=21, Nk=77, bias_kind="bert", packed=False)
 
