@@ -845,12 +845,12 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 // (16 consecutive keys x one slot) and the transposing reads (8 consecutive keys x 4 slots of one query tile) sweep all banks.
 __device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
 __device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
-static inline size_t attn_fused_lds_bytes(int Nq, int Nk) {
+static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool early = false) {
     const int nqp = ((Nq + 31) / 32) * 32;
-    return (size_t)nqp * 256 + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
+    return (size_t)nqp * 256 * (early ? 2 : 1) + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
 }
 static inline bool attn_fused_ok(const AttnArgs& a) {
-    return !a.drop_thr && a.Nk > 128 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;
+    return !a.drop_thr && a.Nk > 32 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;   // (one or two key tiles: the two-kernel form)
 }
 
 // one score block: 16 queries (tile at q0) x the 16 keys of (kf, vf): p = softmax probabilities, ds = p * (dP - D).  Lane: key l15, queries q0 + 4 grp + r.
@@ -890,6 +890,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
 #define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
     do {                                                                                                                                    \
         char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
+        if (tva) {   /* (a wave without a key tile -- fewer than eight tiles: the short towers -- only contracts its dQ tile) */               \
         float p_[2][2][4], ds_[2][2][4];   /* [tile][query tile][r] */                                                                      \
         _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                                                  \
             if (hh < (NH)) {                                                                                                                \
@@ -927,6 +928,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
                 dk[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_, dsf_[1], dk[1][dt], 0, 0, 0);                                      \
             }                                                                                                                               \
         }                                                                                                                                   \
+        }                                                                                                                                   \
         BEFORE;                                                                                                                             \
         if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in sb_; nobody reads this chunk's Q / dO rows any more */ \
         AFTER;                                                                                                                              \
@@ -961,13 +963,14 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
 // contraction, in front of this item's dK / dV stores.
 // ABL (lab library only, TIMING-ONLY, wrong results): 1 no dQ contraction, 2 no per-chunk barrier, 4 the exponential replaced by its argument, 8 no dV / dK contraction,
 // 16 no D = rowsum(dO o O) pass in the prologue, 32 no extra key tile -- what each part of the kernel costs, same box, same process.
-template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0>
+// EARLY (persistent form of the short towers, where LDS and registers allow it): Q / dO tiles double-buffered and EVERYTHING of the next item -- K, Q, dO, the register
+// prefetch -- requested at the START of the current one, so the item boundary waits for nothing.  (The long towers have neither the 74 KB nor the 45 VGPRs.)
+template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0, bool EARLY = false>
 __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const AttnArgs a, int NQP, int n_items) {
     ANTMMF_DYN_LDS(char, smem);
     const int nkt = (a.Nk + 15) >> 4, nkr = nkt < 16 ? nkt : 16, nqc = NQC ? NQC : NQP >> 5;   // key tiles, resident key tiles, query chunks
-    char* Qs = smem;
-    char* Ds = Qs + NQP * 128;
-    char* Ks = Ds + NQP * 128;
+    const int qd_bytes = NQP * 256;   // a Q tile + a dO tile
+    char* Ks = smem + (EARLY ? 2 : 1) * qd_bytes;
     char* Sb = Ks + 288 * 128;
     char* Se = Sb + 2 * 16384;
     float* stats = reinterpret_cast<float*>(Se + (HASE ? nqc * 1024 : 0));   // [lse | dsum][NQP], both negated: accumulator start values
@@ -987,15 +990,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
 #define FUSED_DMA_K(ITEM)                                                                                                                    \
     do {                                                                                                                                    \
         const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                             \
-        for (int pc_ = wave; pc_ < 36; pc_ += ATTN_THREADS / 64)                                                                            \
+        for (int pc_ = wave; pc_ < (HASE ? 36 : 4 * NKS); pc_ += ATTN_THREADS / 64)   /* (the rows the contractions read) */                \
             attn_dma_piece(Ks, lds0 + (uint32_t)(Ks - smem), a.k + (long)b_ * a.Nk * a.ldk + h_ * 64, a.ldk, a.Nk, pc_, lane);              \
     } while (0)
     // chunk C of Q (waves 0 - 3) and dO (waves 4 - 7): one piece per wave
-#define FUSED_DMA_QD(ITEM, C)                                                                                                                \
+#define FUSED_DMA_QD(ITEM, C, QB)   /* QB: byte offset of the destination Q tile (its dO tile follows it) */                                   \
     do {                                                                                                                                    \
         const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                             \
-        if (wave < 4) attn_dma_piece(Qs, lds0, a.q + (long)b_ * a.Nq * a.ldq + h_ * 64, a.ldq, a.Nq, 4 * (C) + wave, lane);                 \
-        else attn_dma_piece(Ds, lds0 + (uint32_t)(Ds - smem), a.d_o + (long)b_ * a.Nq * a.lddo + h_ * 64, a.lddo, a.Nq, 4 * (C) + wave - 4, lane); \
+        if (wave < 4) attn_dma_piece(smem + (QB), lds0 + (uint32_t)(QB), a.q + (long)b_ * a.Nq * a.ldq + h_ * 64, a.ldq, a.Nq, 4 * (C) + wave, lane); \
+        else attn_dma_piece(smem + (QB) + NQP * 128, lds0 + (uint32_t)((QB) + NQP * 128), a.d_o + (long)b_ * a.Nq * a.lddo + h_ * 64, a.lddo, a.Nq, 4 * (C) + wave - 4, lane); \
     } while (0)
     // what an item needs in REGISTERS, requested while the previous item's dK / dV stores drain: its O rows in the staging pattern of the token tiles (thread -> row id >> 3,
     // 16-B slot id & 7, id = thread + 512 i) for D = rowsum(dO o O) -- dO comes out of the landed LDS tile --, its lse row, the V fragments and key biases of this wave's tiles
@@ -1013,7 +1016,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         }                                                                                                                                   \
         pl = -INFINITY;                                                                                                                     \
         if (wave * 64 + lane < a.Nq) pl = a.lse[((long)b_ * a.heads + h_) * a.Nq + wave * 64 + lane];                                       \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                                  \
+        _Pragma("unroll") for (int j_ = 0; j_ < (NKS <= 4 ? 1 : 2); ++j_) {                                                                 \
             const int ki_ = (wave + 8 * j_) * 16 + (lane & 15), krow_ = ki_ < a.Nk ? ki_ : a.Nk - 1;                                        \
             const bf16_t* vp_ = a.v + ((long)b_ * a.Nk + krow_) * a.ldv + h_ * 64 + (lane >> 4) * 8;                                        \
             vfn[j_][0] = load_frag_global(vp_); vfn[j_][1] = load_frag_global(vp_ + 32);                                                    \
@@ -1027,12 +1030,12 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         }                                                                                                                                   \
     } while (0)
 
-    int item = blockIdx.x;
+    int item = blockIdx.x, cur = 0;
     if constexpr (PERSIST) {
         const int lane = lane_w;
         if (item < n_items) {
             FUSED_DMA_K(item);
-            for (int c = 0; c < nqc; ++c) FUSED_DMA_QD(item, c);
+            for (int c = 0; c < nqc; ++c) FUSED_DMA_QD(item, c, 0);
             FUSED_PREFETCH_REGS(item);
         }
     }
@@ -1049,6 +1052,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     const bool has_next = PERSIST && nxt < n_items;
     float* lse_s = stats;
     float* dsum_s = lse_s + NQP;
+    char* Qs = smem + (EARLY ? cur * qd_bytes : 0);
+    char* Ds = Qs + NQP * 128;
     if constexpr (PERSIST) {
         glds_wait_all();         // this wave's pieces of the item, its register prefetch (and everything older) have landed ...
         wg_barrier_lds_only();   // ... and so have the other waves' pieces
@@ -1158,7 +1163,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
 
     // ---- resident key tiles of this wave: `wave` (exists whenever this kernel runs: more than 128 keys) and `wave + 8`
     const int kt[2] = {wave, wave + 8};
-    const bool tvb = FULL || kt[1] < nkr;
+    constexpr bool SMALL = NKS <= 4;   // at most eight key tiles: no wave owns a second one, and waves >= the tile count own none
+    const bool tva = !SMALL || kt[0] < nkr, tvb = !SMALL && (FULL || kt[1] < nkr);
     bf16x8_t kf[2][2], vf[2][2];
     float kbias[2];
     f32x4_t dk[2][4], dv[2][4];
@@ -1177,11 +1183,14 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
     }
-    if (!FULL && !tvb && kt[1] < 2 * NKS) {   // the missing half of the last 32-key slice: its dS^T rows are read by the dQ contraction and never written
+    {   // the missing half of the last 32-key slice: its dS^T rows are read by the dQ contraction and never written
+        const int tz = SMALL ? kt[0] : kt[1];
+        if (!FULL && !(SMALL ? tva : tvb) && tz < 2 * NKS) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(kt[1] * 16 + l15, grp)) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(kt[1] * 16 + l15, 4 + grp)) = make_uint2(0u, 0u);
+            for (int u = 0; u < 2; ++u) {
+                *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(tz * 16 + l15, grp)) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(Sb + u * 16384 + ds_off(tz * 16 + l15, 4 + grp)) = make_uint2(0u, 0u);
+            }
         }
     }
     const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
@@ -1197,6 +1206,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         wg_barrier_lds_only();
         if (has_next) FUSED_DMA_K(nxt);
     }
+    if constexpr (EARLY) {
+        static_assert(!EARLY || (PERSIST && !(ABL & 128)), "EARLY needs the persistent form with K^T in registers");
+        if (has_next) {
+            for (int c_ = 0; c_ < nqc; ++c_) FUSED_DMA_QD(nxt, c_, (cur ^ 1) * qd_bytes);   // (the other Q / dO buffer: last read before this item's opening barrier)
+            FUSED_PREFETCH_REGS(nxt);                                                        // (this item's copies were consumed above)
+        }
+    }
 #define FUSED_KT(KC) (KREG ? ktf[KREG ? ((KC) < NKS ? (KC) : NKS) : 0] : frag_tokens<64>(Ks, (KC), qdt, grp, l15))
 
     const int nqc2 = (a.Nq + 15) >> 5;   // chunks whose second query tile holds queries
@@ -1204,19 +1220,20 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     if constexpr (PERSIST) {
         // (measured and not kept, profiles/r5_attn_bwd_one_kernel_l2_warmup_ab.txt: one dword per 64-B half row of the NEXT item's K, V and O requested during chunk 2, so
         // that the K tile's DMA and the register prefetch at the item boundary find their lines in L2: 1.69 -> 1.80 ms)
-#define FUSED_POST(C) do { if (has_next) FUSED_DMA_QD(nxt, (C)); } while (0)
+#define FUSED_POST(C) do { if (!EARLY && has_next) FUSED_DMA_QD(nxt, (C), 0); } while (0)
         for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, FUSED_POST(c));
         for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, FUSED_POST(c));
 #undef FUSED_POST
         wg_barrier_lds_only();   // every wave is through its last dQ contraction: K and the dS^T buffers are free
         if (!KREG && has_next) FUSED_DMA_K(nxt);
+        cur ^= 1;
     } else {
         for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, (void)0);
         for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, (void)0);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        if (j == 1 && !tvb) continue;
+        if (j == 0 ? !tva : !tvb) continue;
         const int ki = kt[j] * 16 + l15, krow = ki < a.Nk ? ki : a.Nk - 1;
         uint2 vw[4], kw[4];
 #pragma unroll
@@ -1227,7 +1244,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         store_rows_paired<4>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * 64, vw, lane, grp, ki < a.Nk, dkv_al16);
         store_rows_paired<4>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * 64, kw, lane, grp, ki < a.Nk, dkv_al16);
     }
-    if constexpr (PERSIST) { if (has_next) FUSED_PREFETCH_REGS(nxt); }   // (behind the stores: the accumulators' registers are free now; all of it lands under the K tile's latency)
+    if constexpr (PERSIST && !EARLY) { if (has_next) FUSED_PREFETCH_REGS(nxt); }   // (behind the stores: the accumulators' registers are free now; all of it lands under the K tile's latency)
     } while (PERSIST && (item += gridDim.x) < n_items);
 #undef FUSED_KT
 #undef FUSED_DMA_K
@@ -1299,7 +1316,8 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
             const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16, n_items = a.B * a.heads;
             // all sixteen resident key tiles present (the 197- / 257-token towers): the persistent form, one workgroup per CU walking the items
             const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
-            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk);
+            const bool early = persist && nkt <= 8 && attn_fused_lds_bytes(a.Nq, a.Nk, true) <= 160 * 1024;
+            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk, early);
             unsigned pwgs = 256u;
 #ifdef ANTMMF_LAB
             static const char* pw_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_PERSIST_WGS");   // lab / emulator tests: a small grid makes every workgroup walk several items
@@ -1329,7 +1347,16 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                 if (nkt > 16) BWDF(8, true, true, 9, true, 0);
                 else if (nkt == 16) BWDF(8, false, true, 0, true, 0);
                 else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0, true, 0); else BWDF(7, false, false, 0, true, 0); }
-                else { if (nkt > 10) BWDF(6, false, false, 0, true, 0); else BWDF(5, false, false, 0, true, 0); }
+                else if (nkt > 8) { if (nkt > 10) BWDF(6, false, false, 0, true, 0); else BWDF(5, false, false, 0, true, 0); }
+                else if (early) {
+#define BWDE(NKS) do { set_lds(attn_bwd_fused64_kernel<NKS, false, false, 0, true, 0, true>, lds); \
+            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, false, false, 0, true, 0, true>), pgrid, block, lds, stream, a, nqp, n_items); } while (0)
+                    if (nkt > 6) BWDE(4); else if (nkt > 4) BWDE(3); else BWDE(2);
+#undef BWDE
+                }
+                else if (nkt > 6) BWDF(4, false, false, 0, true, 0);
+                else if (nkt > 4) BWDF(3, false, false, 0, true, 0);
+                else BWDF(2, false, false, 0, true, 0);
             } else BWDF(8, true, true, 0, false, 0);
 #undef BWDF
             return antmmf_check_launch();

@@ -255,7 +255,7 @@ def test_attention_fwd32_opt_in(variant):
 
 
 def test_attention_backward_one_kernel(ops):
-    """attn_bwd_fused64_kernel (head size 64, 128 < keys <= 272, no dropout): the 257-token towers (a 17th key tile with ONE valid key, a last chunk with one valid query),
+    """attn_bwd_fused64_kernel (head size 64, 32 < keys <= 272, no dropout): the 257-token towers (a 17th key tile with ONE valid key, a last chunk with one valid query),
     even / odd numbers of resident key tiles (a missing half slice), masked keys incl. -inf, cross lengths either way, the largest size; the shorter cases above keep
     exercising the two-kernel backward."""
     import ctypes
@@ -270,7 +270,7 @@ def test_attention_backward_one_kernel(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=20, Nk=256, bias_kind="none", packed=False)
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=288, Nk=272, bias_kind="inf", packed=False)
     assert lib.antmmf_debug_attn_fused_launches() == n0 + 6, "the one-kernel backward did not run"
-    kc.case_attention(ops, DEV, B=1, heads=1, Nq=40, Nk=128, bias_kind="none", packed=False)   # (at the boundary: two kernels)
+    kc.case_attention(ops, DEV, B=1, heads=1, Nq=40, Nk=32, bias_kind="none", packed=False)   # (one or two key tiles: two kernels)
     assert lib.antmmf_debug_attn_fused_launches() == n0 + 6
 
 
@@ -278,7 +278,8 @@ def test_attention_backward_one_kernel_persistent_walk():
     """The persistent form of attn_bwd_fused64_kernel (all sixteen resident key tiles present) on a grid of TWO workgroups (lab knob), so each walks several (b, h) items:
     the next item's Q / dO pieces land in the rows the current item has finished with, its row statistics go to the second buffer, its K tile is requested after the last
     dQ contraction -- five items of the 257-token shape with a key mask (3 + 2), cross lengths with a 17th key tile (not persistent: run-time chunk count), exactly sixteen key tiles, nine
-    and thirteen key tiles (a wave without a second tile; a missing half slice)."""
+    and thirteen key tiles (a wave without a second tile; a missing half slice), and the short towers: five, three and eight key tiles (waves without any tile, which only
+    contract their dQ tile)."""
     import sys
 
     code = ("import os, sys, torch; sys.path[:0] = [%r, %r, %r]; os.environ['ANTMMF_HIP_LIB'] = %r; os.environ['ANTMMF_ATTN_PERSIST_WGS'] = '2';"
@@ -288,6 +289,9 @@ def test_attention_backward_one_kernel_persistent_walk():
             "kc.case_attention(ops, dev, B=3, heads=1, Nq=20, Nk=256, bias_kind='none', packed=False);"
             "kc.case_attention(ops, dev, B=3, heads=1, Nq=150, Nk=130, bias_kind='bert', packed=False);"
             "kc.case_attention(ops, dev, B=3, heads=1, Nq=197, Nk=197, bias_kind='inf');"
+            "kc.case_attention(ops, dev, B=5, heads=1, Nq=77, Nk=77, bias_kind='bert');"
+            "kc.case_attention(ops, dev, B=3, heads=1, Nq=288, Nk=33, bias_kind='inf', packed=False);"
+            "kc.case_attention(ops, dev, B=3, heads=1, Nq=40, Nk=128, bias_kind='none', packed=False);"
             "print('okwalk')" % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=2400)
     assert "okwalk" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
