@@ -828,7 +828,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
     }
 }
 
-// ---- backward in ONE kernel (head size 64, 128 < Nk <= 272, no dropout: the 257-token image towers) -----------------------------------------------------
+// ---- backward in ONE kernel (head size 64, 32 < Nk <= 272, no dropout: every tower of the contrastive step) --------------------------------------------------
 // Why: at these lengths the backward is closer to its HBM floor than to the MFMA peak -- the two kernels above read Q, K, V, dO, O TWICE and form the
 // scores, dP and the exponentials twice (13 tensor passes, 14 flop units, 2 exponentials per score); one kernel needs 8 passes, 10 units, 1 exponential.
 // How: a workgroup owns one (b, h) with Q, dO AND K token tiles resident in LDS.  Wave w owns the key tiles w and w + 8 (dK / dV accumulators in registers

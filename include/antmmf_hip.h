@@ -184,7 +184,7 @@ int antmmf_attention_fwd(const void* q, const void* k, const void* v, const floa
                          int B, int heads, int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          float scale, float dropout_p, uint64_t dropout_seed, antmmf_stream_t stream);
 /* dq/dk/dv use the same addressing as q/k/v (lddq, lddk, lddv); `o` and `lse` are the forward outputs.  Bit-reproducible (no atomics on any path).  Which kernels run is
- * the library's business: head size 64 with 129 ... 272 keys and no dropout goes to one persistent kernel (8 tensor passes over HBM), everything else to a dQ and a
+ * the library's business: head size 64 with 33 ... 272 keys and no dropout goes to one persistent kernel (8 tensor passes over HBM), everything else to a dQ and a
  * dK / dV kernel (13 passes); the results agree to the rounding of the bf16 outputs.  q, k, v, d_o, o must be 16-byte aligned with row strides that are multiples of 8
  * elements, dq, dk, dv 8-byte aligned with strides that are multiples of 4 (checked on entry: ANTMMF_EINVAL otherwise). */
 int antmmf_attention_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,

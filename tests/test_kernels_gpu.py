@@ -258,7 +258,7 @@ def test_gemm_persistent_uneven_rounds(ops):
     dict(B=2, heads=8, Nq=100, Nk=100, bias_kind="none", head_dim=128),               # ViLBERT: 8 heads x 128, 100 regions
     dict(B=3, heads=8, Nq=37, Nk=100, bias_kind="bert", packed=False, head_dim=128),  # text queries over image regions, additive mask
     dict(B=2, heads=2, Nq=288, Nk=257, bias_kind="inf", packed=False, head_dim=128),  # the largest tiles (147 KB of LDS)
-    # the one-kernel backward (head size 64, 128 < keys <= 272; the 197- and 257-token cases above run on it too): masks on the 17-tile case, a missing half slice,
+    # the one-kernel backward (head size 64, 32 < keys <= 272; the 77-, 197- and 257-token cases above run on it too): masks on the 17-tile case, a missing half slice,
     # cross lengths either way, the tile boundary, the largest size
     dict(B=2, heads=16, Nq=257, Nk=257, bias_kind="bert"),
     dict(B=3, heads=2, Nq=200, Nk=200, bias_kind="inf"),
