@@ -127,7 +127,8 @@ def test_product_kernel_resources():
             ("gemm_nt_k64r_kernel<5, 0>", 256), ("gemm_nt_k64r_kernel<8, 0>", 248), ("gemm_tn_k64_kernel<1>", 256), ("gemm_nt_k64p_kernel<8, 37>", 256),
             ("attn_fwd_kernel<9, false, 64>", 128), ("attn_fwd_kernel<3, false, 64>", 128), ("attn_bwd_dq64_kernel<9, false>", 128), ("attn_bwd_dq64_kernel<3, false>", 128),
             ("attn_bwd_dkv_kernel<false, 64>", 128),
-            ("attn_bwd_fused64_kernel<8, true, true, 9, true, 0>", 256), ("attn_bwd_fused64_kernel<7, false, false, 0, true, 0>", 256)]   # one 8-wave workgroup per CU (151 KB of LDS)
+            ("attn_bwd_fused64_kernel<8, true, true, 9, true, 0, false>", 256), ("attn_bwd_fused64_kernel<7, false, false, 0, true, 0, false>", 256),
+            ("attn_bwd_fused64_kernel<3, false, false, 0, true, 0, true>", 256)]   # one 8-wave workgroup per CU (151 KB of LDS)
     for name, vmax in must:
         assert name in by, f"{name} is not in the product library"
         k = by[name]
