@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: the one-kernel attention backward (attn_bwd_fused64_kernel) -- tests, same-box A/B against the two-kernel backward (lab variant bit 3), per-kernel time, the l14 step
-TAG=${1:-r5m}
+TAG=${1:-r5k}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 ROOT=$(pwd)
 LAB=$ROOT/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: where the one-kernel attention backward spends its time -- SQ counter passes + timing-only ablations (lab library) on the 1024 x 16 x 257 shape
-TAG=${1:-r5n}
+TAG=${1:-r5l}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 ROOT=$(pwd)
 export ANTMMF_HIP_LIB=$ROOT/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so
