@@ -887,7 +887,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
 
 // one 32-query chunk C of attn_bwd_fused64_kernel.  NH = 2: both 16-query tiles hold queries; NH = 1: the second one is pure padding (no score work, zero dS^T rows).
 // BEFORE / AFTER: statements run by every wave before / after the chunk's workgroup barrier (the persistent form's prefetch of the next item).
-#define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
+#define FUSED_CHUNK_SCORE(C, NH)                                                                                                           \
     do {                                                                                                                                    \
         char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
         if (tva) {   /* (a wave without a key tile -- fewer than eight tiles: the short towers -- only contracts its dQ tile) */               \
@@ -929,9 +929,10 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
             }                                                                                                                               \
         }                                                                                                                                   \
         }                                                                                                                                   \
-        BEFORE;                                                                                                                             \
-        if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in sb_; nobody reads this chunk's Q / dO rows any more */ \
-        AFTER;                                                                                                                              \
+    } while (0)
+#define FUSED_CHUNK_DQ(C, NH)   /* this wave's 16 x 16 tile of chunk C's dQ^T, contracted over all keys out of the chunk's dS^T tile */              \
+    do {                                                                                                                                    \
+        char* sb_ = Sb + ((C) & 1) * 16384;                                                                                                 \
         if (!(ABL & 1) && qqt < (NH)) {                                                                                                     \
             f32x4_t g0_ = {0.f, 0.f, 0.f, 0.f}, g1_ = {0.f, 0.f, 0.f, 0.f};                                                                 \
             _Pragma("unroll") for (int kc = 0; kc < NKS; ++kc) {                                                                            \
@@ -952,17 +953,26 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
                                pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
         }                                                                                                                                   \
     } while (0)
+#define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
+    do {                                                                                                                                    \
+        FUSED_CHUNK_SCORE(C, NH);                                                                                                           \
+        BEFORE;                                                                                                                             \
+        if constexpr (!(ABL & 2)) wg_barrier_lds_only();   /* every wave's dS^T rows of this chunk are in the tile; nobody reads this chunk's Q / dO rows any more */ \
+        AFTER;                                                                                                                              \
+        FUSED_CHUNK_DQ(C, NH);                                                                                                              \
+    } while (0)
 
 // NKS: 32-key slices of the resident key tiles (compile time: the dQ contraction is straight-line code); HASE: a 17th key tile exists; FULL: all sixteen resident
 // tiles exist (no per-wave validity tests); NQC: number of query chunks when known at compile time (the extra tile's contraction), 0 = run-time loop.
 // PERSIST: one workgroup per CU walks the items (b, h) blockIdx.x, blockIdx.x + gridDim.x, ... and hides the NEXT item's loads behind this item's arithmetic --
 // with 151 KB of LDS there is no second workgroup on the CU to do that (timing-only ablations of the non-persistent form, profiles/r5_attn_bwd_one_kernel_v1_*:
 // 1.87 ms of which ~ 1.3 ms remain with the dQ / dV / dK contractions, the exponentials and the barriers all removed).  Q and dO of the next item arrive by LDS-DMA
-// chunk by chunk INTO THE ROWS THE CURRENT ITEM HAS JUST FINISHED WITH (chunk c's rows are dead after the chunk's barrier), its D = rowsum(dO o O) and lse row
-// statistics are formed four rows per wave and chunk from coalesced loads into a second statistics buffer, and its K tile is requested right after the last dQ
-// contraction, in front of this item's dK / dV stores.
+// chunk by chunk INTO THE ROWS THE CURRENT ITEM HAS JUST FINISHED WITH (chunk c's rows are dead after the chunk's barrier), its K tile as soon as every wave holds
+// its K^T fragments in registers (KREG below), and its O rows, lse, V fragments and key biases go into registers behind this item's dK / dV stores; D = rowsum(dO o O)
+// is formed at the item boundary from the landed dO tile and those O rows.
 // ABL (lab library only, TIMING-ONLY, wrong results): 1 no dQ contraction, 2 no per-chunk barrier, 4 the exponential replaced by its argument, 8 no dV / dK contraction,
-// 16 no D = rowsum(dO o O) pass in the prologue, 32 no extra key tile -- what each part of the kernel costs, same box, same process.
+// 16 no O rows (D = rowsum(dO o O) comes out as 0), 32 no extra key tile -- what each part of the kernel costs, same box, same process; and two A/Bs of kept / rejected
+// forms: 128 K^T fragments NOT in registers, 256 the dQ contraction one chunk late (see the main loop).
 // EARLY (persistent form of the short towers, where LDS and registers allow it): Q / dO tiles double-buffered and EVERYTHING of the next item -- K, Q, dO, the register
 // prefetch -- requested at the START of the current one, so the item boundary waits for nothing.  (The long towers have neither the 74 KB nor the 45 VGPRs.)
 template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0, bool EARLY = false>
@@ -1221,8 +1231,34 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         // (measured and not kept, profiles/r5_attn_bwd_one_kernel_l2_warmup_ab.txt: one dword per 64-B half row of the NEXT item's K, V and O requested during chunk 2, so
         // that the K tile's DMA and the register prefetch at the item boundary find their lines in L2: 1.69 -> 1.80 ms)
 #define FUSED_POST(C) do { if (!EARLY && has_next) FUSED_DMA_QD(nxt, (C), 0); } while (0)
+        if constexpr (ABL & 256) {
+            // A/B (lab): the dQ contraction of chunk c - 1 in the SAME barrier interval as the score work of chunk c (independent instruction streams for the scheduler:
+            // MFMA + LDS reads of the one next to the VALU-heavy softmax of the other), still one barrier per chunk and two dS^T buffers.  Measured 1.56 -> 1.60 ms
+            // (profiles/r5_attn_bwd_one_kernel_delayed_dq_ab.txt): not the product's order
+            // (assumes at least one full chunk: the instantiation this A/B exists for has eight and one padded chunk)
+            FUSED_CHUNK_SCORE(0, 2);
+            wg_barrier_lds_only();
+            FUSED_POST(0);
+            for (c = 1; c < nqc2; ++c) {
+                FUSED_CHUNK_SCORE(c, 2);
+                FUSED_CHUNK_DQ(c - 1, 2);
+                wg_barrier_lds_only();
+                FUSED_POST(c);
+            }
+            if (c < nqc) {   // the padded chunk (at most one)
+                FUSED_CHUNK_SCORE(c, 1);
+                FUSED_CHUNK_DQ(c - 1, 2);
+                wg_barrier_lds_only();
+                FUSED_POST(c);
+                FUSED_CHUNK_DQ(c, 1);
+                ++c;
+            } else {
+                FUSED_CHUNK_DQ(c - 1, 2);
+            }
+        } else {
         for (; c < nqc2; ++c) FUSED_CHUNK(c, 2, (void)0, FUSED_POST(c));
         for (; c < nqc; ++c) FUSED_CHUNK(c, 1, (void)0, FUSED_POST(c));
+        }
 #undef FUSED_POST
         wg_barrier_lds_only();   // every wave is through its last dQ contraction: K and the dS^T buffers are free
         if (!KREG && has_next) FUSED_DMA_K(nxt);
@@ -1252,6 +1288,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
 #undef FUSED_PREFETCH_REGS
 }
 #undef FUSED_CHUNK
+#undef FUSED_CHUNK_SCORE
+#undef FUSED_CHUNK_DQ
 #undef FUSED_SCORE_BLOCK
 #undef FUSED_EXP
 
@@ -1339,6 +1377,7 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                     case 32: BWDF(8, true, true, 9, true, 32); return antmmf_check_launch();
                     case 15: BWDF(8, true, true, 9, true, 15); return antmmf_check_launch();
                     case 128: BWDF(8, true, true, 9, true, 128); return antmmf_check_launch();
+                    case 256: BWDF(8, true, true, 9, true, 256); return antmmf_check_launch();
                     default: break;
                 }
             }
