@@ -151,11 +151,13 @@ class _Rows:
         mine = torch.full((1,), B, dtype=torch.int64, device=device)
         counts = torch.empty(self.world, dtype=torch.int64, device=device)
         dist.all_gather_into_tensor(counts, mine, group=group)
-        # a rank with MORE rows than the static maximum cannot be padded.  It takes part in the count exchange first, so that EVERY rank sees the violation and fails
-        # with it (device-side assert: no host sync on the good path) instead of the others blocking in the next collective behind a rank that raised alone
-        torch._assert_async((counts <= int(max_rows)).all(), f"a rank holds more rows than max_rows = {max_rows} (contrastive.set_max_rows_per_rank)")
-        if B > max_rows:
-            raise ValueError(f"{B} rows on rank {self.rank} exceed max_rows = {max_rows}")
+        # a rank with MORE rows than the static maximum cannot be padded.  It takes part in the count exchange first and EVERY rank reads the gathered counts on the host, so
+        # all ranks raise the same error together instead of the others blocking in the next collective behind a rank that raised alone.  (One host sync per loss call, on
+        # the ragged path only -- the equal-batch default has none.  Round 5 used torch._assert_async here: stock ROCm wheels compile device-side asserts out, so on the
+        # target the well-behaved ranks saw nothing)
+        most = int(counts.max())
+        if most > int(max_rows):
+            raise ValueError(f"a rank holds {most} rows, more than max_rows = {max_rows} (contrastive.set_max_rows_per_rank); this rank ({self.rank}) holds {B}")
         self.counts = counts
         self.Bg = counts.sum().to(torch.float32)                        # device scalar: the true global batch
         ar = torch.arange(self.Bp, device=device)

@@ -64,6 +64,25 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v);
 template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// 16-B accesses of the row kernels' bf16 tensors.  -DANTMMF_ROW_NT=<bits> (A/B builds only, tools/gpu_r6.sh lnnt; never the product or the lab library) turns them into
+// non-temporal loads (bit 0) / stores (bit 1): the question of VERDICT r5 next #3 (do the streamed-once tensors of the row kernels do better past the caches?)
+typedef unsigned int row_u4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 row_ld16(const void* p) {
+#if defined(ANTMMF_ROW_NT) && (ANTMMF_ROW_NT & 1) && !defined(ANTMMF_EMULATE)
+    const row_u4_t t = __builtin_nontemporal_load(reinterpret_cast<const row_u4_t*>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void row_st16(void* p, uint4 v) {
+#if defined(ANTMMF_ROW_NT) && (ANTMMF_ROW_NT & 2) && !defined(ANTMMF_EMULATE)
+    __builtin_nontemporal_store((row_u4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<row_u4_t*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 // 8-element vector load/store (16 B for bf16, 2 x 16 B for f32); p must be 16-B aligned
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
 template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
@@ -71,7 +90,7 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const uint4 a = row_ld16(p);
     v[0] = bf_lo(a.x); v[1] = bf_hi(a.x); v[2] = bf_lo(a.y); v[3] = bf_hi(a.y);
     v[4] = bf_lo(a.z); v[5] = bf_hi(a.z); v[6] = bf_lo(a.w); v[7] = bf_hi(a.w);
 }
@@ -81,7 +100,7 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    row_st16(p, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])));
 }
 
 // ---- two fp32 per register pair: hipcc turns arithmetic on this type into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two results per
@@ -95,7 +114,7 @@ template <> __device__ __forceinline__ void ld8_f2<float>(const float* p, f2_t (
     v[0] = (f2_t){a.x, a.y}; v[1] = (f2_t){a.z, a.w}; v[2] = (f2_t){b.x, b.y}; v[3] = (f2_t){b.z, b.w};
 }
 template <> __device__ __forceinline__ void ld8_f2<bf16_t>(const bf16_t* p, f2_t (&v)[4]) {
-    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const uint4 a = row_ld16(p);
     v[0] = f2_bf(a.x); v[1] = f2_bf(a.y); v[2] = f2_bf(a.z); v[3] = f2_bf(a.w);
 }
 template <typename T> __device__ __forceinline__ void st8_f2(T* p, const f2_t (&v)[4]);
@@ -104,7 +123,7 @@ template <> __device__ __forceinline__ void st8_f2<float>(float* p, const f2_t (
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
 }
 template <> __device__ __forceinline__ void st8_f2<bf16_t>(bf16_t* p, const f2_t (&v)[4]) {
-    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y));
+    row_st16(p, make_uint4(pack_bf2(v[0].x, v[0].y), pack_bf2(v[1].x, v[1].y), pack_bf2(v[2].x, v[2].y), pack_bf2(v[3].x, v[3].y)));
 }
 
 // wave-wide (64-lane) sum, the same value in every lane.  Device: four DPP adds (xor 1, xor 2, half-row mirror, row mirror: every

@@ -2513,13 +2513,10 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
 #define K64R_ABL_ATTRS(E) do {} while (0)
 #define K64R_ABL_TRY(E, done) do {} while (0)
 #endif
-// (k64p shapes the rolling kernel does not take: the generic epilogue, and R = 128.  The product library serves both with the run-time epilogue form <4>; the lab build
-// keeps the compile-time forms <0 .. 3> of the burst-epilogue kernel for its A/B runs)
-#ifdef ANTMMF_LAB
+// (k64p shapes the rolling kernel does not take -- the generic run-time epilogue, and R = 128 -- go to the BK = 32 ring kernels below in BOTH libraries (round 6; the
+// product used to serve them with the burst kernel's run-time epilogue form gemm_nt_k64p_kernel<4, 33>, 256 VGPRs + 20 B of scratch, off every bench path).  The lab
+// build keeps the burst-epilogue kernel's compile-time forms for its A/B runs: variant bit 14 (every shape) or bit 27 (only the shapes the rolling kernel does not take))
 #define K64P_FALLBACK(E) K64P_LAUNCH(E, PROD | K64F_PRIO)
-#else
-#define K64P_FALLBACK(E) K64P_LAUNCH(4, K64F_ONEBAR | K64F_PRIO)
-#endif
 #define LAUNCH_NT(E)                                                                                                              \
     do {                                                                                                                          \
         static bool once = false;                                                                                                 \
@@ -2531,7 +2528,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_dma_kernel<2, 2, 4, 4, E>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
             once = true;                                                                                                          \
         }                                                                                                                         \
-        if (k64p) {                                                                                                               \
+        if (k64p && ((E < 4 && R >= 192) LAB_ONLY(|| (g_gemm_variant & (16384 | 16 | 128 | 256 | 134217728))))) {                 \
             ++g_k64_launches;                                                                                                     \
             const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);  /* the tile walk needs a multiple of 8 workgroups (XCD = id % 8) */ \
             const unsigned gridp = (g_gemm_variant & 64) ? t8 : (pwgs < t8 ? pwgs : t8);                                          \
@@ -2573,7 +2570,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             LAB_ONLY(else if (g_gemm_variant & 16) K64P_LAUNCH(E, K64F_PRIO | K64F_DIST11);)                                      \
             LAB_ONLY(else if (g_gemm_variant & 128) K64P_LAUNCH(E, PROD);)                                                        \
             LAB_ONLY(else if (g_gemm_variant & 256) K64P_LAUNCH(E, PROD | K64F_PRIO | K64F_CLK);)                                 \
-            else K64P_FALLBACK(E);                                                                                                \
+            LAB_ONLY(else K64P_FALLBACK(E);)                                                                                      \
         }                                                                                                                         \
         else if (big && persist && E < 4 && c_dtype == ANTMMF_BF16 && !(ldc & 7) && (R & 31) == 0 && R >= 128) {                  \
             if (cont) hipLaunchKernelGGL((gemm_nt_pring_kernel<(E < 4 ? E : 0), true>), dim3(pwgs), dim3(512), 131072, stream, g, (int)tiles256); \

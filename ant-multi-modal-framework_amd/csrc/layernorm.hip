@@ -48,7 +48,7 @@ __device__ __forceinline__ void row_sum2(float& a, float& b, float (*sh)[8], int
 template <typename T> struct raw8;
 template <> struct raw8<bf16_t> {
     uint4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load(const bf16_t* p) { v = row_ld16(p); }
     __device__ __forceinline__ void unpack(f2_t (&f)[4]) const { f[0] = f2_bf(v.x); f[1] = f2_bf(v.y); f[2] = f2_bf(v.z); f[3] = f2_bf(v.w); }
 };
 template <> struct raw8<float> {
@@ -422,7 +422,11 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
     // scratch was measured SLOWER: the per-workgroup closing phase dominates).  workgroup-per-row: 1024 workgroups, partials.
     // (re-measured in round 2 with 2x ... 16x the workgroups: 0.31 -> 0.35 / 0.41 / 0.52 / 0.76 ms for 263168 x 1024, 1.58 -> 1.58 / 1.61 / 1.69 / 1.86 ms
     // for the 4096-wide GELU backward -- the column-sum closing phase is per workgroup)
-    const int gw = (int)(want < 512 ? want : 512);
+    // LAB: ANTMMF_ROW_CUS = n sizes the persistent backward grids for n CUs instead of the whole chip (tools/overlap_probe.py: the kernel on a CU-masked stream beside a GEMM)
+    static const char* cus_env = ANTMMF_LAB_ENV("ANTMMF_ROW_CUS");
+    const int row_cus = cus_env ? atoi(cus_env) : 0;
+    const int gw_cap = row_cus > 0 ? 2 * row_cus : 512;
+    const int gw = (int)(want < gw_cap ? want : gw_cap);
     const int gb = (int)(rows < 1024 ? rows : 1024);
     int gb_used = gb;   // the grid the workgroup-per-row kernel was launched with (<= gb: what is resident), = the number of partial rows it wrote
     if (!(wide && partials && partial_elems >= (long)gb * ns * cols)) partials = nullptr;
@@ -431,7 +435,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
 #define LN_BWD_Y(V, BLK, GRID, LDS, A, D, Y) \
     do { \
         int grid_ = GRID; \
-        if (BLK) { static int res_ = 0; if (!res_) res_ = ln_resident_grid(ln_bwd_kernel<T, V, BLK, A, D, Y>, LDS, 1024); grid_ = grid_ < res_ ? grid_ : res_; gb_used = grid_; } \
+        if (BLK) { static int res_ = 0; if (!res_) res_ = ln_resident_grid(ln_bwd_kernel<T, V, BLK, A, D, Y>, LDS, 1024); grid_ = grid_ < res_ ? grid_ : res_; if (row_cus > 0 && grid_ > res_ / 256 * row_cus) grid_ = res_ / 256 * row_cus; gb_used = grid_; } \
         LN_BWD_Z(V, BLK, grid_, LDS, A, D, Y); \
     } while (0)
 #define LN_BWD_Z(V, BLK, GRID, LDS, A, D, Y) hipLaunchKernelGGL((ln_bwd_kernel<T, V, BLK, A, D, Y>), dim3(GRID), dim3(256), LDS, s, (const T*)dy, (const T*)x, mean, rstd, g, (const T*)dres, (T*)dx, dgamma, dbeta, dxsum, rows, cols, act, partials, beta, (T*)yout)

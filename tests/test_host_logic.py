@@ -134,7 +134,7 @@ def test_product_kernel_resources():
         k = by[name]
         assert k["scratch"] == 0 and k["spill_vgpr"] == 0 and k["vgpr"] + k["agpr"] <= vmax, (name, k)
     scratch = sorted(n for n, v in by.items() if v["scratch"])
-    assert scratch in ([], ["gemm_nt_k64p_kernel<4, 33>"]), scratch   # the generic run-time epilogue (activation without a kept output: off the bench paths), 20 B per lane
+    assert scratch == [], scratch   # (round 6: the one kernel that had 20 B per lane, the burst kernel's run-time epilogue form gemm_nt_k64p_kernel<4, 33>, is gone from the product)
     # experiment kernels stay in the lab library
     for n in by:
         assert not n.startswith(("attn_fwd32_kernel", "ffn_")) and "gemm_nt_k64r_kernel<0, 8>" not in n, n
@@ -438,7 +438,7 @@ def _too_many_rows_case(rank, world):
     try:
         contrastive.clip_itc_sharded(t, t.clone(), torch.tensor(1.0), max_rows=3)
     except (ValueError, RuntimeError, AssertionError) as e:
-        return type(e).__name__
+        return type(e).__name__ + ": " + str(e)
     return "no error"
 
 
@@ -446,7 +446,8 @@ def test_ragged_batch_over_the_maximum_fails_on_every_rank():
     if not os.path.exists(os.path.join(ROOT, "tests", "emu", "build", "libantmmf_emu.so")):
         pytest.skip("emulated kernel library not built")
     out = _spawn(_too_many_rows_case, 29649)
-    assert out[0] != "no error" and out[1] != "no error", out
+    # the SAME host-side ValueError on both ranks, raised from the gathered counts (not a device-side assert: stock ROCm wheels compile those out)
+    assert all(out[r].startswith("ValueError: a rank holds 4 rows, more than max_rows = 3") for r in (0, 1)), out
 
 
 def test_base_trainer_data_parallel_two_ranks():
@@ -792,3 +793,57 @@ def test_bench_self_launches_n_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench._self_launch(A())
     assert "exposes 1 GPU" in str(e.value.code)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "prj")), reason="the reference tree is only present in the build container (it never travels to the GPU box)")
+def test_every_shipped_reference_config_loads_unchanged():
+    """north_star: the build "drops into prj/M2_Encoder and the prj/*_vtp configs unchanged".  Every yml the reference ships under prj/*_vtp/configs (91: base / cnvid / snps3 /
+    dmae, their `includes:` chains resolved against the reference's own tree) goes through this build's build_config (antmmf/common/configuration.py:106-139,240-345 there), every
+    prj/M2_Encoder/configs/*.json through the VLMo config loader (vlmo/config.py:22-165).  The files are READ where they lie; nothing of them is copied into the repo."""
+    import glob
+
+    from antmmf.common.build import build_config
+
+    m2 = os.path.join(PKG, "prj", "M2_Encoder")
+    if m2 not in sys.path:
+        sys.path.insert(0, m2)
+    from vlmo.config import default_config, load_json_config
+
+    ymls = sorted(glob.glob(os.path.join(REF, "prj", "*_vtp", "configs", "**", "*.yml"), recursive=True))
+    assert len(ymls) >= 91, len(ymls)
+    heads = {}
+    for y in ymls:
+        cfg = build_config(y)
+        # the framework defaults are underneath every file (training_parameters exists even where the yml has none)
+        assert cfg.training_parameters.trainer, y
+        ma = cfg.get("model_attributes", None)
+        univl = ma.get("univl", None) if ma is not None else None
+        if univl is None:
+            continue
+        # the model section resolves to a mapping with the keys the registry model reads; files that name a head inherit / carry the rest through `includes:`
+        head = univl.get("training_head_type", None)
+        heads[head] = heads.get(head, 0) + 1
+        if head == "video_text_retrieval":
+            assert univl.get("arch_type", None) in ("univl", "clip"), y
+    # the four project trees all ship retrieval configs for this path (base 9, cnvid 7, snps3 7, dmae 9)
+    assert heads.get("video_text_retrieval", 0) >= 32, heads
+    jsons = sorted(glob.glob(os.path.join(REF, "prj", "M2_Encoder", "configs", "*.json")))
+    assert len(jsons) >= 3
+    known = set(default_config())
+    sizes = {}
+    for j in jsons:
+        cfg = load_json_config(j)
+        sizes[os.path.basename(j)] = (cfg["beit_version"], cfg["encoder_layers"], cfg["encoder_embed_dim"], cfg["beit3_vl_layers"])
+        assert cfg["loss_names"]["itc"] in (0, 1) and cfg["image_size"] and cfg["patch_size"]
+        # every key of a shipped json is either one this build's defaults know or one of the named off-path keys it carries through untouched (serving: modelscope /
+        # model_file; data side: whole_word_masking, visual_mask_size; kernel choice of the reference: flash_attn, precision -- this build computes in bf16 on its own
+        # attention kernels whatever they say).  A NEW key in a shipped file fails here instead of being silently ignored.
+        import json as _json
+
+        extra = set(_json.load(open(j))) - known
+        assert extra <= {"flash_attn", "model_file", "modelscope", "precision", "whole_word_masking", "visual_mask_size"}, (j, extra)
+        assert all(k in cfg for k in extra)
+    assert sizes["Encoder_0.4B.json"][:3] == ("base", 9, 768) and sizes["Encoder_1B.json"][:3] == ("large", 21, 1024) and sizes["Encoder_10B.json"][:3] == ("huge", 21, 4096), sizes

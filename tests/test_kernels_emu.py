@@ -149,11 +149,12 @@ def test_gemm_persistent_ring(cont):
     assert "okpersist" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("variant", ["4", pytest.param("20", marks=pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="A/B variant: set ANTMMF_SLOW_TESTS=1"))])
+@pytest.mark.parametrize("variant", ["4", "134217732", pytest.param("134217748", marks=pytest.mark.skipif(not os.environ.get("ANTMMF_SLOW_TESTS"), reason="A/B variant: set ANTMMF_SLOW_TESTS=1"))])
 def test_gemm_k64_persistent(variant):
     """The BK = 64 quarter-phase persistent kernel (default for the large GEMMs) on 2 - 16-tile problems with an 8-workgroup grid, so that
     workgroups walk two tiles and the DMA ring crosses the tile boundary: nk = 2 (no steady state), 3 and 5; every epilogue (staged for
-    plain / bias; register-level lane swap for residual / generic).  variant 20: the 1 / 3 / 3 / 1 DMA distribution."""
+    plain / bias; register-level lane swap for residual / generic).  variant 4 = the dispatch of both libraries (the generic run-time epilogue and R = 128 go to the other
+    kernel families: 9 of the 13 calls are k64 launches); + bit 27: the burst-epilogue kernel's own forms for those shapes (lab A/B only: all 13); + bit 4: the 1 / 3 / 3 / 1 DMA distribution."""
     import subprocess
     import sys
 
@@ -164,8 +165,8 @@ def test_gemm_k64_persistent(variant):
             "kc.case_gemm_k64(ops, dev, I=1024, J=1024, R=128, quick=True);"
             "kc.case_gemm_k64(ops, dev, I=768, J=768, R=320, quick=True);"
             "lib = ctypes.CDLL(os.environ['ANTMMF_HIP_LIB']); lib.antmmf_debug_gemm_k64_launches.restype = ctypes.c_long;"
-            "assert lib.antmmf_debug_gemm_k64_launches() >= 11; print('okk64')"
-            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant))
+            "assert lib.antmmf_debug_gemm_k64_launches() >= %d, lib.antmmf_debug_gemm_k64_launches(); print('okk64')"
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant, 9 if variant == "4" else 13))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
     assert "okk64" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
+#include <cstdlib>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -12,6 +14,10 @@ __device__ __forceinline__ int swz32(int row) { return (0x78 >> (((row >> 2) & 3
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
+// effective shader clock of a launch (sustain mode): workgroup 0 reads the shader cycle counter and the constant 100-MHz counter around its whole run
+__device__ unsigned long long g_clk[2];
+#define CLK_BEGIN() const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define CLK_END() do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - clk_c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; } } while (0)
 template <int N> __device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // MODE bits: 1 = LDS fragment reads, 2 = barrier per step, 4 = DMA ring, 8 = use 32x32x16 MFMA instead (same flops)
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(512) void kstag(const uint16_t* __restrict__ P, con
     constexpr int STAGES = 4, TI = 8, TJ = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wi = wave >> 2, wj = wave & 3, l15 = lane & 15, grp = lane >> 4;
     const bool late = wave >= 4;
+    CLK_BEGIN();
     const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
     f32x4_t acc[TI][TJ];
     for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
@@ -162,6 +169,7 @@ __global__ __launch_bounds__(512) void kstag(const uint16_t* __restrict__ P, con
         for (int a = 0; a < TI; ++a) for (int b = 0; b < TJ; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
         if (s == 123.456f) out[blockIdx.x * 512 + threadIdx.x] = s;
     }
+    CLK_END();
 }
 template <int WITH_STORE>
 void runstag(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(256) void k1wb(const uint16_t* __restrict__ P, cons
     constexpr int STAGES = 4, T = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wi = wave >> 1, wj = wave & 1, l15 = lane & 15, grp = lane >> 4;
     const int i0 = (blockIdx.x / ntiles_j) * 256, j0 = (blockIdx.x % ntiles_j) * 256;
+    CLK_BEGIN();
     f32x4_t acc[T][T];
     for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) acc[a][b] = (f32x4_t){0, 0, 0, 0};
     const uint16_t* src[8]; int dst[8];
@@ -514,6 +523,7 @@ __global__ __launch_bounds__(256) void k1wb(const uint16_t* __restrict__ P, cons
     float s = 0;
     for (int a = 0; a < T; ++a) for (int b = 0; b < T; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
     if (check || s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+    CLK_END();
 }
 void run1wb(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int I, int J, int R) {
     const int tiles = (I / 256) * (J / 256), nk = R / 32;
@@ -742,8 +752,55 @@ void run(const char* name, const uint16_t* P, const uint16_t* Q, float* out, int
     printf("%-46s I=%d J=%d R=%d  %.3f ms  %.1f TFLOP/s\n", name, I, J, R, ms, 2.0 * I * J * R / (ms * 1e-3) / 1e12);
 }
 
-int main() {
+// `gemm_ablate sustain [seconds]`: the two K-loop forms back to back for >= `seconds` each (default 10), wall-clock TFLOP/s per second of the run and the effective shader
+// clock of the last launch -- the figure of merit on a power-capped part is sustained wall-clock throughput, not cycles per K-step (VERDICT r5 next #2a).
+template <typename L>
+static void sustain(const char* name, double flop, double seconds, L launch) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) launch();
+    hipDeviceSynchronize();
+    double total_ms = 0; long n = 0; int window = 0;
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(e0);
+        const int batch = 40;
+        for (int w = 0; w < batch; ++w) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long clk[2] = {0, 1};
+        hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk));
+        total_ms += ms; n += batch;
+        if ((window++ & 3) == 0)
+            printf("{\"kernel\": \"%s\", \"t_s\": %.2f, \"tflops\": %.1f, \"clock_mhz\": %.0f}\n", name, total_ms * 1e-3, flop * batch / (ms * 1e-3) / 1e12, clk[0] / (clk[1] / 100.0));
+    }
+    printf("{\"kernel\": \"%s\", \"sustained_s\": %.1f, \"launches\": %ld, \"tflops_avg\": %.1f}\n", name, total_ms * 1e-3, n, flop * n / (total_ms * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
     const int I = 257 * 256, J = 4096, R = 1024;
+    if (argc > 1 && !strcmp(argv[1], "sustain")) {
+        const double secs = argc > 2 ? atof(argv[2]) : 10.0;
+        uint16_t *P, *Q; float* out;
+        hipMalloc(&P, (size_t)I * 4096 * 2); hipMalloc(&Q, (size_t)4096 * 4096 * 2); hipMalloc(&out, (size_t)I * 4096 * 2);
+        std::vector<uint16_t> h((size_t)4096 * 4096);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x3c00 + (i * 2654435761u >> 20 & 0x3ff));
+        hipMemcpy(Q, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        for (size_t off = 0; off < (size_t)I * 4096; off += h.size()) hipMemcpy(P + off, h.data(), (off + h.size() <= (size_t)I * 4096 ? h.size() : (size_t)I * 4096 - off) * 2, hipMemcpyHostToDevice);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&kstag<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k1wb), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        for (int rep = 0; rep < 2; ++rep) {
+            const int J2 = rep ? 1024 : 4096, R2 = rep ? 4096 : 1024;
+            const int tiles = (I / 256) * (J2 / 256), nk = R2 / 32;
+            const double flop = 2.0 * I * J2 * R2;
+            char nm[96];
+            for (int round = 0; round < 2; ++round) {   // A B A B: drift of the box shows as a difference between the rounds
+                snprintf(nm, sizeof nm, "two_group_8w_128x64 J=%d R=%d round %d", J2, R2, round);
+                sustain(nm, flop, secs, [&]() { hipLaunchKernelGGL(kstag<0>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R2, nk, J2 / 256); });
+                snprintf(nm, sizeof nm, "one_wave_4w_128x128_agpr J=%d R=%d round %d", J2, R2, round);
+                sustain(nm, flop, secs, [&]() { hipLaunchKernelGGL(k1wb, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R2, nk, J2 / 256, 0); });
+            }
+        }
+        return 0;
+    }
     uint16_t *P, *Q; float* out;
     hipMalloc(&P, (size_t)I * 4096 * 2); hipMalloc(&Q, (size_t)4096 * 4096 * 2); hipMalloc(&out, (size_t)I * 4096 * 2);
     std::vector<uint16_t> h((size_t)4096 * 4096);

@@ -1,0 +1,37 @@
+"""Per-(kernel, grid) averages out of a rocprofv3 `*kernel_trace.csv` -- the stats file lumps the image-tower and text-tower launches of a kernel together, this keeps them apart
+(the grid of a row kernel is its row count / 4), so that in-step durations can be set against the isolated ones of tools/ln_bench.py and tools/attn_bench.py.
+
+    python tools/kernel_trace_split.py <kernel_trace.csv> [name-filter ...]      (default filter: ln_ attn_ colsum)
+"""
+import csv
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    keys = sys.argv[2:] or ["ln_", "attn_", "colsum"]
+    acc = {}
+    with open(path) as f:
+        rd = csv.DictReader(f)
+        for r in rd:
+            name = r.get("Kernel_Name") or r.get("Name") or ""
+            if not any(k in name for k in keys):
+                continue
+            grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+            wg = r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "?"
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+            short = name.split("(")[0].replace("void ", "").replace("unsigned short", "bf16")
+            a = acc.setdefault((short, grid, wg), [0, 0.0, 1e9, 0.0])
+            a[0] += 1
+            a[1] += dur
+            a[2] = min(a[2], dur)
+            a[3] = max(a[3], dur)
+    print(f"{'kernel':72s} {'grid':>10s} {'wg':>5s} {'calls':>6s} {'avg ms':>8s} {'min':>8s} {'max':>8s} {'total ms':>9s}")
+    for (short, grid, wg), (n, tot, lo, hi) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        if tot < 0.5:
+            continue
+        print(f"{short[:72]:72s} {grid:>10s} {wg:>5s} {n:6d} {tot / n:8.4f} {lo:8.4f} {hi:8.4f} {tot:9.2f}")
+
+
+if __name__ == "__main__":
+    main()
