@@ -43,7 +43,9 @@ def _assert_equal_batch(n_rows, device, group):
     """The sharded losses and the MoCo queue assume the same number of rows on every rank (row0 = rank * B, all_gather_into_tensor /
     reduce_scatter_tensor take equal shares; the reference instead exchanges sizes and pads on every call,
     distributed_utils.py:131-160).  A tiny all-gather of the local count + a DEVICE-side assert (no host sync) turns a ragged
-    batch into an error instead of a hang or mis-indexed diagonals.  ANTMMF_SKIP_BATCH_CHECK=1 removes it."""
+    batch into an error instead of a hang or mis-indexed diagonals (on this image's wheel a failed device assert aborts the process: measured,
+    profiles/r6_assert_async_probe.txt; a wheel built without device asserts would not notice -- `pad_ragged_batches` is the supported way to
+    run ragged batches and checks on the host).  ANTMMF_SKIP_BATCH_CHECK=1 removes it."""
     import os
 
     if os.environ.get("ANTMMF_SKIP_BATCH_CHECK"):
@@ -153,8 +155,9 @@ class _Rows:
         dist.all_gather_into_tensor(counts, mine, group=group)
         # a rank with MORE rows than the static maximum cannot be padded.  It takes part in the count exchange first and EVERY rank reads the gathered counts on the host, so
         # all ranks raise the same error together instead of the others blocking in the next collective behind a rank that raised alone.  (One host sync per loss call, on
-        # the ragged path only -- the equal-batch default has none.  Round 5 used torch._assert_async here: stock ROCm wheels compile device-side asserts out, so on the
-        # target the well-behaved ranks saw nothing)
+        # the ragged path only -- the equal-batch default has none.  Round 5 used torch._assert_async here; whether a device-side assert fires depends on how the wheel was
+        # built (on this image it does -- as a queue abort that takes the whole process down, profiles/r6_assert_async_probe.txt -- stock ROCm builds compile it out): a
+        # host-side ValueError that every rank raises is the same on every build)
         most = int(counts.max())
         if most > int(max_rows):
             raise ValueError(f"a rank holds {most} rows, more than max_rows = {max_rows} (contrastive.set_max_rows_per_rank); this rank ({self.rank}) holds {B}")

@@ -207,20 +207,27 @@ def layer_norm(x, weight, bias, eps):
 
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) (+ residual).  weight_layout "oi": W is [out, in] (nn.Linear); "io": W is [in, out]
-    (CLIP `proj` / `text_projection`, used as x @ W)."""
+    (CLIP `proj` / `text_projection`, used as x @ W).
+    out_f32 (round 6; small heads whose state must not be rounded to bf16 between layers -- DMAE's temporal transformer): x may be fp32 (rounded to bf16 only as the
+    GEMM's operand: independent per-element errors that average out over the reduction), y and dx are fp32 (the MFMA's fp32 accumulators stored unrounded)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual, weight_layout):
+    def forward(ctx, x, weight, bias, act, residual, weight_layout, out_f32=False):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
+        ctx.x_f32 = x2.dtype == torch.float32
+        if ctx.x_f32:
+            x2 = ops.cast_bf16(x2)
         W = compute_copy(weight)
         io = weight_layout == "io"
         n_out = W.shape[1] if io else W.shape[0]
+        if out_f32 and (act or residual is not None):
+            raise ValueError("linear(out_f32=True): plain bias epilogue only")
         aux = torch.empty(x2.shape[0], n_out, dtype=BF, device=x.device) if act else None
         res2 = residual.reshape(-1, n_out) if residual is not None else None
-        y = ops.gemm(x2, W, q_rmajor=io, bias=f32(bias), act=act, residual=res2, aux=aux)
+        y = ops.gemm(x2, W, q_rmajor=io, bias=f32(bias), act=act, residual=res2, aux=aux, out_dtype=torch.float32 if out_f32 else BF)
         ctx.save_for_backward(x2, weight, bias, aux)
         ctx.act, ctx.io, ctx.shp, ctx.has_res = act, io, shp, residual is not None
         return y.view(*shp[:-1], n_out)
@@ -232,19 +239,24 @@ class _Linear(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         sink = GradSink()
-        du = ops.act_bwd(dy2, aux, ctx.act) if ctx.act else dy2
+        if dy2.dtype == torch.float32:   # out_f32: the bias gradient from the unrounded gradient, the GEMM operand rounded once
+            _bgrad(sink, bias, dy2)
+            dy2 = ops.cast_bf16(dy2)
+            du = dy2
+        else:
+            du = ops.act_bwd(dy2, aux, ctx.act) if ctx.act else dy2
+            _bgrad(sink, bias, du)
         _wgrad(sink, weight, du, x2, w_is_in_out=ctx.io)
-        _bgrad(sink, bias, du)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dgrad(du, weight, "io" if ctx.io else "oi").view(ctx.shp)
+            dx = dgrad(du, weight, "io" if ctx.io else "oi", **(dict(out_dtype=torch.float32) if ctx.x_f32 else {})).view(ctx.shp)
         return (dx, sink.result(weight, ctx.needs_input_grad[1]), sink.result(bias, bias is not None and ctx.needs_input_grad[2]),
-                None, dy if ctx.has_res else None, None)
+                None, dy if ctx.has_res else None, None, None)
 
 
-def linear(x, weight, bias=None, act=None, residual=None, weight_layout="oi"):
+def linear(x, weight, bias=None, act=None, residual=None, weight_layout="oi", out_f32=False):
     _note_untracked(weight, bias)
-    return _Linear.apply(x, weight, bias, act, residual, weight_layout)
+    return _Linear.apply(x, weight, bias, act, residual, weight_layout, out_f32)
 
 
 class _L2Norm(torch.autograd.Function):

@@ -60,9 +60,29 @@ class ResidualAttentionBlockDmae(nn.Module):
                     w1=self.mlp.c_fc.weight, b1=self.mlp.c_fc.bias, w2=self.mlp.c_proj.weight, b2=self.mlp.c_proj.bias)
 
     def forward(self, para_tuple: tuple):
-        """(x [B, N, d] bf16, key_bias [B, N] fp32 additive) -> same tuple (the reference threads (x, attn_mask) the same way)."""
+        """(x [B, N, d], key_bias [B, N] fp32 additive) -> same tuple (the reference threads (x, attn_mask) the same way).  bf16 x: the fused layer.  fp32 x (what
+        TransformerClip hands over by default): the same block with its STATE in fp32, see _forward_f32."""
         x, key_bias = para_tuple
+        if x.dtype == torch.float32:
+            return self._forward_f32(x, key_bias), key_bias
         return HF.transformer_layer(x, self._spec, self._params(), key_bias=key_bias), key_bias
+
+    def _forward_f32(self, x, key_bias):
+        """The block on an fp32 residual stream (round 6).  The temporal transformer sits between the towers and a loss with logit scale 100 (DMAE / CLIP4Clip seqTransf,
+        reference dmae_utils.py:186-227,574-619): with the fused bf16 layer its four layers rounded the residual stream, the LayerNorm outputs and every Linear's output to
+        bf16, and that -- not the towers -- was the larger part of the level-3 loss deviation (measured: head part -1.8e-2 of -1.2e-2 total at toy dims, tests/real_width_case.py).
+        Here the stream, the LayerNorms (fp32 kernels), the Linears' outputs (bf16 MFMA with fp32 accumulators stored unrounded, HF.linear(out_f32=True)) and QuickGELU
+        stay fp32; bf16 appears only as GEMM / attention OPERANDS, whose per-element rounding errors are independent and average out over the reductions.  The tensors
+        are [B, <= 13 frames, 768]: nothing next to the towers."""
+        B, N, d = x.shape
+        h = HF.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.variance_epsilon)
+        qkv = HF.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias, out_f32=True).to(torch.bfloat16)
+        o = HF.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], self.n_head, 64 ** -0.5, key_bias)
+        x = x + HF.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, out_f32=True)
+        h = HF.layer_norm(x, self.ln_2.weight, self.ln_2.bias, self.ln_2.variance_epsilon)
+        u = HF.linear(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, out_f32=True)
+        g = u * torch.sigmoid(1.702 * u)
+        return x + HF.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, out_f32=True)
 
 
 class TransformerClip(nn.Module):
@@ -72,11 +92,15 @@ class TransformerClip(nn.Module):
         self.layers = layers
         self.resblocks = nn.Sequential(*[ResidualAttentionBlockDmae(width, heads) for _ in range(layers)])
 
+    # fp32 residual stream through the blocks (ResidualAttentionBlockDmae._forward_f32); False = the fused bf16 layer (the pre-round-6 behaviour, kept for A/B)
+    FP32_STREAM = True
+
     def forward(self, x: torch.Tensor, attn_mask: torch.Tensor):
         """Reference calling convention: x is LND, attn_mask [B, L, L] additive.  The mask DmaeUtils builds is constant along
         the query axis ((1 - video_mask) * -1e6 expanded, :205-206); row 0 is taken as the per-key bias of the fused kernel."""
         key_bias = attn_mask[:, 0, :].float().contiguous()
-        y, _ = self.resblocks((x.permute(1, 0, 2).contiguous().to(torch.bfloat16), key_bias))
+        xin = x.permute(1, 0, 2).contiguous()
+        y, _ = self.resblocks((xin.float() if self.FP32_STREAM else xin.to(torch.bfloat16), key_bias))
         return y.permute(1, 0, 2)
 
 

@@ -115,14 +115,24 @@ def dmae_stage3(P, image_data, input_ids, input_mask, n_clips, vit_heads, patch,
     vis_embed = towers.bert_embeddings(Pe, inputs_embeds=vis_in, token_type_ids=torch.ones(vis_in.shape[:2], dtype=torch.long))
     vis_mask = torch.ones(b, n_clips + 1)
     _, pooled = towers.roberta_bert_encoder(Pt, input_ids, input_mask, bert_heads)
-    text_l1 = ops.l2_normalize(pooled).unsqueeze(1)
+    return dmae_stage3_head(P, cap_embed, vis_embed, vis_mask, ops.l2_normalize(pooled), input_mask, loss_type, interaction, with_va, sim_header, sim_layers)
+
+
+def dmae_stage3_head(P, cap_embed, vis_embed, vis_mask, text_l1, input_mask, loss_type="negNCE", interaction="wti", with_va=True, sim_header="meanP", sim_layers=2):
+    """The stage-3 head alone, from the token features up (dmae_utils.py:249-278: per-token L2 normalisation, optional seqTransf aggregation, token-wise interaction,
+    loss in both directions): cap_embed [B, T, D] word features, vis_embed [B, V, D] frame features, text_l1 [B, D] the L2-normalised stage-1 sentence embedding.
+    Split out of dmae_stage3 so that the tests can evaluate the fp32 head on the PRODUCT's tower outputs (which part of a level-3 deviation is the towers' bf16 and which
+    the head's)."""
+    text_l1 = text_l1.unsqueeze(1)
     cap_embed = cap_embed / cap_embed.norm(dim=-1, keepdim=True)
     vis_embed = vis_embed / vis_embed.norm(dim=-1, keepdim=True)
     Pd = towers._sub(P, "dmae_utils.")
     agg, tok_mask, _ = towers.dmae_agg_visual_feat(Pd, vis_embed, vis_mask, heads=vis_embed.shape[-1] // 64, layers=sim_layers, sim_header=sim_header)
     simi = losses.dmae_wti_interaction(Pd, text_l1, cap_embed, agg, input_mask.float(), tok_mask, interaction, with_va)
     fn = losses.neg_nce if loss_type == "negNCE" else losses.cross_en
-    return dict(l3_simi=simi, loss=(fn(simi) + fn(simi.t())) / 2)
+    # feats: what DmaeUtils.get_partial_similarity (TPM-CL) is handed next to the score matrix -- the sentence feature [B, 1, D], the normalised word features and the
+    # normalised, NOT aggregated frame features (dmae_utils.py:262-277)
+    return dict(l3_simi=simi, loss=(fn(simi) + fn(simi.t())) / 2, feats=(text_l1, cap_embed, vis_embed, vis_mask))
 
 
 def m2_itc(P, image, text_ids, text_masks, heads, patch, gather=None):

@@ -705,7 +705,7 @@ model = UnivlForVideoTextRetrieval(Configuration(dict(%r, training_stage="stage1
 W.fill_module_(model)
 model = model.to(dev).train()
 P = tiny_models.clip_arch_params(dmae=True)
-bsz, n_clips, rel1, rel3, floor3, serr = 4, 4, [], [], [], []
+bsz, n_clips, rel1, rel3, floor3, serr, head3, tower3 = 4, 4, [], [], [], [], [], []
 for b in range(K):
     img = W.data_tensor(f"dmaek.image.{b}", (bsz, n_clips, 3, 32, 32))
     lengths = W.data_ints(f"dmaek.len.{b}", (bsz,), 3, 13)
@@ -719,21 +719,31 @@ for b in range(K):
         o3 = ostep.dmae_stage3(P, img, ids, mask, n_clips, 2, 8, 2, loss_type="negNCE", sim_header="meanP")
         with torch.autocast("cpu", dtype=torch.bfloat16):
             a3 = float(ostep.dmae_stage3(P, img, ids, mask, n_clips, 2, 8, 2, loss_type="negNCE", sim_header="meanP")["loss"])
+        # which part of the level-3 deviation is the head's and which the towers': the ORACLE's fp32 head evaluated on the PRODUCT's tower outputs (word / frame token features
+        # and the sentence embedding, as handed to DmaeUtils.get_similarity_logits)
+        img_in = dict(image_data=img.to(dev), image_pad_mask=torch.zeros(bsz, n_clips, 32, 32, dtype=torch.bool, device=dev), image_n_clips=[n_clips] * bsz, image_num_frames=[1] * bsz)
+        cap_in, vis_in, _, _ = model.module.get_l2_input(img_in, dict(caption_input_ids=ids.to(dev), caption_input_mask=mask.to(dev), caption_raw_input_ids=ids.to(dev)))
+        h3 = float(ostep.dmae_stage3_head(P, cap_in[0].float().cpu(), vis_in[0].float().cpu(), vis_in[1].float().cpu(), cap_in[2].float().cpu(), mask,
+                                          loss_type="negNCE", sim_header="meanP")["loss"])
     r3 = float(o3["loss"])
     rel1.append((float(out["losses"]["level1_similarity_loss"]) - r1) / abs(r1))
     rel3.append((float(out["losses"]["level3_similarity_loss"]) - r3) / abs(r3))
     floor3.append((a3 - r3) / abs(r3))
+    head3.append((float(out["losses"]["level3_similarity_loss"]) - h3) / abs(r3))   # product head vs fp32 head, same (product) features
+    tower3.append((h3 - r3) / abs(r3))                                             # fp32 head: product features vs fp32 features
     serr.append(float((out["l3_simi"].float().cpu() - o3["l3_simi"]).abs().max()))
 m1 = sum(rel1) / K
 rms = lambda v: (sum(x * x for x in v) / len(v)) ** 0.5
 rep = os.environ.get("ANTMMF_REAL_WIDTH_OUT")
 if rep:
     import json
-    open(rep, "a").write(json.dumps(dict(case="dmae_stage3_loss_contract", level1_rel=rel1, level3_rel=rel3, level3_rel_autocast_oracle=floor3, rms=[rms(rel3), rms(floor3)], scores_max_abs=max(serr))) + "\n")
+    open(rep, "a").write(json.dumps(dict(case="dmae_stage3_loss_contract", level1_rel=rel1, level3_rel=rel3, level3_rel_autocast_oracle=floor3, rms=[rms(rel3), rms(floor3)], scores_max_abs=max(serr),
+                                         level3_head_part=head3, level3_tower_part=tower3, rms_parts=[rms(head3), rms(tower3)])) + "\n")
 assert abs(m1) <= 1e-3 and max(abs(r) for r in rel1) <= 1e-3, (m1, rel1)
 assert max(serr) <= 3e-3, serr
 assert rms(rel3) <= max(8e-3, 1.5 * rms(floor3)) and max(abs(r) for r in rel3) <= 2.5e-2, (rel3, floor3)
-print("okdmaek", "level1 mean", m1, "level3 rel", [round(r, 5) for r in rel3], "autocast-oracle rel", [round(r, 5) for r in floor3], "rms", rms(rel3), rms(floor3), "scores max abs", max(serr))
+print("okdmaek", "level1 mean", m1, "level3 rel", [round(r, 5) for r in rel3], "autocast-oracle rel", [round(r, 5) for r in floor3], "rms", rms(rel3), rms(floor3), "scores max abs", max(serr),
+      "head part", [round(r, 5) for r in head3], "tower part", [round(r, 5) for r in tower3], "rms parts", rms(head3), rms(tower3))
 """ % (ROOT, dev_str, k, TINY_CLIP_CFG, DMAE_E2E)
 
 

@@ -261,6 +261,9 @@ def case_vtp8(dev):
     return rep, gates
 
 
+HEAD_GATE = {}   # per-case gate of the head's part of the level-3 loss deviation (filled from measurements)
+
+
 def case_dmae12(dev, which="dmae12"):
     import tiny_models
     from oracle import step as ostep
@@ -272,16 +275,26 @@ def case_dmae12(dev, which="dmae12"):
     if which == "vtp8t":   # config 3 with its temporal module (bench.py VTP_WORKLOADS["vtp8t"]): 8 frames, 77-token ragged captions, CrossEn
         n, seq, loss_type = 8, 77 if full else 12, "cross_entropy"
         lengths = [seq, 21 if full else 7]
+    # "dmae12tpm" (round 6): the DMAE step with TPM-CL ON at real width -- partial-order margin losses of type 4 (dmae_utils.py:280-463) on the meanP header (the header the
+    # oracle's margin loss restates and ops_dmae_tpmcl.pt pins), 4 videos = one 4 x 4 caption x video block
+    tpm = which == "dmae12tpm"
+    sim_header = "meanP" if tpm else "seqTransf"
+    if tpm:
+        B = 4 if full else 2
     h = c["hidden"]
     # l3_with_nfc False: the second-best-frame term is a function of ARG-max indices (dmae_utils.py:105-118) -- discontinuous in the features, so two correct builds differ by
     # whole terms when a near-tie flips (measured at this width with it on: 5 % on the scores); it is pinned on the reference's own fixtures (ops_dmae_wti.pt, with and without)
-    extra = dict(training_stage="stage1+stage3", with_cross_encoder=False, l3_interaction="wti", l3_with_nfc=False, l3_wti_arch=1, l3_sim_header="seqTransf",
-                 l3_sim_header_hidden_layer=L, l3_partial_type=-1, l3_max_frames=n, l3_max_words=seq, l3_loss_type=loss_type)
+    extra = dict(training_stage="stage1+stage3", with_cross_encoder=False, l3_interaction="wti", l3_with_nfc=False, l3_wti_arch=1, l3_sim_header=sim_header,
+                 l3_sim_header_hidden_layer=L, l3_partial_type=4 if tpm else -1, l3_max_frames=n, l3_max_words=seq, l3_loss_type=loss_type)
     sys.path.insert(0, os.path.join(PKG, "prj", "dmae_vtp"))
     import roi_univl  # noqa: F401
     from antmmf.common.configuration import Configuration
     from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
 
+    if os.environ.get("ANTMMF_DMAE_BF16_STREAM") == "1":   # A/B of the temporal transformer's state precision (round 6): the fused bf16 layer instead of the fp32 stream
+        from roi_univl.univl.model import dmae_utils as _du
+
+        _du.TransformerClip.FP32_STREAM = False
     model = UnivlForVideoTextRetrieval(Configuration(clip_cfg(c, **extra)))
     # the oracle's parameter table = the product model's own names (towers as in tiny_models.clip_arch_shapes + the dmae_utils.* head), filled by name
     P = W.fill_dict({k: tuple(v.shape) for k, v in model.named_parameters()})
@@ -295,17 +308,41 @@ def case_dmae12(dev, which="dmae12"):
     l1, l3 = out["losses"]["level1_similarity_loss"], out["losses"]["level3_similarity_loss"]
     t1 = time.time()
     r1 = ostep.univl_stage1(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"])
-    r3 = ostep.dmae_stage3(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"], loss_type=loss_type, with_va=False, sim_header="seqTransf", sim_layers=L)
+    r3 = ostep.dmae_stage3(P, frames, ids, mask, n, c["heads"], c["patch"], c["bert_heads"], loss_type=loss_type, with_va=False, sim_header=sim_header, sim_layers=L)
+    from oracle import losses as olosses
+    from oracle import towers as otowers
+
+    Pd = otowers._sub(P, "dmae_utils.")
+    r_margin = olosses.dmae_tpmcl_margin_loss(Pd, *r3["feats"][:3], mask.float(), r3["feats"][3], 4) if tpm else None
+    # Which part of the level-3 deviation is the HEAD's and which the TOWERS' (round 6): the oracle's fp32 head -- and its fp32 TPM-CL margin loss -- evaluated
+    # on the PRODUCT's tower outputs (word / frame token features and sentence embedding exactly as DmaeUtils.get_similarity_logits receives them).  head part = product loss -
+    # that; tower part = that - the all-fp32 oracle.
+    with torch.no_grad():
+        cap_in, vis_in, _, _ = model.module.get_l2_input(img_input, cap_input)
+        fp = lambda t: t.detach().float().cpu()   # noqa: E731
+        hmix = ostep.dmae_stage3_head({k: v.detach() for k, v in P.items()}, fp(cap_in[0]), fp(vis_in[0]), fp(vis_in[1]), fp(cap_in[2]), mask, loss_type=loss_type, with_va=False,
+                                      sim_header=sim_header, sim_layers=L)
+        hmix_margin = float(olosses.dmae_tpmcl_margin_loss({k: v.detach() for k, v in Pd.items()}, *hmix["feats"][:3], mask.float(), hmix["feats"][3], 4)) if tpm else 0.0
+    ref3 = float(r3["loss"]) + (float(r_margin) if tpm else 0.0)
+    mix3 = float(hmix["loss"]) + hmix_margin
     # gradient check on a scalar that is alive whatever the scores are (with l3_with_nfc on, this random-weight model's scores are O(1000): NegNCE clamps its softmax at
     # 1e-6 and sits ON the clamp, zero gradient on both sides): the level-3 head is driven through fixed positive weights on the [T, V] token-wise scores
     wpin = (W.data_tensor("fd." + which + ".pin", (B, B)).abs() + 0.5)
-    (r1["loss"] + (r3["l3_simi"] * wpin).sum() / 100.0).backward()
-    t_oracle = time.time() - t1
-    (l1 + (out["l3_simi"].float() * wpin.to(dev)).sum() / 100.0).backward()
+    if tpm:   # the margin loss joins both scalars: its gradient reaches the TPM-CL predictors and, through the features, both towers
+        (r1["loss"] + (r3["l3_simi"] * wpin).sum() / 100.0 + r_margin).backward()
+        t_oracle = time.time() - t1
+        (l1 + (out["l3_simi"].float() * wpin.to(dev)).sum() / 100.0 + (l3 - (model.loss_fct(out["l3_simi"]) + model.loss_fct(out["l3_simi"].t())) / 2)).backward()
+    else:
+        (r1["loss"] + (r3["l3_simi"] * wpin).sum() / 100.0).backward()
+        t_oracle = time.time() - t1
+        (l1 + (out["l3_simi"].float() * wpin.to(dev)).sum() / 100.0).backward()
     rows, zero = cmp_grads(dict(model.named_parameters()), P)
     s3 = out["l3_simi"].detach().float().cpu()
     rep = dict(case=which, full=full, videos=B, frames=n, loss1=float(l1), ref_loss1=float(r1["loss"]), loss1_rel=round((float(l1) - float(r1["loss"])) / abs(float(r1["loss"])), 6),
-               loss3=float(l3), ref_loss3=float(r3["loss"]), loss3_rel=round((float(l3) - float(r3["loss"])) / abs(float(r3["loss"])), 6),
+               loss3=float(l3), ref_loss3=ref3, loss3_rel=round((float(l3) - ref3) / abs(ref3), 6),
+               loss3_head_part=round((float(l3) - mix3) / abs(ref3), 6), loss3_tower_part=round((mix3 - ref3) / abs(ref3), 6),
+               l3_simi_head_part_max_abs=round(float((out["l3_simi"].detach().float().cpu() - hmix["l3_simi"]).abs().max()), 6),
+               margin=dict(ref=float(r_margin), fp32_head_on_product_features=hmix_margin) if tpm else None,
                l3_simi_max_abs=round(float((s3 - r3["l3_simi"].detach()).abs().max()), 6), l3_simi_ref_absmax=round(float(r3["l3_simi"].detach().abs().max()), 4),
                grads=report_rows(rows, ("resblocks.0.", "resblocks.11.", "encoder.layer.0.", "encoder.layer.11.", "dmae_utils", "embeddings")),
                zero_grads=sorted(zero, reverse=True)[:2], seconds=dict(oracle_fwd_bwd=round(t_oracle, 1)))
@@ -321,6 +358,10 @@ def case_dmae12(dev, which="dmae12"):
     # residual stream through the 4 temporal layers is bf16 as well, 5.4 % / 4.0 %: gate 8 %)
     if rep["l3_simi_max_abs"] > 8e-2 * rep["l3_simi_ref_absmax"]:
         gates.append("l3_simi")
+    # round 6: the level-3 loss IS gated now, on the part that is this build's head (given the same tower outputs, the product's head against the fp32 oracle head); the
+    # towers' part (bf16 ViT / BERT features under a logit scale of 100) is reported next to it.  Gate sizes: measured values in profiles/r6_real_width.jsonl
+    if abs(rep["loss3_head_part"]) > HEAD_GATE.get(which, 5e-3):
+        gates.append("loss3_head_part")
     gates += grad_gates(rep["grads"], max_err=0.25, min_cos=0.98, min_global=0.998)
     return rep, gates
 
@@ -329,7 +370,7 @@ def main():
     case = sys.argv[1]
     dev = torch.device(sys.argv[2] if len(sys.argv) > 2 else "cuda:0")
     torch.manual_seed(0)
-    fn = dict(l14=case_l14, b16=lambda d: case_l14(d, "b16"), vtp8=case_vtp8, vtp8t=lambda d: case_dmae12(d, "vtp8t"), dmae12=case_dmae12)[case]
+    fn = dict(l14=case_l14, b16=lambda d: case_l14(d, "b16"), vtp8=case_vtp8, vtp8t=lambda d: case_dmae12(d, "vtp8t"), dmae12=case_dmae12, dmae12tpm=lambda d: case_dmae12(d, "dmae12tpm"))[case]
     rep, gates = fn(dev)
     rep["failed_gates"] = gates
     print("REALWIDTH " + json.dumps(rep, default=lambda o: list(o) if isinstance(o, tuple) else str(o)))

@@ -53,6 +53,28 @@ lnbench)   # isolated row kernels: product library against the non-temporal-load
     lib=$LIBDIR/libantmmf_hip.so; [ $v != base ] && lib=$LIBDIR/libantmmf_hip_rownt$v.so
     ANTMMF_HIP_LIB=$lib timeout 300 python tools/ln_bench.py rownt_$v 2>&1 | grep '^{' | cut -c1-200
   done | tee gpurun_out/${TAG}_ln_bench_rownt_ab.jsonl ;;
+rowpmc)    # HBM-side bytes of the row / attention kernels inside the step and in an isolated loop (separate --pmc passes, kernel trace only)
+  for what in step loop; do
+    P=$ROOT/gpurun_out/${TAG}_rowpmc_$what; mkdir -p $P
+    for c in FETCH_SIZE WRITE_SIZE; do
+      if [ $what = step ]; then cmd="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"; else cmd="python $ROOT/tools/ln_bench.py pmc"; fi
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/$c -o p -- $cmd > $P.$c.log 2>&1); echo "$what $c rc=$?"
+    done
+    python tools/row_pmc.py $P | tee gpurun_out/${TAG}_row_kernels_pmc_$what.txt
+    find $P -type f -delete 2>/dev/null
+  done ;;
+dmaehead)  # level-3 loss deviation split into the head's and the towers' part at real width, temporal transformer on the fused bf16 layer vs the fp32 stream
+  for mode in 1 0; do
+    for c in dmae12 vtp8t dmae12tpm; do
+      echo "--- $c ANTMMF_DMAE_BF16_STREAM=$mode"
+      ANTMMF_DMAE_BF16_STREAM=$mode ANTMMF_REAL_WIDTH_REPORT_ONLY=1 timeout 900 python tests/real_width_case.py $c cuda:0 2>/dev/null | grep REALWIDTH | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l[len('REALWIDTH '):]); d['bf16_stream'] = $mode
+    print(json.dumps({k: d[k] for k in ('case', 'bf16_stream', 'loss1_rel', 'loss3_rel', 'loss3_head_part', 'loss3_tower_part', 'l3_simi_head_part_max_abs', 'l3_simi_max_abs', 'l3_simi_ref_absmax', 'margin', 'failed_gates')}), 'global_cos', d['grads']['global_cos'])
+"
+    done
+  done | tee gpurun_out/${TAG}_dmae_head_tower_split.txt ;;
 asserts)   # does a device-side assert fire on this wheel?  (contrastive._assert_equal_batch relies on torch._assert_async)
   timeout 120 python -c "
 import torch
