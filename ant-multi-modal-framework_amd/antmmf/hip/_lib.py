@@ -45,6 +45,7 @@ _SIGNATURES = {
     "antmmf_gemm_bf16": [P, P, P, I, I, I, L, L, L, I, I, I, F, P, I, P, L, P, L, P, L, I, I, P],
     "antmmf_gemm_bf16_ws": [P, P, P, I, I, I, L, L, L, I, I, I, F, P, I, P, L, P, L, P, L, I, I, P, L, P],
     "antmmf_gemm_wgrad_bf16": [P, P, P, L, I, I, L, L, L, I, P, L, P],
+    "antmmf_gemm_wgrad_bf16_seg": [P, P, P, I, I, L, I, L, L, L, I, P, L, P],
     "antmmf_attention_fwd": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, F, F, U64, P],
     "antmmf_attention_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
     "antmmf_attention_fwd_hd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, F, U64, P],

@@ -208,8 +208,8 @@ def layer_norm(x, weight, bias, eps):
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) (+ residual).  weight_layout "oi": W is [out, in] (nn.Linear); "io": W is [in, out]
     (CLIP `proj` / `text_projection`, used as x @ W).
-    out_f32 (round 6; small heads whose state must not be rounded to bf16 between layers -- DMAE's temporal transformer): x may be fp32 (rounded to bf16 only as the
-    GEMM's operand: independent per-element errors that average out over the reduction), y and dx are fp32 (the MFMA's fp32 accumulators stored unrounded)."""
+    out_f32 (round 6; for small heads whose state should not be rounded to bf16 between layers -- the opt-in fp32 stream of DMAE's temporal transformer): x may be fp32
+    (rounded to bf16 only as the GEMM's operand), y and dx are fp32 (the MFMA's fp32 accumulators stored unrounded)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, residual, weight_layout, out_f32=False):
@@ -632,11 +632,17 @@ class _TransformerLayer(torch.autograd.Function):
             _wgrad(sink, P["wqkv"], dqkv2, h)
             _bgrad(sink, P["bqkv"], dqkv2)
         else:
+            ws_ = [P["w" + nm] for nm in "qkv"]
+            if all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and T >= 4096 and T % 64 == 0:
+                # separate q / k / v projections (BERT, torchscale): ONE wgrad GEMM over the packed dQ | dK | dV, its reduce launch scatters the three row segments into the
+                # three parameters' gradient buffers (round 6: 3072 x 1024 over 263168 tokens is 48 tiles x 5 token splits instead of 3 x (16 tiles x 16 splits))
+                ops.gemm_wgrad_seg_([sink.buf(w) for w in ws_], dqkv2, h)
+            else:
+                for i, nm in enumerate("qkv"):
+                    _wgrad(sink, P["w" + nm], dqkv2[:, i * d:(i + 1) * d], h)
             for i, nm in enumerate("qkv"):
-                sl = dqkv2[:, i * d:(i + 1) * d]
-                _wgrad(sink, P["w" + nm], sl, h)
                 if not (nm == "v" and bv_fused):
-                    _bgrad(sink, P["b" + nm], sl)
+                    _bgrad(sink, P["b" + nm], dqkv2[:, i * d:(i + 1) * d])
         del h
         if ctx.needs_input_grad[0]:
             if not pre_ln:

@@ -366,6 +366,44 @@ def gemm_wgrad_(dW, dY, X, split_k_hint=1):
     return dW
 
 
+def gemm_wgrad_seg_(dWs, dY, X, split_k_hint=1):
+    """dWs[s][seg_rows, k_in] += dY[:, s * seg_rows : (s + 1) * seg_rows]^T X for the <= 4 equally shaped fp32 buffers in `dWs` (unrelated addresses: the separate
+    q / k / v weights of a layer in the gradient arena) as ONE wgrad GEMM over the packed dY (csrc/gemm.hip antmmf_gemm_wgrad_bf16_seg)."""
+    import ctypes
+
+    _dev_ok(dY, X, *dWs)
+    for t, n in ((dY, "dY"), (X, "X")):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
+            raise ValueError(f"gemm_wgrad_seg_: {n} must be a 2-D bf16 tensor with unit inner stride")
+    n_seg = len(dWs)
+    seg_rows, k_in = dWs[0].shape
+    tokens = dY.shape[0]
+    if not 1 <= n_seg <= 4 or dY.shape[1] != n_seg * seg_rows or X.shape != (tokens, k_in):
+        raise ValueError("gemm_wgrad_seg_: shape mismatch")
+    ld = dWs[0].stride(0)
+    for w in dWs:
+        _f32(w, "dW")
+        if tuple(w.shape) != (seg_rows, k_in) or w.stride(1) != 1 or w.stride(0) != ld:
+            raise ValueError("gemm_wgrad_seg_: the segments must have one shape and one row stride")
+    need = 32 * n_seg * seg_rows * k_in
+    key = (dY.device, _stream())
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dY.device)
+        _WGRAD_WS[key] = ws
+    ptrs = (ctypes.c_void_p * n_seg)(*[w.data_ptr() for w in dWs])
+    ev = None
+    if GEMM_TRACE is not None and _lib.backend() == 1:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _rc(_lib.load().antmmf_gemm_wgrad_bf16_seg(_p(dY), _p(X), ctypes.cast(ptrs, ctypes.c_void_p), n_seg, seg_rows, tokens, k_in, dY.stride(0), X.stride(0), ld,
+                                               int(split_k_hint), _p(ws), ws.numel() * 4, _stream()), "antmmf_gemm_wgrad_bf16_seg")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * tokens * n_seg * seg_rows * k_in, "tn", (n_seg * seg_rows, k_in, tokens, "wgrad")))
+    return dWs
+
+
 # ------------------------------------------------------------------------------ M2 feed-forward with the sub-LayerNorm folded into its GEMMs
 _FFN_WS = {}
 

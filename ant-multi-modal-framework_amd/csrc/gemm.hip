@@ -2132,6 +2132,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The same reduction with the output rows cut into up to four equal SEGMENTS that live at unrelated addresses (antmmf_gemm_wgrad_bf16_seg: the q / k / v projection
+// weights of a layer are separate parameters of the gradient arena, their wgrad is ONE token-major GEMM over the packed dQKV)
+struct SegDst { float* p[4]; int rows; };
+static thread_local const SegDst* tl_seg = nullptr;   // set by the _seg entry around its gemm_impl call: host-side dispatch state of that call only
+#define ANTMMF_ESEG (-77)                              /* private: "this shape does not take the workspace path": the _seg entry then runs one call per segment */
+__global__ __launch_bounds__(256) void splitk_reduce_seg_kernel(const float* __restrict__ ws, const SegDst d, int splits, int I, int J, long ldc) {
+    const long nvec = (long)I * J / 4, plane = (long)I * J;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const long e = v * 4;
+        const int i = (int)(e / J), j = (int)(e % J);
+        float4 s = *reinterpret_cast<const float4*>(ws + e);
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(ws + z * plane + e);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int sg = i / d.rows;
+        float4* o = reinterpret_cast<float4*>(d.p[sg] + (long)(i - sg * d.rows) * ldc + j);
+        const float4 c = *o;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        *o = s;
+    }
+}
+
 // ---- 4-stage LDS-DMA ring for wgrad (all-r-major): 256 x 256 output tile, 32 tokens per stage, natural [r][cols] LDS
 // image (512-B rows), fragments by ds_read_b64_tr_b16, split over the token range by gridDim.z (fp32 atomics when split).
 // STAGGER = true (product): the two-group schedule of gemm_nt_ring_kernel; false: one barrier per K-step (kept for A/B runs,
@@ -2437,6 +2460,8 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     if (split_k < 1) split_k = 1;
     if (split_k > nk) split_k = nk;
     if (split_k > 1 && (c_dtype != ANTMMF_F32 || !accumulate || bias || act != ANTMMF_ACT_NONE || residual || aux || gate)) return ANTMMF_EINVAL;
+    // segmented destination (antmmf_gemm_wgrad_bf16_seg): only the BK = 64 wgrad path with its workspace + reduce launch knows it
+    if (tl_seg && !(p_rmajor && q_rmajor && (R & 63) == 0 && (I & 255) == 0 && (J & 255) == 0 && c_dtype == ANTMMF_F32 && accumulate && R >= 4096 && workspace)) return ANTMMF_ESEG;
     GemmArgs g;
     g.P = (const bf16_t*)P; g.Q = (const bf16_t*)Q; g.C = C; g.bias = bias; g.residual = (const bf16_t*)residual;
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
@@ -2649,6 +2674,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             while ((nk64 % k64_steps) == 1) ++k64_steps;   // a trailing split of a single K-tile would have no steady state
             k64_zs = (nk64 + k64_steps - 1) / k64_steps;
         }
+        if (tl_seg && !(k64_steps >= 2 && k64_zs > 1 && workspace_bytes >= (long)k64_zs * I * J * 4)) return ANTMMF_ESEG;
         if (k64_steps >= 2) {
             g.ksteps_per_split = k64_steps;
             const bool ws64 = k64_zs > 1 && workspace && workspace_bytes >= (long)k64_zs * I * J * 4;
@@ -2660,7 +2686,11 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             if (ws64) {
                 const long nvec = (long)I * J / 4;
                 const int rg = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, workspace, reinterpret_cast<float*>(C), k64_zs, I, J, ldc, 1);
+                if (tl_seg) {
+                    const SegDst sd = *tl_seg;   // (a copy made on THIS thread: the CPU lane emulator evaluates launch arguments on its worker threads, where the thread-local is null)
+                    hipLaunchKernelGGL(splitk_reduce_seg_kernel, dim3(rg), dim3(256), 0, stream, workspace, sd, k64_zs, I, J, ldc);
+                }
+                else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, stream, workspace, reinterpret_cast<float*>(C), k64_zs, I, J, ldc, 1);
             }
             return antmmf_check_launch();
         }
@@ -2988,4 +3018,28 @@ extern "C" int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, 
     if (tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;
     return gemm_impl(dY, X, dW, n_out, k_in, (int)tokens, ld_dy, ld_x, ld_dw, 1, 1, ANTMMF_F32, 1.0f, nullptr, ANTMMF_ACT_NONE, nullptr, 0, nullptr, 0,
                      nullptr, 0, 1, split_k_hint, workspace, workspace_bytes, stream);
+}
+
+// The same for n_seg (<= 4) weights of seg_rows x k_in each whose gradients live at unrelated addresses dW[0 .. n_seg) while their dY columns are adjacent
+// (dY[tokens][n_seg * seg_rows]: the packed dQKV of a layer with separate q / k / v projections): ONE wgrad GEMM of n_seg * seg_rows output rows -- fewer, fuller token
+// splits than n_seg launches of seg_rows rows (3072 x 1024: 48 tiles x 5 splits instead of 3 x (16 tiles x 16 splits); a third of the partial-sum traffic) -- whose
+// reduce launch scatters the row segments.  Shapes that do not take the workspace path run as n_seg ordinary calls.
+extern "C" int antmmf_gemm_wgrad_bf16_seg(const void* dY, const void* X, float* const* dW, int n_seg, int seg_rows, long tokens, int k_in, long ld_dy, long ld_x,
+                                          long ld_dw, int split_k_hint, float* workspace, long workspace_bytes, hipStream_t stream) {
+    if (!dW || n_seg < 1 || n_seg > 4 || seg_rows <= 0 || tokens <= 0 || tokens > 0x7fffffffL) return ANTMMF_EINVAL;
+    for (int s = 0; s < n_seg; ++s) if (!dW[s]) return ANTMMF_EINVAL;
+    if (n_seg > 1) {
+        SegDst d; d.rows = seg_rows;
+        for (int s = 0; s < 4; ++s) d.p[s] = dW[s < n_seg ? s : 0];
+        tl_seg = &d;
+        const int rc = gemm_impl(dY, X, dW[0], n_seg * seg_rows, k_in, (int)tokens, ld_dy, ld_x, ld_dw, 1, 1, ANTMMF_F32, 1.0f, nullptr, ANTMMF_ACT_NONE, nullptr, 0, nullptr, 0,
+                                 nullptr, 0, 1, split_k_hint, workspace, workspace_bytes, stream);
+        tl_seg = nullptr;
+        if (rc != ANTMMF_ESEG) return rc;
+    }
+    for (int s = 0; s < n_seg; ++s) {
+        const int rc = antmmf_gemm_wgrad_bf16((const bf16_t*)dY + (long)s * seg_rows, X, dW[s], tokens, seg_rows, k_in, ld_dy, ld_x, ld_dw, split_k_hint, workspace, workspace_bytes, stream);
+        if (rc != ANTMMF_OK) return rc;
+    }
+    return ANTMMF_OK;
 }

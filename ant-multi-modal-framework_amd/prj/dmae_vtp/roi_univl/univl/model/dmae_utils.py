@@ -68,12 +68,11 @@ class ResidualAttentionBlockDmae(nn.Module):
         return HF.transformer_layer(x, self._spec, self._params(), key_bias=key_bias), key_bias
 
     def _forward_f32(self, x, key_bias):
-        """The block on an fp32 residual stream (round 6).  The temporal transformer sits between the towers and a loss with logit scale 100 (DMAE / CLIP4Clip seqTransf,
-        reference dmae_utils.py:186-227,574-619): with the fused bf16 layer its four layers rounded the residual stream, the LayerNorm outputs and every Linear's output to
-        bf16, and that -- not the towers -- was the larger part of the level-3 loss deviation (measured: head part -1.8e-2 of -1.2e-2 total at toy dims, tests/real_width_case.py).
-        Here the stream, the LayerNorms (fp32 kernels), the Linears' outputs (bf16 MFMA with fp32 accumulators stored unrounded, HF.linear(out_f32=True)) and QuickGELU
-        stay fp32; bf16 appears only as GEMM / attention OPERANDS, whose per-element rounding errors are independent and average out over the reductions.  The tensors
-        are [B, <= 13 frames, 768]: nothing next to the towers."""
+        """The block on an fp32 residual stream (round 6 experiment, opt-in through TransformerClip.FP32_STREAM).  The temporal transformer sits between the towers and a
+        loss with logit scale 100 (DMAE / CLIP4Clip seqTransf, reference dmae_utils.py:186-227,574-619); here the stream, the LayerNorms (fp32 kernels), the Linears'
+        outputs (bf16 MFMA with fp32 accumulators stored unrounded, HF.linear(out_f32=True)) and QuickGELU stay fp32 and bf16 appears only as GEMM / attention OPERANDS.
+        Against the reference run of ops_dmae_seqtransf.pt the output error goes from 0.37 % to 0.26 % rms -- the operand rounding is most of it (a sum of K products with
+        independent relative errors 2^-9 has that relative error, not 2^-9 / sqrt(K)) -- and the level-3 loss does not get closer (see FP32_STREAM)."""
         B, N, d = x.shape
         h = HF.layer_norm(x, self.ln_1.weight, self.ln_1.bias, self.ln_1.variance_epsilon)
         qkv = HF.linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias, out_f32=True).to(torch.bfloat16)
@@ -92,8 +91,11 @@ class TransformerClip(nn.Module):
         self.layers = layers
         self.resblocks = nn.Sequential(*[ResidualAttentionBlockDmae(width, heads) for _ in range(layers)])
 
-    # fp32 residual stream through the blocks (ResidualAttentionBlockDmae._forward_f32); False = the fused bf16 layer (the pre-round-6 behaviour, kept for A/B)
-    FP32_STREAM = True
+    # True: fp32 residual stream through the blocks (ResidualAttentionBlockDmae._forward_f32).  Built and measured in round 6 and NOT the default: at real width the head's
+    # part of the level-3 loss deviation is +1.2 % (dmae12) / +2.4 % (vtp8t) on the fused bf16 layer and -6.2 % / +1.6 % with the fp32 stream
+    # (profiles/r6_dmae_level3_head_tower_split.txt) -- the bf16 GEMM / attention OPERANDS alone leave ~0.3 % rms on the block's output, which the logit scale of 100 turns
+    # into per cent either way, and the towers' part (-2.8 % / -3.0 %) is there whatever the head does.
+    FP32_STREAM = False
 
     def forward(self, x: torch.Tensor, attn_mask: torch.Tensor):
         """Reference calling convention: x is LND, attn_mask [B, L, L] additive.  The mask DmaeUtils builds is constant along

@@ -173,6 +173,14 @@ int antmmf_gemm_wgrad_bf16(const void* dY, const void* X, float* dW, int64_t tok
                            int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes,
                            antmmf_stream_t stream);
 
+/* The same for n_seg (<= 4) weights of seg_rows x k_in whose gradient buffers dW[0 .. n_seg) are unrelated addresses (host array of device pointers) while their dY
+ * columns are adjacent, dY[tokens][n_seg * seg_rows]: the separate q / k / v projections of BertSelfAttention (modeling_bert.py:140-146) and of torchscale's
+ * MultiheadAttention (multihead_attention.py:66-71), whose dQ | dK | dV this build keeps packed -- one wgrad GEMM instead of three, the row segments scattered by its
+ * reduce launch.  Shapes that do not take the workspace path run as n_seg ordinary calls; same workspace rule as above with n_out = n_seg * seg_rows. */
+int antmmf_gemm_wgrad_bf16_seg(const void* dY, const void* X, float* const* dW, int n_seg, int seg_rows, int64_t tokens, int k_in,
+                               int64_t ld_dy, int64_t ld_x, int64_t ld_dw, int split_k_hint, float* workspace, int64_t workspace_bytes,
+                               antmmf_stream_t stream);
+
 /* ---- fused multi-head attention, head_dim = 64, bf16, Nk <= 288 (whole key row in LDS):
  *   O[b,q,h,:] = softmax_k( scale * <Q[b,q,h,:], K[b,k,h,:]> + key_bias[b,k] ) V[b,k,h,:]
  * element (b, n, h, e) of Q lives at q + (b*Nq + n)*ldq + h*64 + e (K, V with Nk / ldk / ldv; O with ldo), so a packed

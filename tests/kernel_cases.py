@@ -448,6 +448,26 @@ def case_gemm_wgrad_ring(ops, dev, tokens=4096, n_out=256, k_in=256, quick=False
     assert float(big[:, k_in:].abs().max()) == 0.0
 
 
+def case_gemm_wgrad_seg(ops, dev, tokens=4096, rows=256, k_in=256, n_seg=3):
+    """One wgrad GEMM over the packed dQ | dK | dV whose reduce launch scatters the row segments into separate gradient buffers (antmmf_gemm_wgrad_bf16_seg) against
+    per-segment calls and the fp32 product; a shape off the workspace path (tokens < 4096) takes the per-segment fallback inside the entry point."""
+    dY = q(rnd((tokens, n_seg * rows), 57, 0.5))
+    Xa = q(rnd((tokens, k_in), 58, 0.5))
+    # the three destinations at unrelated offsets of one buffer, in an order that is NOT the column order (the arena holds k, v, q)
+    arena = torch.full((n_seg * rows * k_in + 3 * 64,), 0.25, device=dev)
+    order = [(s_ + 1) % n_seg for s_ in range(n_seg)]
+    dst = [arena[order[s_] * (rows * k_in + 64):order[s_] * (rows * k_in + 64) + rows * k_in].view(rows, k_in) for s_ in range(n_seg)]
+    ops.gemm_wgrad_seg_(dst, dY.to(dev, BF), Xa.to(dev, BF))
+    for s_ in range(n_seg):
+        check(f"gemm.tn.seg.{s_}", dst[s_], dY[:, s_ * rows:(s_ + 1) * rows].t() @ Xa + 0.25, 2e-3, 2e-3)
+    pads = torch.cat([arena[i * (rows * k_in + 64) + rows * k_in:(i + 1) * (rows * k_in + 64)] for i in range(n_seg)])
+    assert float((pads - 0.25).abs().max()) == 0.0          # nothing outside the segments was touched
+    small = [torch.zeros(rows, k_in, device=dev) for _ in range(n_seg)]
+    ops.gemm_wgrad_seg_(small, dY[:1024].to(dev, BF), Xa[:1024].to(dev, BF))
+    for s_ in range(n_seg):
+        check(f"gemm.tn.seg.fallback.{s_}", small[s_], dY[:1024, s_ * rows:(s_ + 1) * rows].t() @ Xa[:1024], 2e-3, 2e-3)
+
+
 # ------------------------------------------------------------------------------ attention
 def _attn_ref(qh, kh, vh, scale, key_bias):
     return oops.attention_core(qh, kh, vh, scale, key_bias)

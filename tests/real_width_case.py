@@ -261,7 +261,10 @@ def case_vtp8(dev):
     return rep, gates
 
 
-HEAD_GATE = {}   # per-case gate of the head's part of the level-3 loss deviation (filled from measurements)
+# Gate of the HEAD's part of the level-3 loss deviation (product head vs the fp32 oracle head on the same, product, tower outputs).  Measured on MI355X
+# (profiles/r6_dmae_level3_head_tower_split.txt): seqTransf heads +1.2 % (dmae12) / +2.4 % (vtp8t) -- four bf16 temporal layers in front of a logit scale of 100; either sign
+# -- against a towers' part of -2.8 % / -3.0 %; the meanP head with TPM-CL on (no bf16 layer in the head): 1e-5-class, gated at 2e-3.
+HEAD_GATE = {"dmae12tpm": 2e-3}
 
 
 def case_dmae12(dev, which="dmae12"):
@@ -291,10 +294,10 @@ def case_dmae12(dev, which="dmae12"):
     from antmmf.common.configuration import Configuration
     from roi_univl.univl.model.univl_video_ret import UnivlForVideoTextRetrieval
 
-    if os.environ.get("ANTMMF_DMAE_BF16_STREAM") == "1":   # A/B of the temporal transformer's state precision (round 6): the fused bf16 layer instead of the fp32 stream
+    if os.environ.get("ANTMMF_DMAE_BF16_STREAM") == "0":   # A/B of the temporal transformer's state precision (round 6): the opt-in fp32 stream instead of the fused bf16 layer
         from roi_univl.univl.model import dmae_utils as _du
 
-        _du.TransformerClip.FP32_STREAM = False
+        _du.TransformerClip.FP32_STREAM = True
     model = UnivlForVideoTextRetrieval(Configuration(clip_cfg(c, **extra)))
     # the oracle's parameter table = the product model's own names (towers as in tiny_models.clip_arch_shapes + the dmae_utils.* head), filled by name
     P = W.fill_dict({k: tuple(v.shape) for k, v in model.named_parameters()})
@@ -360,7 +363,7 @@ def case_dmae12(dev, which="dmae12"):
         gates.append("l3_simi")
     # round 6: the level-3 loss IS gated now, on the part that is this build's head (given the same tower outputs, the product's head against the fp32 oracle head); the
     # towers' part (bf16 ViT / BERT features under a logit scale of 100) is reported next to it.  Gate sizes: measured values in profiles/r6_real_width.jsonl
-    if abs(rep["loss3_head_part"]) > HEAD_GATE.get(which, 5e-3):
+    if abs(rep["loss3_head_part"]) > HEAD_GATE.get(which, 5e-2) or rep["l3_simi_head_part_max_abs"] > 4e-2 * rep["l3_simi_ref_absmax"]:
         gates.append("loss3_head_part")
     gates += grad_gates(rep["grads"], max_err=0.25, min_cos=0.98, min_global=0.998)
     return rep, gates

@@ -229,6 +229,11 @@ def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, quick=not os.environ.get("ANTMMF_SLOW_TESTS"))
 
 
+def test_gemm_wgrad_segments(ops):
+    """the q / k / v wgrad as ONE launch with a segmented destination (round 6)"""
+    kc.case_gemm_wgrad_seg(ops, DEV)
+
+
 def test_attention_self(ops):
     kc.case_attention(ops, DEV, B=2, heads=2, Nq=17, Nk=17, bias_kind="none")
 

@@ -214,6 +214,12 @@ def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, tokens=257 * 64, n_out=1024, k_in=512)
 
 
+def test_gemm_wgrad_segments(ops):
+    """the q / k / v wgrad as ONE launch with a segmented destination (round 6): toy size and the flagship's (3 x 1024 x 1024 over 65792 tokens)"""
+    kc.case_gemm_wgrad_seg(ops, DEV)
+    kc.case_gemm_wgrad_seg(ops, DEV, tokens=257 * 256, rows=1024, k_in=1024)
+
+
 def test_gemm_large_linearity(ops):
     """Full-size property check (BASELINE sizes; the oracle would take minutes): the GEMM is linear in P,
     and agrees with an fp32 matmul of the same bf16 operands on a random sample of rows."""

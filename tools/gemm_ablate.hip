@@ -799,6 +799,20 @@ int main(int argc, char** argv) {
                 sustain(nm, flop, secs, [&]() { hipLaunchKernelGGL(k1wb, dim3(tiles), dim3(256), 131072, 0, P, Q, out, R2, nk, J2 / 256, 0); });
             }
         }
+        // the same simple ring loop (no two-group stagger) on the two MFMA shapes: does 32 x 32 x 16 (half the operand register reads per flop) sustain more at wall-clock?
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k32<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        {
+            const int J2 = 4096, R2 = 1024, tiles = (I / 256) * (J2 / 256), nk = R2 / 32;
+            const double flop = 2.0 * I * J2 * R2;
+            for (int round = 0; round < 2; ++round) {
+                char nm[96];
+                snprintf(nm, sizeof nm, "ring_loop_mfma_16x16x32 J=%d R=%d round %d", J2, R2, round);
+                sustain(nm, flop, secs * 0.5, [&]() { hipLaunchKernelGGL(k<7>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R2, nk, J2 / 256); });
+                snprintf(nm, sizeof nm, "ring_loop_mfma_32x32x16 J=%d R=%d round %d", J2, R2, round);
+                sustain(nm, flop, secs * 0.5, [&]() { hipLaunchKernelGGL(k32<7>, dim3(tiles), dim3(512), 131072, 0, P, Q, out, R2, nk, J2 / 256); });
+            }
+        }
         return 0;
     }
     uint16_t *P, *Q; float* out;
