@@ -374,6 +374,11 @@ def set_keep_ffn_norm(flag):
 # from a streaming kernel into them buys nothing (step 1314 vs 1313 pairs/s).  Since round 5 its entry points live in the LAB library only
 # (libantmmf_hip_lab.so, include/antmmf_hip_lab.h): set_ffn_fold(True) works when that library is the loaded one (tests, tools/ffn_fold_bench.py) and raises otherwise.
 FFN_FOLD = False
+if os.environ.get("ANTMMF_FFN_FOLD"):   # rounds 3 - 4 read this variable; since round 5 the fold is an experiment of the lab library behind set_ffn_fold()
+    import warnings
+
+    warnings.warn("ANTMMF_FFN_FOLD is set but ignored: the sub-LN fold is a lab-library experiment (antmmf.hip.functional.set_ffn_fold(True) with "
+                  "ANTMMF_HIP_LIB=.../libantmmf_hip_lab.so); the product path always runs the two 4d-wide LayerNorm passes", stacklevel=2)
 
 
 # Collector for the one thing the reference does with attention MAPS on this path (univl_video_base.py:131-143: words_importance = sum over layers of the
@@ -633,9 +638,11 @@ class _TransformerLayer(torch.autograd.Function):
             _bgrad(sink, P["bqkv"], dqkv2)
         else:
             ws_ = [P["w" + nm] for nm in "qkv"]
-            if all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and T >= 4096 and T % 64 == 0:
+            if all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and 4096 <= T <= 131072 and T % 64 == 0:
                 # separate q / k / v projections (BERT, torchscale): ONE wgrad GEMM over the packed dQ | dK | dV, its reduce launch scatters the three row segments into the
-                # three parameters' gradient buffers (round 6: 3072 x 1024 over 263168 tokens is 48 tiles x 5 token splits instead of 3 x (16 tiles x 16 splits))
+                # three parameters' gradient buffers.  Measured in the l14 step (profiles/r6_gemm_table_l14_qkv_wgrad_merged.txt): 3072 x 1024 is 48 tiles x 5 token splits
+                # = 240 workgroups against 3 x (16 tiles x 16 splits = 256) -- on the 77-token text tower (78848 tokens: 77 K-tiles per split before) 402 us instead of
+                # 3 x 150 us, on the image tower (263168 tokens) 1359 us instead of 3 x 445 us: the merged launch leaves 16 CUs idle and loses; hence the token bound
                 ops.gemm_wgrad_seg_([sink.buf(w) for w in ws_], dqkv2, h)
             else:
                 for i, nm in enumerate("qkv"):

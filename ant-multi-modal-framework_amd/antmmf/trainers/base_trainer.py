@@ -115,13 +115,17 @@ class BaseTrainer:
         self.epoch_iterations = len(self.train_batches) if hasattr(self.train_batches, "__len__") else 0
         # ragged per-rank batches (the reference pads + trims on every gather, distributed_utils.py:131-160): with `pad_ragged_batches` the row-sharded
         # losses pad every rank to the per-rank batch size of the configuration (reference: batch_size is the GLOBAL size, utils/general.py get_batch_size).
-        # The maximum is process-wide and also serves the evaluation loader, so it covers the LARGER of batch_size and test_batch_size (ceil: a global size that
-        # does not divide by the world leaves one more row on the first ranks); a rank that still exceeds it fails on every rank together (contrastive._Rows)
+        # SEPARATE maxima for training and evaluation (ceil: a global size that does not divide by the world leaves one more row on the first ranks): the training steps pad to
+        # batch_size / W, `evaluate` switches to test_batch_size / W for its loop and back (round 5 took the larger of the two for the whole run: with a bigger
+        # test_batch_size every TRAINING step padded its embeddings and slabs to the eval size).  A rank over the maximum fails on every rank together (contrastive._Rows)
+        self._max_rows_train = self._max_rows_eval = None
         if tp.get("pad_ragged_batches", False) and tp.get("batch_size", None):
             from antmmf.hip import contrastive
 
-            biggest = max(int(tp.batch_size), int(tp.get("test_batch_size", 0) or 0))
-            contrastive.set_max_rows_per_rank(max(1, -(-biggest // get_world_size())))
+            world = get_world_size()
+            self._max_rows_train = max(1, -(-int(tp.batch_size) // world))
+            self._max_rows_eval = max(1, -(-int(tp.get("test_batch_size", 0) or tp.batch_size) // world))
+            contrastive.set_max_rows_per_rank(self._max_rows_train)
         self.setup_lr_scheduler()
         self.load_extras()
 
@@ -266,19 +270,36 @@ class BaseTrainer:
         return loss
 
     # ------------------------------------------------------------------ evaluation / early stopping
+    def _enter_eval_rows(self):
+        """the ragged-batch padding maximum of the evaluation loader for the duration of an evaluation loop (see __init__)"""
+        if getattr(self, "_max_rows_eval", None) is not None:
+            from antmmf.hip import contrastive
+
+            contrastive.set_max_rows_per_rank(self._max_rows_eval)
+
+    def _leave_eval_rows(self):
+        if getattr(self, "_max_rows_train", None) is not None:
+            from antmmf.hip import contrastive
+
+            contrastive.set_max_rows_per_rank(self._max_rows_train)
+
     def evaluate(self, batches):
         """Mean losses of `batches` in eval mode (no gradients, no optimizer); overridden by RetrievalTrainer for retrieval metrics."""
         was_training = self.model.training
         self.model.eval()
         sums, n = {}, 0
-        with torch.no_grad():
-            for batch in batches:
-                report, _, _ = self._forward_pass(batch)
-                if report is None:
-                    continue
-                n += 1
-                for k, v in report["losses"].items():
-                    sums[k] = sums.get(k, 0) + v.detach().float().mean()
+        self._enter_eval_rows()
+        try:
+            with torch.no_grad():
+                for batch in batches:
+                    report, _, _ = self._forward_pass(batch)
+                    if report is None:
+                        continue
+                    n += 1
+                    for k, v in report["losses"].items():
+                        sums[k] = sums.get(k, 0) + v.detach().float().mean()
+        finally:
+            self._leave_eval_rows()
         if was_training:
             self.model.train()
         if sums and get_world_size() > 1 and not self.config.training_parameters.get("losses_are_global", True):

@@ -45,7 +45,11 @@ class RetrievalTrainer(BaseTrainer):
         return result
 
     def evaluate_set(self, batches):
-        out = self._evaluate_set(batches)
+        self._enter_eval_rows()      # (the evaluation loader's own ragged-batch padding maximum: BaseTrainer.__init__)
+        try:
+            out = self._evaluate_set(batches)
+        finally:
+            self._leave_eval_rows()
         synchronize()
         return out
 

@@ -881,7 +881,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
 #else
     (void)tile;
     const uint32_t m = __builtin_amdgcn_readfirstlane(tile_lds + piece * 1024);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(g) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(g) : "memory", "m0");   // (m0 is written here: the compiler must not keep a value of its own in it across the statement -- movrel, sendmsg, its own LDS-DMA builtins)
 #endif
 }
 

@@ -575,7 +575,10 @@ def main():
                        # N > 1: the gradient buckets of the last step in launch order (which went to RCCL from inside backward, which at the end, and when)
                        "grad_buckets": getattr(trainer.arena, "last_bucket_log", None) if world > 1 else None,
                        "peak_hbm_gib": round(hw.max_allocated() / 2 ** 30, 1),
-                       "reserved_hbm_gib": round(hw.max_reserved() / 2 ** 30, 1)},
+                       "reserved_hbm_gib": round(hw.max_reserved() / 2 ** 30, 1),
+                       # WHICH library served the step (ANTMMF_HIP_LIB can point at another build of the ABI): path relative to the repo, lab or product, size in bytes
+                       "library": {"path": os.path.relpath(_lib.lib_path(), os.path.dirname(os.path.abspath(__file__))), "lab": bool(_lib.is_lab()),
+                                   "bytes": os.path.getsize(_lib.lib_path()) if os.path.isfile(_lib.lib_path()) else None}},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_k64r_kernel / gemm_tn_k64_kernel (bf16 MFMA GEMM family, all layouts)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gemm_traffic_*.json); algorithmic bytes per launch = 2(I R + J R + I J)",
                          "launches_per_step": n // a.steps, "avg_launch_ms": round(gemm_ms / n, 4),

@@ -304,7 +304,7 @@ def case_dmae12(dev, which="dmae12"):
     assert set(tiny_models.clip_arch_shapes(c)) <= set(P) | {"module.text_encoder.pooler.dense.weight", "module.text_encoder.pooler.dense.bias"}
     copy_weights(model, P)
     model = model.to(dev).train()
-    frames, ids, mask, img_input, cap_input = video_inputs("fd." + which, B, n, c, seq, lengths or [seq, seq], dev)   # (DMAE's predictors are built for exactly l3_max_words tokens)
+    frames, ids, mask, img_input, cap_input = video_inputs("fd." + which, B, n, c, seq, lengths or [seq] * B, dev)   # (DMAE's predictors are built for exactly l3_max_words tokens)
     for v in P.values():
         v.requires_grad_(True)
     out = model(img_input, cap_input)

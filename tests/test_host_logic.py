@@ -162,6 +162,25 @@ def test_k64r_isa_audit(tmp_path):
     assert sum("loads 28 problems 0" in ln for ln in lines) == 2 and sum("loads 16 problems 0" in ln for ln in lines) == 1, p.stdout    # the two residual kernels and the gate kernel were really audited
 
 
+def test_attention_m0_audit(tmp_path):
+    """tools/m0_audit.py over the ISA hipcc emits for csrc/attention.hip (device-only -S, ~40 s): the one-kernel attention backward sets M0 and issues its LDS-DMA pieces
+    from inline asm (attn_dma_piece, "m0" clobbered) -- every such piece has its own `s_mov_b32 m0` and the compiler never reads M0 behind one of them without writing it
+    first."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        pytest.skip("hipcc not available")
+    assert '"memory", "m0")' in open(os.path.join(PKG, "csrc", "attention.hip")).read()
+    out = tmp_path / "attn_dev.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-S", "--cuda-device-only",
+                           os.path.join(PKG, "csrc", "attention.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "m0_audit.py"), str(out)], capture_output=True, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("m0 audit ")]
+    assert p.returncode == 0 and len(lines) >= 10 and all(ln.endswith("problems 0") for ln in lines), p.stdout[-3000:]
+
+
 def test_hip_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
     from antmmf.hip import _lib, ops
 

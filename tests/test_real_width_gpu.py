@@ -30,7 +30,7 @@ def run_case(case, dev, env_extra=None, timeout=1500):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["l14", "b16", "vtp8", "vtp8t", "dmae12"])
+@pytest.mark.parametrize("case", ["l14", "b16", "vtp8", "vtp8t", "dmae12", "dmae12tpm"])
 def test_real_width_step_vs_oracle(case):
     rep = run_case(case, "cuda:0")
     assert rep["full"]

@@ -157,6 +157,32 @@ def test_evaluation_and_early_stopping():
     assert "total_loss" in tr.last_evaluation and tr.last_evaluation["total_loss"] > 0
 
 
+def test_ragged_padding_maximum_is_per_phase():
+    """`pad_ragged_batches`: training steps pad to batch_size / W, an evaluation loop to test_batch_size / W and back -- a bigger test_batch_size must not make every
+    TRAINING step pad to the eval size."""
+    from antmmf.hip import contrastive
+
+    Trainer = _toy_trainer()
+    seen = []
+    try:
+        tr = Trainer(_cfg(batch_size=4, test_batch_size=16, pad_ragged_batches=True, evaluation_interval=2, max_iterations=4, monitored_metric="total_loss"), _batches(4))
+        tr.load()
+        assert contrastive._DEFAULT_MAX_ROWS == 4
+        tr.load_task(_batches(4), _batches(2, seed=5))
+        inner = tr.model.forward
+
+        def spy(*a, **k):
+            seen.append((tr.model.training, contrastive._DEFAULT_MAX_ROWS))
+            return inner(*a, **k)
+
+        tr.model.forward = spy
+        tr.train()
+        assert {m for t, m in seen if t} == {4} and {m for t, m in seen if not t} == {16}, seen
+        assert contrastive._DEFAULT_MAX_ROWS == 4     # back to the training maximum after the last evaluation
+    finally:
+        contrastive.set_max_rows_per_rank(None)
+
+
 def test_fp32_escape_list_and_hard_mining_ratio():
     """amp_attributes.amp_escapes (reference register_fp32.py:42-69): the named class receives fp32 inputs; unknown names warn.
     hard_example_mining + change_iter / change_rate put `incre_num` into the batch (reference base_trainer.py:552-571)."""

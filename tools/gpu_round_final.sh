@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 measurement set (same sequence as rounds 2 - 4): parity on the product library (+ the real-width / contract reports), default bench (+cpu baseline, +gemm table),
+# The per-round measurement set (same sequence since round 2): parity on the product library (+ the real-width / contract reports), default bench (+cpu baseline, +gemm table),
 # rocprofv3 stats of the default command, the other workloads with their own kernel stats, PMC traffic passes, own vs hipBLASLt per shape (lab library), loss kernels.
-# usage: gpu_round5_final.sh TAG [skip_traffic]
+# usage: gpu_round_final.sh TAG [skip_traffic]
 TAG=${1:-r5}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 export ANTMMF_REAL_WIDTH_OUT=$PWD/gpurun_out/${TAG}_real_width.jsonl; rm -f $ANTMMF_REAL_WIDTH_OUT
