@@ -2,7 +2,7 @@
 # The per-round measurement set (same sequence since round 2): parity on the product library (+ the real-width / contract reports), default bench (+cpu baseline, +gemm table),
 # rocprofv3 stats of the default command, the other workloads with their own kernel stats, PMC traffic passes, own vs hipBLASLt per shape (lab library), loss kernels.
 # usage: gpu_round_final.sh TAG [skip_traffic]
-TAG=${1:-r5}
+TAG=${1:-r6}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 export ANTMMF_REAL_WIDTH_OUT=$PWD/gpurun_out/${TAG}_real_width.jsonl; rm -f $ANTMMF_REAL_WIDTH_OUT
 python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log
@@ -14,7 +14,8 @@ timeout 900 python bench.py --gemm-table gpurun_out/${TAG}_gemm_table_l14.txt > 
 echo "=== rocprofv3 --kernel-trace --stats of the default bench command"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_l14 -o prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_l14.log 2>&1
 cd $GRAFT_REPO_ROOT
-f=$(find gpurun_out/${TAG}_prof_l14 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_bench_l14_kernel_stats.csv && head -24 "$f" | cut -c1-150
+f=$(find gpurun_out/${TAG}_prof_l14 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_bench_l14_kernel_stats.csv && python tools/kernel_families.py "$f" | tee gpurun_out/${TAG}_bench_l14_families.txt
+t=$(find gpurun_out/${TAG}_prof_l14 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/kernel_trace_split.py "$t" > gpurun_out/${TAG}_bench_l14_row_kernels_by_grid.txt
 find gpurun_out/${TAG}_prof_l14 -type f ! -name "*stats*" -delete 2>/dev/null
 for wl in b16 vtp8 vtp8t dmae12; do
   echo "=== bench $wl"
