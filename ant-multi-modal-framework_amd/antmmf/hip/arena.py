@@ -17,6 +17,13 @@ from . import ops
 ALIGN = 64  # elements; keeps every view 16-B aligned in all three buffers
 
 
+def _force_collectives():
+    """tests only: antmmf.hip.contrastive.FORCE_COLLECTIVES (the collectives through a one-rank process group)"""
+    from . import contrastive
+
+    return contrastive.FORCE_COLLECTIVES
+
+
 class ParamArena:
     def __init__(self, param_groups, device=None):
         """param_groups: list of dicts with "params" (as torch optimizers take them)."""
@@ -100,9 +107,7 @@ class ParamArena:
         stream, under the rest of the backward pass.  `allreduce_grads()` launches what is left and waits.
         reduce_dtype=torch.bfloat16 sends buckets as bf16 (half the xGMI bytes; the sum of W bf16 values carries ~3 significant digits)."""
         self._ov = None
-        import os
-
-        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not os.environ.get("ANTMMF_FORCE_COLLECTIVES")):
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _force_collectives()):
             return False
         key = (bucket_bytes,)
         if getattr(self, "_bucket_key", None) != key:
@@ -188,9 +193,7 @@ class ParamArena:
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         world = dist.get_world_size(group)
-        import os
-
-        if world == 1 and not os.environ.get("ANTMMF_FORCE_COLLECTIVES"):
+        if world == 1 and not _force_collectives():
             return 1
         if getattr(self, "_ov", None) is None:
             self.arm_overlap(group, bucket_bytes, reduce_dtype)

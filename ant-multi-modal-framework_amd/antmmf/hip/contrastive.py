@@ -31,12 +31,16 @@ def _world(group):
     return 1, 0
 
 
-def _single(w):
-    """world size 1 skips the collectives -- unless a process group exists and ANTMMF_FORCE_COLLECTIVES=1 (GPU test: the real RCCL entry
-    points with one rank, the driver's boxes have a single GPU)."""
-    import os
+# Test switches of this module are Python attributes, not environment variables (round 6: the product path reads no ANTMMF_* variable except the library
+# path ANTMMF_HIP_LIB).  FORCE_COLLECTIVES: run the collectives through a ONE-rank process group as well (tests/test_e2e_gpu.py::test_rccl_entry_points_one_rank
+# -- the real RCCL entry points on the one-GPU boxes); SKIP_BATCH_CHECK: no equal-batch guard in front of the gathers.
+FORCE_COLLECTIVES = False
+SKIP_BATCH_CHECK = False
 
-    return w == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("ANTMMF_FORCE_COLLECTIVES"))
+
+def _single(w):
+    """world size 1 skips the collectives -- unless a process group exists and FORCE_COLLECTIVES is set (see above)."""
+    return w == 1 and not (dist.is_available() and dist.is_initialized() and FORCE_COLLECTIVES)
 
 
 def _assert_equal_batch(n_rows, device, group):
@@ -45,10 +49,8 @@ def _assert_equal_batch(n_rows, device, group):
     distributed_utils.py:131-160).  A tiny all-gather of the local count + a DEVICE-side assert (no host sync) turns a ragged
     batch into an error instead of a hang or mis-indexed diagonals (on this image's wheel a failed device assert aborts the process: measured,
     profiles/r6_assert_async_probe.txt; a wheel built without device asserts would not notice -- `pad_ragged_batches` is the supported way to
-    run ragged batches and checks on the host).  ANTMMF_SKIP_BATCH_CHECK=1 removes it."""
-    import os
-
-    if os.environ.get("ANTMMF_SKIP_BATCH_CHECK"):
+    run ragged batches and checks on the host).  contrastive.SKIP_BATCH_CHECK = True removes it."""
+    if SKIP_BATCH_CHECK:
         return
     w, _ = _world(group)
     mine = torch.full((1,), int(n_rows), dtype=torch.int64, device=device)

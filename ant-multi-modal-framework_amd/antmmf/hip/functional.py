@@ -359,6 +359,7 @@ def _packed_qkv_weight_t(P, spec):
 # when HBM allows (288 GB on MI355X: the ViT-L/14 step at 1024 pairs/GPU peaks at ~175 GiB without it).  Set through set_keep_ffn_norm().
 KEEP_FFN_NORM = False
 COLSUM_HANDOFFS = [0]   # diagnostic: fc2 bias gradients taken from the next layer's ln1 backward instead of a column-sum pass
+DEBUG_NO_HANDOFF = False  # debugging aid (a Python attribute, not an environment variable): always run the column-sum pass
 
 
 def set_keep_ffn_norm(flag):
@@ -537,7 +538,7 @@ class _TransformerLayer(torch.autograd.Function):
             _wgrad(sink, P["w2"], dy_w2, g_n)
         # fc2's bias gradient = column sums of the incoming gradient.  When that gradient is the dx of the NEXT layer's ln1 backward, that
         # kernel has already summed its columns (handed over on the tensor, valid only while the tensor is unmodified: _version check)
-        handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0 and not os.environ.get("ANTMMF_DEBUG_NO_HANDOFF")) else None
+        handed = getattr(dy, "_antmmf_colsum", None) if (pre_ln and p_hid == 0 and not DEBUG_NO_HANDOFF) else None
         handed_ok = handed is not None and handed[1:] == (dy._version, dy.data_ptr(), tuple(dy.shape)) and handed[0].shape[0] == d
         if ctx.fold:
             # ---- sub-LN fold: one row pass over d-wide tensors (the LayerNorm's two row means, rstd-scaled dy for fc2's wgrad, the column sums the

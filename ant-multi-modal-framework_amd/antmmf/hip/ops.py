@@ -3,7 +3,6 @@
 Every wrapper validates device / dtype / layout, passes raw pointers + torch's current HIP stream and
 raises on a non-zero return code.  PyTorch is used for memory and streams only.
 """
-import os
 
 import torch
 
@@ -99,10 +98,6 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, dres=None, 
     return dx
 
 
-def _renorm_ref(x, mean, rstd, gamma, beta):
-    return (((x.float() - mean[:, None]) * rstd[:, None]) * gamma + beta).to(x.dtype)
-
-
 def layernorm_bwd_renorm(dy, x, mean, rstd, gamma, beta, dgamma=None, dbeta=None, dres=None, dxsum=None):
     """Plain LayerNorm backward that also returns y = LN(x) again (one extra write instead of a recompute pass): -> (dx, y)."""
     _dev_ok(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, dres, dxsum)
@@ -112,9 +107,6 @@ def layernorm_bwd_renorm(dy, x, mean, rstd, gamma, beta, dgamma=None, dbeta=None
     _c(dy, "dy"); _c(x, "x")
     if dres is not None:
         _c(dres, "dres")
-    if os.environ.get("ANTMMF_DEBUG_NO_RENORM"):   # debugging aid: the two-pass form this entry replaces
-        dx = layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres, dxsum=dxsum)
-        return dx, layernorm_fwd(x, gamma, beta, 0.0, want_stats=False)[0] if False else _renorm_ref(x, mean, rstd, gamma, beta)
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)

@@ -334,7 +334,7 @@ def test_m2_full_width_step_properties():
 
 def test_rccl_entry_points_one_rank():
     """SURVEY 8a C1 / 8e on the hardware the driver has (one GPU per box): the step's collectives through the REAL RCCL entry points with a
-    one-rank process group (backend "nccl" = RCCL; ANTMMF_FORCE_COLLECTIVES=1 keeps the world-1 shortcuts off): the packed all-gather /
+    one-rank process group (backend "nccl" = RCCL; antmmf.hip.contrastive.FORCE_COLLECTIVES keeps the world-1 shortcuts off): the packed all-gather /
     reduce-scatter of the sharded losses, the device-side equal-batch assert, the loss all-reduce, and the flat-arena gradient all-reduce
     started from inside backward (fp32 and bf16 buckets) -- the tiny M2 step must equal the run without a process group."""
     code = r"""
@@ -362,7 +362,9 @@ def run(use_pg, dtype=None):
     opt.step()
     return float(loss), opt.arena.master.clone(), armed, getattr(opt.arena, "overlapped_buckets", 0)
 l0, m0, _, _ = run(False)
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29688", ANTMMF_FORCE_COLLECTIVES="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29688")
+from antmmf.hip import contrastive
+contrastive.FORCE_COLLECTIVES = True
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 l1, m1, armed, early = run(True)
 l2, m2, _, _ = run(True, torch.bfloat16)

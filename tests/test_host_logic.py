@@ -866,3 +866,14 @@ def test_every_shipped_reference_config_loads_unchanged():
         assert extra <= {"flash_attn", "model_file", "modelscope", "precision", "whole_word_masking", "visual_mask_size"}, (j, extra)
         assert all(k in cfg for k in extra)
     assert sizes["Encoder_0.4B.json"][:3] == ("base", 9, 768) and sizes["Encoder_1B.json"][:3] == ("large", 21, 1024) and sizes["Encoder_10B.json"][:3] == ("huge", 21, 4096), sizes
+
+
+def test_python_product_path_reads_no_switch_from_the_environment():
+    """VERDICT r5 hygiene: the Python side of the product path reads two environment variables and no more -- ANTMMF_HIP_LIB (which build of the ABI to load; bench.py prints
+    the answer as config.library) and, to warn that it is ignored, ANTMMF_FFN_FOLD.  Test switches are module attributes (contrastive.FORCE_COLLECTIVES, ...)."""
+    import glob
+
+    names = set()
+    for f in glob.glob(os.path.join(PKG, "antmmf", "**", "*.py"), recursive=True) + glob.glob(os.path.join(PKG, "prj", "**", "*.py"), recursive=True):
+        names |= set(re.findall(r"""environ(?:\.get|\.setdefault|\.pop)?[\[(]\s*["'](ANTMMF_\w+)["']""", open(f).read()))
+    assert names == {"ANTMMF_HIP_LIB", "ANTMMF_ALLOW_EMULATOR", "ANTMMF_FFN_FOLD"}, names    # (ALLOW_EMULATOR: the loader refuses the CPU emulator build outside pytest without it)
