@@ -1,5 +1,5 @@
 // gemm_bench.cpp -- within-process A/B of the NT GEMM kernel variants of libantmmf_hip.so on the ViT-L/14 step's shapes.
-// Build: hipcc -O2 tools/gemm_bench.cpp -o tools/gemm_bench -ldl -lhipblaslt      Run (GPU box): tools/gemm_bench [pairs=1024] [rounds=3]
+// Build: hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -o tools/gemm_bench -ldl -lhipblaslt      Run (GPU box): tools/gemm_bench [pairs=1024] [rounds=3]
 // GEMM_BENCH_HIPBLASLT=1 adds, per NT shape, the vendor library on the SAME buffers, interleaved in the same rounds ("the honest
 // baseline to beat"): hipblasLtMatmul, bf16 in / bf16 out, fp32 compute, the same fused epilogue (bias vector; residual as beta = 1 on a
 // separate C), the best of the first 16 heuristic algorithms (each timed once, the winner re-timed with the others).
