@@ -18,6 +18,7 @@ prof_bench() {   # prof_bench NAME [env assignments...] : rocprofv3 kernel stats
   [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_${name}_kernel_stats.csv
   local t=$(find gpurun_out/${TAG}_prof_$name -name "*kernel_trace.csv" | head -1)
   [ -n "$t" ] && python tools/kernel_trace_split.py "$t" > gpurun_out/${TAG}_${name}_row_kernels_by_grid.txt
+  [ -n "$t" ] && python tools/kernel_trace_split.py "$t" --seq "ln_bwd_kernel<unsigned short, 2, false, 0, true, true>" > gpurun_out/${TAG}_${name}_renorm_bwd_neighbours.txt
   find gpurun_out/${TAG}_prof_$name -type f ! -name "*stats*" -delete 2>/dev/null
   python tools/kernel_families.py gpurun_out/${TAG}_${name}_kernel_stats.csv 8 | tee gpurun_out/${TAG}_${name}_families.txt
 }

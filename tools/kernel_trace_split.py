@@ -7,8 +7,28 @@ import csv
 import sys
 
 
+def sequence(path, needle, before=2, after=1, limit=40):
+    """`--seq <needle>`: the launches around every launch whose name contains `needle`, in stream order -- what ran in front of a kernel that is slower in the step than in a loop"""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r.get("Kernel_Name") or "").split("(")[0].replace("void ", "")[:60], r.get("Grid_Size_X") or r.get("Grid_Size") or "?"))
+    rows.sort()
+    hits = [i for i, r in enumerate(rows) if needle in r[2]]
+    hits = hits[len(hits) // 2:len(hits) // 2 + limit]     # a window from the middle of the run (steady state)
+    for i in hits:
+        line = []
+        for j in range(max(0, i - before), min(len(rows), i + after + 1)):
+            s0, e0, nm, grid = rows[j]
+            gap = (s0 - rows[j - 1][1]) * 1e-3 if j else 0.0
+            line.append(f"{'>>' if j == i else '  '}{nm}[{grid}] {(e0 - s0) * 1e-6:.3f} ms (gap {gap:.1f} us)")
+        print(" | ".join(line))
+
+
 def main():
     path = sys.argv[1]
+    if len(sys.argv) > 3 and sys.argv[2] == "--seq":
+        return sequence(path, sys.argv[3])
     keys = sys.argv[2:] or ["ln_", "attn_", "colsum"]
     acc = {}
     with open(path) as f:
