@@ -15,7 +15,9 @@ def sequence(path, needle, before=2, after=1, limit=40):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r.get("Kernel_Name") or "").split("(")[0].replace("void ", "")[:60], r.get("Grid_Size_X") or r.get("Grid_Size") or "?"))
     rows.sort()
     hits = [i for i, r in enumerate(rows) if needle in r[2]]
-    hits = hits[len(hits) // 2:len(hits) // 2 + limit]     # a window from the middle of the run (steady state)
+    hits = hits[len(hits) // 3:]                            # steady state only (behind the warm-up steps)
+    by_dur = sorted(hits, key=lambda i: rows[i][1] - rows[i][0])
+    hits = sorted(by_dur[-limit * 3 // 4:] + by_dur[:limit // 4])   # mostly the LONGEST instances (the image tower's), a few of the shortest
     for i in hits:
         line = []
         for j in range(max(0, i - before), min(len(rows), i + after + 1)):

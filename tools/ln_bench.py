@@ -53,7 +53,10 @@ def main():
             rep(f"ln_bwd.{label}.{cols}.act={act}.dxsum", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, act=act, dxsum=dxs)), 3 * e, rows=rows)
             if cols == 1024:
                 rep(f"ln_bwd.{label}.{cols}.plain", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db)), 3 * e, rows=rows)
-                rep(f"ln_bwd.{label}.{cols}.dres.dxsum", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dy, dxsum=dxs)), 4 * e, rows=rows)
+                dr = torch.randn(rows, cols, device=dev).to(torch.bfloat16)     # (a tensor of its own: dres = dy would be one stream less)
+                rep(f"ln_bwd.{label}.{cols}.dres.dxsum", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dr, dxsum=dxs)), 4 * e, rows=rows)
+                rep(f"ln_bwd_renorm.{label}.{cols}.dres.dxsum", timeit(lambda: ops.layernorm_bwd_renorm(dy, x, mean, rstd, g, b, dg, db, dres=dr, dxsum=dxs)), 5 * e, rows=rows)
+                del dr
                 rep(f"colsum.{label}.{cols}", timeit(lambda: ops.colsum_(dxs, dy)), e, rows=rows)
             else:
                 y2, m2, r2 = ops.layernorm_fwd(x, g, b, 1e-5, act=None)

@@ -156,6 +156,7 @@ def main():
     g_d, be_d = torch.rand(d, device=dev) + 0.5, torch.randn(d, device=dev) * 0.1
     g_f, be_f = torch.rand(F, device=dev) + 0.5, torch.randn(F, device=dev) * 0.1
     dy_d, dy_f = rnd(T, d), rnd(T, F)
+    dr_d = rnd(T, d)     # the residual-branch gradient: a tensor of its own (the runs of profiles/r6_two_stream_overlap_* passed dres = dy: four distinct streams, not five)
     _, m_d, r_d = ops.layernorm_fwd(x_d, g_d, be_d, 1e-5)
     _, m_f, r_f = ops.layernorm_fwd(x_f, g_f, be_f, 1e-5, act="gelu")
     dg_d, db_d, dxs_d = torch.zeros(d, device=dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev)
@@ -170,7 +171,7 @@ def main():
         "ln_fwd_d": (lambda: ops.layernorm_fwd(x_d, g_d, be_d, 1e-5), 2 * e_d, 4),
         "ln_fwd_4d_gelu": (lambda: ops.layernorm_fwd(x_f, g_f, be_f, 1e-5, act="gelu"), 2 * e_f, 1),
         "ln_bwd_4d_gelu": (lambda: ops.layernorm_bwd(dy_f, x_f, m_f, r_f, g_f, dg_f, db_f, act="gelu", dxsum=dxs_f), 3 * e_f, 1),
-        "ln_bwd_renorm_d": (lambda: ops.layernorm_bwd_renorm(dy_d, x_d, m_d, r_d, g_d, be_d, dg_d, db_d, dres=dy_d, dxsum=dxs_d), 5 * e_d, 3),
+        "ln_bwd_renorm_d": (lambda: ops.layernorm_bwd_renorm(dy_d, x_d, m_d, r_d, g_d, be_d, dg_d, db_d, dres=dr_d, dxsum=dxs_d), 5 * e_d, 3),
         "attn_fwd": (lambda: ops.attention_fwd(q, k, v, 16, 0.125, None), 4 * e_d, 1),
         "attn_bwd": (lambda: ops.attention_bwd(q, k, v, o, lse, do, 16, 0.125, None, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:]), 8 * e_d, 1),
     }
