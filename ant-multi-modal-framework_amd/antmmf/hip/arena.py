@@ -24,11 +24,41 @@ def _force_collectives():
     return contrastive.FORCE_COLLECTIVES
 
 
+def tag_pack(*params):
+    """Ask the arena to lay these parameters out ADJACENTLY, in this order (they must end up in one parameter group): the separate q / k / v projection weights (and
+    biases) of an attention module, which the fused layer consumes as ONE [3d, d] GEMM operand -- adjacent in the arena, the packed operand is a VIEW of the bf16 shadow
+    (functional._packed_qkv_weight) instead of three copies per layer and optimizer step.  Called by the parameter-holder modules at construction; harmless without an arena."""
+    token = object()
+    for i, p in enumerate(params):
+        if p is not None:
+            p._antmmf_pack = (token, i)
+
+
+def _pack_order(ps):
+    """`ps` with the members of every tagged pack pulled together (in tag order) at the position of the pack's first member; everything else keeps its place."""
+    by_token = {}
+    for p in ps:
+        t = getattr(p, "_antmmf_pack", None)
+        if t is not None:
+            by_token.setdefault(id(t[0]), []).append(p)
+    out, placed = [], set()
+    for p in ps:
+        if id(p) in placed:
+            continue
+        t = getattr(p, "_antmmf_pack", None)
+        members = sorted(by_token[id(t[0])], key=lambda q: q._antmmf_pack[1]) if t is not None else [p]
+        for q in members:
+            placed.add(id(q))
+            out.append(q)
+    return out
+
+
 class ParamArena:
     def __init__(self, param_groups, device=None):
         """param_groups: list of dicts with "params" (as torch optimizers take them)."""
         seen, self.groups = set(), []
-        total = 0
+        total = legacy_total = 0
+        self.legacy_offsets = {}     # id(p) -> offset in the layout WITHOUT pack reordering (what builds before round 6 used: HipAdamW.load_state_dict remaps their flat moments)
         for g in param_groups:
             ps = []
             for p in g["params"]:
@@ -36,6 +66,10 @@ class ParamArena:
                     continue
                 seen.add(id(p))
                 ps.append(p)
+            for p in ps:
+                self.legacy_offsets[id(p)] = legacy_total
+                legacy_total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            ps = _pack_order(ps)
             start = total
             for p in ps:
                 total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
@@ -249,9 +283,13 @@ class HipAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
+    def _layout(self):
+        """(offset, numel) of every arena parameter in param_groups order: travels with the flat moments so that a reader with another layout notices"""
+        return [(int(p._antmmf_offset), int(p.numel())) for g in self.param_groups for p in g["params"] if getattr(p, "_antmmf_arena", None) is self.arena]
+
     def state_dict(self):
         d = super().state_dict()
-        d["antmmf_arena"] = dict(step=self._step, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq)
+        d["antmmf_arena"] = dict(step=self._step, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, layout=self._layout())
         return d
 
     def load_state_dict(self, state_dict):
@@ -264,8 +302,20 @@ class HipAdamW(torch.optim.Optimizer):
         super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if extra is not None:
             self._step = int(extra["step"])
-            self.exp_avg.copy_(extra["exp_avg"])
-            self.exp_avg_sq.copy_(extra["exp_avg_sq"])
+            mine = self._layout()
+            theirs = extra.get("layout", None)
+            if theirs is None:   # written before round 6: the arena order was the parameter order, without pack reordering
+                theirs = [(self.arena.legacy_offsets[id(p)], int(p.numel())) for g in self.param_groups for p in g["params"] if getattr(p, "_antmmf_arena", None) is self.arena]
+            theirs = [tuple(t) for t in theirs]
+            if theirs == mine:
+                self.exp_avg.copy_(extra["exp_avg"])
+                self.exp_avg_sq.copy_(extra["exp_avg_sq"])
+                return
+            if len(theirs) != len(mine) or any(a[1] != b[1] for a, b in zip(theirs, mine)) or extra["exp_avg"].numel() != self.exp_avg.numel():
+                raise ValueError("HipAdamW.load_state_dict: the flat optimizer state belongs to another set of parameters")
+            for (so, n), (do, _) in zip(theirs, mine):       # same parameters, another arena order: moments move parameter by parameter
+                self.exp_avg[do:do + n].copy_(extra["exp_avg"][so:so + n])
+                self.exp_avg_sq[do:do + n].copy_(extra["exp_avg_sq"][so:so + n])
             return
         if not per_param:
             return

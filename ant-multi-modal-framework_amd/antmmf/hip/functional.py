@@ -337,9 +337,33 @@ def _cached_on(p, attr, build):
     return val
 
 
+def _arena_run(params):
+    """(arena, first offset) when `params` sit back to back in ONE arena, in this order (arena.tag_pack asked for it and their sizes are multiples of the arena's
+    alignment) -- their concatenation is then a view of the arena's buffers; None otherwise."""
+    arena = getattr(params[0], "_antmmf_arena", None) if params[0] is not None else None
+    if arena is None:
+        return None
+    off = params[0]._antmmf_offset
+    nxt = off
+    for p in params:
+        if p is None or getattr(p, "_antmmf_arena", None) is not arena or p._antmmf_offset != nxt:
+            return None
+        nxt += p.numel()
+    return arena, off
+
+
 def _packed_qkv_weight(P, spec):
     if spec.packed_qkv:
         return compute_copy(P["wqkv"]), f32(P["bqkv"])
+    ws, bs = [P["wq"], P["wk"], P["wv"]], [P["bq"], P["bk"], P["bv"]]
+    rw, rb = _arena_run(ws), _arena_run(bs)
+    if rw is not None and rb is not None:
+        # q / k / v weights adjacent in the arena (round 6): the [3d, d] operand is a view of the bf16 shadow, the [3d] bias a view of the fp32 master -- no copy at all
+        # (before: torch.cat of three weights, three biases and three transposed weights per layer and optimizer step = 7 launches x 48 layers of the flagship)
+        for w in ws:
+            compute_copy(w)      # (out-of-band writes to a master are picked up per parameter here; no launch when the shadow is fresh)
+        d = ws[0].shape[1]
+        return rw[0].shadow[rw[1]:rw[1] + 3 * ws[0].numel()].view(3 * ws[0].shape[0], d), rb[0].master[rb[1]:rb[1] + 3 * bs[0].numel()]
     # separate q / k / v projections (BERT, torchscale): one [3d, d] GEMM operand, rebuilt once per optimizer step
     w = _cached_on(P["wq"], "_antmmf_qkv_w", lambda: torch.cat([compute_copy(P["wq"]), compute_copy(P["wk"]), compute_copy(P["wv"])], dim=0))
     b = _cached_on(P["wq"], "_antmmf_qkv_b", lambda: torch.cat([f32(P["bq"]), f32(P["bk"]), f32(P["bv"])], dim=0))
@@ -349,6 +373,9 @@ def _packed_qkv_weight(P, spec):
 def _packed_qkv_weight_t(P, spec):
     if spec.packed_qkv:
         return compute_copy_t(P["wqkv"])                                   # [d, 3d]
+    if _arena_run([P["wq"], P["wk"], P["wv"]]) is not None:
+        # the transpose of the packed view, once per optimizer step (one launch; before: three transposes + a cat along the columns)
+        return _cached_on(P["wq"], "_antmmf_qkv_wt", lambda: ops.transpose_bf16(_packed_qkv_weight(P, spec)[0]))
     return _cached_on(P["wq"], "_antmmf_qkv_wt",
                       lambda: torch.cat([compute_copy_t(P["wq"]), compute_copy_t(P["wk"]), compute_copy_t(P["wv"])], dim=1))
 
@@ -648,9 +675,14 @@ class _TransformerLayer(torch.autograd.Function):
             else:
                 for i, nm in enumerate("qkv"):
                     _wgrad(sink, P["w" + nm], dqkv2[:, i * d:(i + 1) * d], h)
-            for i, nm in enumerate("qkv"):
-                if not (nm == "v" and bv_fused):
-                    _bgrad(sink, P["b" + nm], dqkv2[:, i * d:(i + 1) * d])
+            rqk = _arena_run([P["bq"], P["bk"]]) if (bv_fused and P["bq"] is not None and P["bk"] is not None and P["bq"].requires_grad and P["bk"].requires_grad) else None
+            if rqk is not None:
+                # q and k biases adjacent in the gradient arena (arena.tag_pack): ONE column-sum launch over dQ | dK into both slots (the v bias comes out of the inner LayerNorm's backward)
+                ops.colsum_(rqk[0].grad[rqk[1]:rqk[1] + 2 * d], dqkv2[:, :2 * d])
+            else:
+                for i, nm in enumerate("qkv"):
+                    if not (nm == "v" and bv_fused):
+                        _bgrad(sink, P["b" + nm], dqkv2[:, i * d:(i + 1) * d])
         del h
         if ctx.needs_input_grad[0]:
             if not pre_ln:

@@ -35,6 +35,11 @@ class BertSelfAttention(nn.Module):
         self.key = nn.Linear(config.hidden_size, self.all_head_size)
         self.value = nn.Linear(config.hidden_size, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+        # the fused layer consumes q / k / v as ONE [3d, d] operand: ask the optimizer arena to keep them adjacent, in that order (antmmf.hip.arena.tag_pack)
+        from antmmf.hip.arena import tag_pack
+
+        tag_pack(self.query.weight, self.key.weight, self.value.weight)
+        tag_pack(self.query.bias, self.key.bias, self.value.bias)
 
 
 class BertSelfOutput(nn.Module):

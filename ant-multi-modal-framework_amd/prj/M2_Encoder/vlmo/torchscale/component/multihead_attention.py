@@ -21,6 +21,14 @@ class MultiheadAttention(nn.Module):
         self.q_proj = MultiwayWrapper(args, nn.Linear(embed_dim, embed_dim, bias=True))
         self.out_proj = MultiwayWrapper(args, nn.Linear(embed_dim, embed_dim, bias=True))
         self.inner_attn_ln = MultiwayWrapper(args, nn.LayerNorm(embed_dim, eps=args.layernorm_eps)) if subln else None
+        # the fused layer consumes q / k / v as ONE [3d, d] operand: ask the optimizer arena to keep them adjacent, in that order (antmmf.hip.arena.tag_pack)
+        from antmmf.hip.arena import tag_pack
+
+        for br in ("A", "B"):
+            q, k, v = (getattr(self, nm).pick(br) for nm in ("q_proj", "k_proj", "v_proj"))
+            if getattr(q.weight, "_antmmf_pack", None) is None:     # (without multiway both branches are the same module)
+                tag_pack(q.weight, k.weight, v.weight)
+                tag_pack(q.bias, k.bias, v.bias)
 
     def reset_parameters(self):
         for br in ("A", "B"):

@@ -327,3 +327,49 @@ def test_early_stop_state_is_persisted_and_best_weights_are_final(tmp_path):
     tr2 = Trainer(cfg2, batches)
     tr2.load()
     assert tr2.best_iteration == tr.best_iteration and abs(tr2.best_monitored - tr.best_monitored) < 1e-12
+
+
+def test_arena_pack_adjacency_views_and_legacy_optimizer_state():
+    """Round 6: parameters tagged with arena.tag_pack (the separate q / k / v projections) are laid out adjacently, in tag order, whatever their order in the module -- the
+    packed [3d, d] operand and [3d] bias of the fused layer are then VIEWS of the arena (equal to the concatenation, no copy); everything else keeps its place.  The flat
+    optimizer moments carry their layout: a state written by a build WITHOUT pack reordering (no layout entry) is remapped parameter by parameter."""
+    from antmmf.hip import functional as HF
+    from antmmf.hip.arena import HipAdamW, tag_pack
+
+    torch.manual_seed(3)
+    d = 64
+    k, v, q, o = (torch.nn.Linear(d, d) for _ in range(4))       # torchscale's order: k, v, q (multihead_attention.py:66-71)
+    tag_pack(q.weight, k.weight, v.weight)
+    tag_pack(q.bias, k.bias, v.bias)
+    decay, no_decay = [k.weight, v.weight, o.weight, q.weight], [k.bias, v.bias, o.bias, q.bias]
+    opt = HipAdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-2)
+    P = dict(wq=q.weight, wk=k.weight, wv=v.weight, bq=q.bias, bk=k.bias, bv=v.bias)
+    assert HF._arena_run([q.weight, k.weight, v.weight]) is not None and HF._arena_run([q.bias, k.bias, v.bias]) is not None
+    assert o.weight._antmmf_offset == 3 * d * d                      # the pack sits where its first member (k) was, the untagged parameter follows
+    spec = HF.LayerSpec(kind="m2", heads=1, eps=1e-5, act="gelu", packed_qkv=False)
+    w, b = HF._packed_qkv_weight(P, spec)
+    assert w.data_ptr() == opt.arena.shadow.data_ptr() + 2 * q.weight._antmmf_offset and b.data_ptr() == opt.arena.master.data_ptr() + 4 * q.bias._antmmf_offset
+    torch.testing.assert_close(w.float(), torch.cat([q.weight, k.weight, v.weight]).detach().bfloat16().float(), rtol=0, atol=0)
+    torch.testing.assert_close(b, torch.cat([q.bias, k.bias, v.bias]).detach(), rtol=0, atol=0)
+    torch.testing.assert_close(HF._packed_qkv_weight_t(P, spec).float(), w.float().t(), rtol=0, atol=0)
+    # a legacy flat state: moments laid out in plain parameter order (k, v, o, q | k, v, o, q), recognisable values per parameter
+    legacy = torch.zeros_like(opt.exp_avg)
+    off = 0
+    for i, p in enumerate(decay + no_decay):
+        legacy[off:off + p.numel()] = float(i + 1)
+        off += (p.numel() + 63) // 64 * 64
+    sd = opt.state_dict()
+    sd["antmmf_arena"] = dict(step=5, exp_avg=legacy, exp_avg_sq=legacy * 2)      # no "layout": written before round 6
+    opt.load_state_dict(sd)
+    for i, p in enumerate(decay + no_decay):
+        sl = opt.exp_avg[p._antmmf_offset:p._antmmf_offset + p.numel()]
+        assert float(sl.min()) == float(sl.max()) == float(i + 1), (i, float(sl.min()), float(sl.max()))
+    assert opt._step == 5
+    # its own state (with the layout) round-trips unchanged
+    import copy
+
+    sd2 = copy.deepcopy(opt.state_dict())      # (the state dict holds the live moment tensors)
+    before = opt.exp_avg.clone()
+    opt.exp_avg.zero_()
+    opt.load_state_dict(sd2)
+    torch.testing.assert_close(opt.exp_avg, before, rtol=0, atol=0)
