@@ -33,6 +33,7 @@ _SIGNATURES = {
     "antmmf_transpose_bf16": [P, P, I, I, P],
     "antmmf_transpose_bf16_batched": [P, P, P, I, L, P],
     "antmmf_cast_f32_bf16": [P, P, L, P],
+    "antmmf_split_hi_lo_bf16": [P, L, I, I, P, P, I, I, P],
     "antmmf_patchify": [P, P, I, I, I, I, I, I, F, F, I, P],
     "antmmf_assemble_tokens": [P, P, P, P, P, L, I, I, P],
     "antmmf_split_tokens": [P, P, L, I, I, P],

@@ -197,12 +197,6 @@ class _Rows:
         return g[:self.B] if self.ragged and g.shape[0] != self.B else g
 
 
-def _split(x):
-    hi = x.to(BF)
-    lo = (x - hi.float()).to(BF)
-    return hi, lo
-
-
 def _pad2(t, r_mult, c_mult):
     r, c = t.shape
     pr, pc = (-r) % r_mult, (-c) % c_mult
@@ -213,26 +207,30 @@ def _pad2(t, r_mult, c_mult):
 
 def matmul_f32(A, B, a_rmajor=False, b_rmajor=False):
     """fp32-accurate  out[i, j] = sum_r A[i, r] B[j, r]  (operands [I, R] / [J, R], or [R, I] / [R, J] when *_rmajor)
-    on the bf16 MFMA GEMM via a hi/lo split.  Operands are zero-padded to the kernel's alignment (tiny tensors)."""
+    on the bf16 MFMA GEMM via a hi/lo split.  Operands are zero-padded to the kernel's alignment (tiny tensors) by the split kernel itself (ops.split_hi_lo: one launch
+    per operand; round 6 -- it was a cast, a cast back, a subtraction, a cast, a pad and a copy each)."""
     I = A.shape[1] if a_rmajor else A.shape[0]
     J = B.shape[1] if b_rmajor else B.shape[0]
-    A = _pad2(A.float(), 8, 8)
-    B = _pad2(B.float(), 8, 8)
-    Ip = A.shape[1] if a_rmajor else A.shape[0]
-    Jp = B.shape[1] if b_rmajor else B.shape[0]
-    ah, al = _split(A)
-    bh, bl = _split(B)
-    out = torch.zeros(Ip, Jp, dtype=torch.float32, device=A.device)
+    A = A if (A.dtype == torch.float32 and A.dim() == 2 and A.stride(1) == 1) else A.float().contiguous()
+    B = B if (B.dtype == torch.float32 and B.dim() == 2 and B.stride(1) == 1) else B.float().contiguous()
+    ah, al = ops.split_hi_lo(A)
+    bh, bl = ops.split_hi_lo(B)
+    Ip = ah.shape[1] if a_rmajor else ah.shape[0]
+    Jp = bh.shape[1] if b_rmajor else bh.shape[0]
     # a long reduction into a handful of output tiles (the weight gradient of a small Linear over ~1e5 rows: the TPM-CL predictors) is split over the rows -- as ONE
     # workgroup per GEMM it took 2.1 ms x 3 (6.3 ms of the dmae12 step)
     split = 1
     if a_rmajor and b_rmajor:
-        R = A.shape[0]
+        R = ah.shape[0]
         tiles = ((Ip + 127) // 128) * ((Jp + 127) // 128)
         if tiles < 64 and R >= 4096:
             split = min(64, max(1, 256 // tiles), R // 1024)
-    for x, y in ((ah, bh), (ah, bl), (al, bh)):
-        ops.gemm(x, y, out=out, p_rmajor=a_rmajor, q_rmajor=b_rmajor, accumulate=True, split_k=split)
+    # the first product initialises `out` (no zero-fill launch) where the layout's kernels store without accumulating: the forward layouts; the token-major (wgrad) layout
+    # accumulates by construction (row split, atomics) and starts from zeros
+    init = not (a_rmajor and b_rmajor) and split == 1
+    out = torch.empty(Ip, Jp, dtype=torch.float32, device=A.device) if init else torch.zeros(Ip, Jp, dtype=torch.float32, device=A.device)
+    for n, (x, y) in enumerate(((ah, bh), (ah, bl), (al, bh))):
+        ops.gemm(x, y, out=out, p_rmajor=a_rmajor, q_rmajor=b_rmajor, accumulate=not (init and n == 0), split_k=split)
     return out[:I, :J] if (Ip != I or Jp != J) else out
 
 

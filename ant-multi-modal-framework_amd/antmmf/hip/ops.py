@@ -189,6 +189,21 @@ def cast_bf16(x, out=None):
     return out
 
 
+def split_hi_lo(x, r_mult=8, c_mult=8):
+    """fp32 [rows, cols] (unit inner stride) -> (hi, lo) bf16, zero-padded to multiples of (r_mult, c_mult): hi = bf16(x), lo = bf16(x - hi).  One launch."""
+    _dev_ok(x); _f32(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("split_hi_lo: x must be 2-D with unit inner stride")
+    rows, cols = x.shape
+    rp, cp = (rows + r_mult - 1) // r_mult * r_mult, (cols + c_mult - 1) // c_mult * c_mult
+    if cp % 8:
+        raise ValueError("split_hi_lo: the padded column count must be a multiple of 8")
+    hi = torch.empty(rp, cp, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(rp, cp, dtype=torch.bfloat16, device=x.device)
+    _rc(_lib.load().antmmf_split_hi_lo_bf16(_p(x), x.stride(0) if rows > 1 else max(cols, 1), rows, cols, _p(hi), _p(lo), rp, cp, _stream()), "antmmf_split_hi_lo_bf16")
+    return hi, lo
+
+
 def patchify(img, patch, kpad=None, shift=0.0, scale=1.0):
     _dev_ok(img); _c(img, "img")
     b, c, h, w = img.shape

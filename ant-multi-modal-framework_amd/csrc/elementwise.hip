@@ -229,6 +229,32 @@ extern "C" int antmmf_cast_f32_bf16(const float* in, void* out, long n, hipStrea
     return antmmf_check_launch();
 }
 
+// ------------------------------------------------------------------ hi / lo split of an fp32 operand (the fp32-accurate similarity GEMMs: x = hi + lo + O(2^-16 |x|))
+// x [rows, cols] fp32 (row stride ldx) -> hi = bf16(x), lo = bf16(x - float(hi)), both [rows_pad, cols_pad] dense, zero outside the operand.  One pass instead of the
+// cast / cast back / subtract / cast (+ pad) launches torch makes of it; same round-to-nearest-even, bit-identical results.  cols_pad is a multiple of 8: a thread
+// writes one 16-byte vector of each output.  Replaces (reference, stock torch ops): the fp32 `torch.matmul` of L2-normalised embeddings, univl_video_ret.py:357-387.
+__global__ __launch_bounds__(256) void split_hi_lo_kernel(const float* __restrict__ x, long ldx, int rows, int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                          int rows_pad, int cols_pad) {
+    const int vpr = cols_pad >> 3;
+    const long total = (long)rows_pad * vpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / vpr), c0 = (int)(i % vpr) << 3;
+        float v[8], h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (r < rows && c0 + e < cols) ? x[(long)r * ldx + c0 + e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { h[e] = bf2f(f2bf(v[e])); l[e] = v[e] - h[e]; }
+        st8<bf16_t>(hi + (long)r * cols_pad + c0, h);
+        st8<bf16_t>(lo + (long)r * cols_pad + c0, l);
+    }
+}
+extern "C" int antmmf_split_hi_lo_bf16(const float* x, long ldx, int rows, int cols, void* hi, void* lo, int rows_pad, int cols_pad, hipStream_t s) {
+    if (!x || !hi || !lo || rows < 0 || cols < 0 || rows_pad < rows || cols_pad < cols || (cols_pad & 7) || ldx < cols) return ANTMMF_EINVAL;
+    if (!rows_pad || !cols_pad) return ANTMMF_OK;
+    hipLaunchKernelGGL(split_hi_lo_kernel, dim3(ew_grid((long)rows_pad * (cols_pad >> 3))), dim3(256), 0, s, x, ldx, rows, cols, (bf16_t*)hi, (bf16_t*)lo, rows_pad, cols_pad);
+    return antmmf_check_launch();
+}
+
 // ------------------------------------------------------------------ patch extraction (im2col for a stride == kernel conv)
 // image [B, C, H, W] (fp32 or bf16, optional affine (x - shift) * scale: M2's inception normalise) ->
 // patches [B * Gh * Gw, Kpad] bf16, inner order (c, py, px) == Conv2d weight.flatten(1); columns >= C*P*P are zero.

@@ -100,6 +100,10 @@ int antmmf_transpose_bf16_batched(const void* in_base, void* out_base, const int
                                   antmmf_stream_t stream);
 /* ---- flat fp32 -> bf16 cast. */
 int antmmf_cast_f32_bf16(const float* in, void* out, int64_t n, antmmf_stream_t stream);
+/* ---- hi / lo split of an fp32 GEMM operand: hi = bf16(x), lo = bf16(x - float(hi)), both [rows_pad, cols_pad] dense and zero outside x [rows, cols] (row stride ldx);
+ * cols_pad % 8 == 0.  hi.hi + hi.lo + lo.hi on the bf16 MFMA GEMM reproduces the fp32 product of the reference's similarity matmuls (univl_video_ret.py:357-387,
+ * dmae_utils.py:85-131) to fp32 accuracy; this entry makes the split one pass (bit-identical to cast / subtract / cast). */
+int antmmf_split_hi_lo_bf16(const float* x, int64_t ldx, int rows, int cols, void* hi, void* lo, int rows_pad, int cols_pad, antmmf_stream_t stream);
 
 /* ---- patch extraction for a stride == kernel conv (nn.Conv2d(3, W, P, P): clip/model.py:289-295,310-312;
  * VisionEmbedding.proj: torchscale/component/embedding.py:49,69), with the optional input affine

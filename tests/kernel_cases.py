@@ -794,3 +794,26 @@ def case_dropout(ops, dev):
     imp0 = torch.zeros(B, N, device=dev)
     ops.attention_key_importance_(imp0, qd, kd, lse0, heads, scale, key_bias.to(dev), weight=1.0 / heads)
     check("attn.importance", imp0, torch.softmax(s, -1).detach().mean(1).sum(1), 2e-2, 2e-2)
+
+
+def case_split_hi_lo(ops, dev):
+    """ops.split_hi_lo against the torch form it replaces (cast, cast back, subtract, cast, zero pad): bit-identical, ragged shapes, a row-strided view."""
+    for rows, cols in ((5, 13), (64, 64), (1, 7), (33, 1024)):
+        x = rnd((rows, cols), 71 + rows, 3.0)
+        x[0, 0] = 1e-30; x[-1, -1] = -65504.0 * 3
+        for view in (False, True):
+            src = x
+            if view:
+                big = torch.zeros(rows, cols + 5)
+                big[:, :cols] = x
+                src = big.to(dev)[:, :cols]
+            else:
+                src = x.to(dev)
+            hi, lo = ops.split_hi_lo(src)
+            rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+            assert hi.shape == (rp, cp) and lo.shape == (rp, cp)
+            h_ref = x.to(BF)
+            l_ref = (x - h_ref.float()).to(BF)
+            assert torch.equal(hi[:rows, :cols].cpu(), h_ref) and torch.equal(lo[:rows, :cols].cpu(), l_ref), (rows, cols, view)
+            pad = torch.cat([hi[rows:].flatten(), hi[:rows, cols:].flatten(), lo[rows:].flatten(), lo[:rows, cols:].flatten()])
+            assert pad.numel() == 0 or float(pad.float().abs().max()) == 0.0

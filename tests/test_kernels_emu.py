@@ -229,6 +229,10 @@ def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, quick=not os.environ.get("ANTMMF_SLOW_TESTS"))
 
 
+def test_split_hi_lo(ops):
+    kc.case_split_hi_lo(ops, DEV)
+
+
 def test_gemm_wgrad_segments(ops):
     """the q / k / v wgrad as ONE launch with a segmented destination (round 6)"""
     kc.case_gemm_wgrad_seg(ops, DEV)

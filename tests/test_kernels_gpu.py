@@ -214,6 +214,10 @@ def test_gemm_wgrad_ring(ops):
     kc.case_gemm_wgrad_ring(ops, DEV, tokens=257 * 64, n_out=1024, k_in=512)
 
 
+def test_split_hi_lo(ops):
+    kc.case_split_hi_lo(ops, DEV)
+
+
 def test_gemm_wgrad_segments(ops):
     """the q / k / v wgrad as ONE launch with a segmented destination (round 6): toy size and the flagship's (3 x 1024 x 1024 over 65792 tokens)"""
     kc.case_gemm_wgrad_seg(ops, DEV)
