@@ -211,8 +211,9 @@ def matmul_f32(A, B, a_rmajor=False, b_rmajor=False):
     per operand; round 6 -- it was a cast, a cast back, a subtraction, a cast, a pad and a copy each)."""
     I = A.shape[1] if a_rmajor else A.shape[0]
     J = B.shape[1] if b_rmajor else B.shape[0]
-    A = A if (A.dtype == torch.float32 and A.dim() == 2 and A.stride(1) == 1) else A.float().contiguous()
-    B = B if (B.dtype == torch.float32 and B.dim() == 2 and B.stride(1) == 1) else B.float().contiguous()
+    ok = lambda t: t.dtype == torch.float32 and t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1])   # noqa: E731
+    A = A if ok(A) else A.float().contiguous()
+    B = B if ok(B) else B.float().contiguous()
     ah, al = ops.split_hi_lo(A)
     bh, bl = ops.split_hi_lo(B)
     Ip = ah.shape[1] if a_rmajor else ah.shape[0]

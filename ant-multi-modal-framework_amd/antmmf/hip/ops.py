@@ -192,7 +192,7 @@ def cast_bf16(x, out=None):
 def split_hi_lo(x, r_mult=8, c_mult=8):
     """fp32 [rows, cols] (unit inner stride) -> (hi, lo) bf16, zero-padded to multiples of (r_mult, c_mult): hi = bf16(x), lo = bf16(x - hi).  One launch."""
     _dev_ok(x); _f32(x, "x")
-    if x.dim() != 2 or x.stride(1) != 1:
+    if x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1):      # (a single column may carry any inner stride)
         raise ValueError("split_hi_lo: x must be 2-D with unit inner stride")
     rows, cols = x.shape
     rp, cp = (rows + r_mult - 1) // r_mult * r_mult, (cols + c_mult - 1) // c_mult * c_mult

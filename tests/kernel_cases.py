@@ -798,7 +798,10 @@ def case_dropout(ops, dev):
 
 def case_split_hi_lo(ops, dev):
     """ops.split_hi_lo against the torch form it replaces (cast, cast back, subtract, cast, zero pad): bit-identical, ragged shapes, a row-strided view."""
-    for rows, cols in ((5, 13), (64, 64), (1, 7), (33, 1024)):
+    odd = torch.randn(6, 1).expand(6, 1).as_strided((6, 1), (1, 6))     # one column with a non-unit inner stride (what a reshape can hand over)
+    hi, lo = ops.split_hi_lo(odd.to(dev).as_strided((6, 1), (1, 6)))
+    assert torch.equal(hi[:6, :1].cpu(), odd.to(BF)) and float(hi[:, 1:].float().abs().max()) == 0.0
+    for rows, cols in ((5, 13), (64, 64), (1, 7), (33, 1024), (9, 1)):
         x = rnd((rows, cols), 71 + rows, 3.0)
         x[0, 0] = 1e-30; x[-1, -1] = -65504.0 * 3
         for view in (False, True):
