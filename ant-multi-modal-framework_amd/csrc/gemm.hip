@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                    ONEBAR = FLAGS & K64F_ONEBAR;
     // residual / generic epilogues run from registers (permuted Q rows + lane swap, 16-B accesses of 64-B row segments: the residual is read
     // coalesced); plain / bias epilogues stage through the 32 KiB of LDS above the ring (128-B row segments)
-    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4 || EPI == 8 || EPI >= 16;   // EPI 8: out = acc * gate (the dgrad through an activation whose derivative was stored); 16 / 32 / 64: the sub-LN fold (GemmArgs::ffn_mode 1 / 2 / 3)
+    constexpr bool SWAPEPI = (EPI & 2) || EPI == 4 || EPI == 8 || EPI == 9 || EPI >= 16;   // EPI 8: out = acc * gate (the dgrad through an activation whose derivative was stored); 16 / 32 / 64: the sub-LN fold (GemmArgs::ffn_mode 1 / 2 / 3)
     const int lane = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
@@ -1288,7 +1288,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
             // ---- epilogue straight from the accumulators.  lane (l15, grp) holds out[i = it 16 + l15][j = jt 16 + 4 PB(grp) + r],
             // PB = {0, 2, 1, 3}; after the swap it holds 8 consecutive columns of fragment 2 p + (lane >> 5) at (grp & 1) * 8.
             constexpr bool FFN1 = EPI == 16, FFN2 = EPI == 32, FFN3 = EPI == 64;
-            constexpr bool GENERIC = EPI == 4, GATEMUL = EPI == 8, BIAS = ((EPI & 1) && EPI < 8) || FFN1, RES = ((EPI & 2) && EPI < 8) || FFN2;
+            // GATEACT (EPI 9, round 6): out = acc * act'(gate) -- the dgrad through an activation whose PRE-ACTIVATION was kept (the recompute policy of the CLIP / BERT
+            // feed-forwards): the gate tile is requested up front like GATEMUL's, the derivative is evaluated in packed fp32 in front of the multiply
+            constexpr bool GENERIC = EPI == 4, GATEACT = EPI == 9, GATEMUL = EPI == 8 || GATEACT, BIAS = ((EPI & 1) && EPI < 8) || FFN1, RES = ((EPI & 2) && EPI < 8) || FFN2;
             const int pbg = ((grp & 1) << 1) | (grp >> 1);
             const int jw = j0 + wj * 64, iw = i0 + wi * 128 + l15;
             if (FFN2) {
@@ -1487,7 +1489,11 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
                     }
                     if (GATEMUL) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[2 * e] *= bf_lo(rv[q][e]); v[2 * e + 1] *= bf_hi(rv[q][e]); }
+                        for (int e = 0; e < 4; ++e) {
+                            f2_t dz = f2_bf(rv[q][e]);
+                            if (GATEACT) { f2_t z_unused; act_fwd_grad2<-1>(f2_bf(rv[q][e]), g.act, z_unused, dz); }
+                            v[2 * e] *= dz.x; v[2 * e + 1] *= dz.y;
+                        }
                     } else if (RES || (GENERIC && g.residual)) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rv[q][e]); v[2 * e + 1] += bf_hi(rv[q][e]); }
@@ -2614,6 +2620,14 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             static bool once5 = false;
             if (!once5) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once5 = true; }
             hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+        } else
+        if (k64p && gate && !g.gate_grad && act != ANTMMF_ACT_NONE && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {
+            // out = acc * act'(gate) (the dgrad of the CLIP / BERT feed-forwards under the RECOMPUTE activation policy: the pre-activation was kept, not its derivative) on the
+            // burst kernel's register-level epilogue with all 16 gate vectors requested up front -- round 6; the generic run-time epilogue served it at half the speed
+            ++g_k64_launches;
+            const unsigned t8 = (unsigned)((tiles256 + 7) / 8 * 8);
+            const unsigned gridp = pwgs < t8 ? pwgs : t8;
+            K64P_LAUNCH(9, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
         } else
         if (k64p && gate && g.gate_grad && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {
             // out = acc * gate on the register-level epilogue of the residual kernels (16 gate vectors requested up front) instead of the generic one

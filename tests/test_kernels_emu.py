@@ -154,7 +154,7 @@ def test_gemm_k64_persistent(variant):
     """The BK = 64 quarter-phase persistent kernel (default for the large GEMMs) on 2 - 16-tile problems with an 8-workgroup grid, so that
     workgroups walk two tiles and the DMA ring crosses the tile boundary: nk = 2 (no steady state), 3 and 5; every epilogue (staged for
     plain / bias; register-level lane swap for residual / generic).  variant 4 = the dispatch of both libraries (the generic run-time epilogue and R = 128 go to the other
-    kernel families: 9 of the 13 calls are k64 launches); + bit 27: the burst-epilogue kernel's own forms for those shapes (lab A/B only: all 13); + bit 4: the 1 / 3 / 3 / 1 DMA distribution."""
+    kernel families: 10 of the 13 calls are k64 launches); + bit 27: the burst-epilogue kernel's own forms for those shapes (lab A/B only: all 13); + bit 4: the 1 / 3 / 3 / 1 DMA distribution."""
     import subprocess
     import sys
 
@@ -166,7 +166,7 @@ def test_gemm_k64_persistent(variant):
             "kc.case_gemm_k64(ops, dev, I=768, J=768, R=320, quick=True);"
             "lib = ctypes.CDLL(os.environ['ANTMMF_HIP_LIB']); lib.antmmf_debug_gemm_k64_launches.restype = ctypes.c_long;"
             "assert lib.antmmf_debug_gemm_k64_launches() >= %d, lib.antmmf_debug_gemm_k64_launches(); print('okk64')"
-            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant, 9 if variant == "4" else 13))
+            % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "ant-multi-modal-framework_amd"), ROOT, EMU_LIB, variant, 10 if variant == "4" else 13))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
     assert "okk64" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

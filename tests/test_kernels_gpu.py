@@ -148,9 +148,9 @@ def test_gemm_k64_persistent(ops):
     before = lib.antmmf_debug_gemm_k64_launches()
     kc.case_gemm_k64(ops, DEV, I=13312, J=2560, R=256)
     kc.case_gemm_k64(ops, DEV, I=33024, J=1024, R=128, quick=True)
-    # 7 of the first case's 9 calls run on the BK = 64 kernels (plain / bias / residual / both / two-output activation / gated dgrad / strided output); the generic run-time
-    # epilogue (activation + residual + aux + alpha; gate with the activation recomputed) and R = 128 are served by the BK = 32 ring kernels since round 6
-    assert lib.antmmf_debug_gemm_k64_launches() - before >= 7, "the dispatcher did not pick the k64 kernel"
+    # 8 of the first case's 9 calls run on the BK = 64 kernels (plain / bias / residual / both / two-output activation / gated dgrad with the stored or the recomputed
+    # derivative / strided output); the generic run-time epilogue (activation + residual + aux + alpha) and R = 128 are served by the BK = 32 ring kernels since round 6
+    assert lib.antmmf_debug_gemm_k64_launches() - before >= 8, "the dispatcher did not pick the k64 kernel"
 
 
 @pytest.mark.parametrize("which", ["product", "lab"])
