@@ -402,6 +402,8 @@ def set_keep_ffn_norm(flag):
 # from a streaming kernel into them buys nothing (step 1314 vs 1313 pairs/s).  Since round 5 its entry points live in the LAB library only
 # (libantmmf_hip_lab.so, include/antmmf_hip_lab.h): set_ffn_fold(True) works when that library is the loaded one (tests, tools/ffn_fold_bench.py) and raises otherwise.
 FFN_FOLD = False
+# q / k / v bias gradients out of the attention backward's per-item token sums (round 6; module flag for the A/B, tools/colsum_ab.py)
+ATTN_BWD_SUMS = True
 if os.environ.get("ANTMMF_FFN_FOLD"):   # rounds 3 - 4 read this variable; since round 5 the fold is an experiment of the lab library behind set_ffn_fold()
     import warnings
 
@@ -648,10 +650,19 @@ class _TransformerLayer(torch.autograd.Function):
         del o_n
         q3 = qkv.view(B, N, 3 * d)
         dqkv = torch.empty(B, N, 3 * d, dtype=BF, device=qkv.device)
+        # q / k / v bias gradients: the one-kernel attention backward also returns, per batch item, the token sums of dQ | dK | dV ([B, 3d] fp32) -- their column
+        # sums are the bias gradients, so the column-sum passes over the B * N rows of dQ | dK | dV (0.19 ms per image-tower layer of the flagship) are not run
+        qkv_biases = [P["bqkv"]] if spec.packed_qkv else [P["bq"], P["bk"], P["bv"]]
+        tok_sums = None
+        # (the library serves the long towers only -- at 77 - 86 tokens the sums cost the kernel more than the pass they save: profiles/r6b_attn_bwd_token_sums_ab.txt)
+        if (ATTN_BWD_SUMS and d == 64 * spec.heads and any(b_ is not None and b_.requires_grad for b_ in qkv_biases)
+                and ops.attention_bwd_sums_ok(64, N, N, p_att)):
+            tok_sums = torch.empty(B, 3 * d, dtype=torch.float32, device=qkv.device)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,
-                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dropout_p=p_att, dropout_seed=seed)
+                          dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], dropout_p=p_att, dropout_seed=seed, sums=tok_sums, sums_v=not bv_fused)
         del do
         dqkv2 = dqkv.view(T, 3 * d)
+        bsrc = tok_sums if tok_sums is not None else dqkv2   # what the q / k / v bias gradients are column sums of
         dx = None
         if pre_ln:   # (also when x itself needs no gradient: ln1's own parameters do)
             dh = ops.gemm(dqkv2, _packed_qkv_weight_t(P, spec))
@@ -663,7 +674,7 @@ class _TransformerLayer(torch.autograd.Function):
             h = x2
         if spec.packed_qkv:
             _wgrad(sink, P["wqkv"], dqkv2, h)
-            _bgrad(sink, P["bqkv"], dqkv2)
+            _bgrad(sink, P["bqkv"], bsrc)
         else:
             ws_ = [P["w" + nm] for nm in "qkv"]
             if all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and 4096 <= T <= 131072 and T % 64 == 0:
@@ -678,11 +689,15 @@ class _TransformerLayer(torch.autograd.Function):
             rqk = _arena_run([P["bq"], P["bk"]]) if (bv_fused and P["bq"] is not None and P["bk"] is not None and P["bq"].requires_grad and P["bk"].requires_grad) else None
             if rqk is not None:
                 # q and k biases adjacent in the gradient arena (arena.tag_pack): ONE column-sum launch over dQ | dK into both slots (the v bias comes out of the inner LayerNorm's backward)
-                ops.colsum_(rqk[0].grad[rqk[1]:rqk[1] + 2 * d], dqkv2[:, :2 * d])
+                ops.colsum_(rqk[0].grad[rqk[1]:rqk[1] + 2 * d], bsrc[:, :2 * d])
             else:
-                for i, nm in enumerate("qkv"):
-                    if not (nm == "v" and bv_fused):
-                        _bgrad(sink, P["b" + nm], dqkv2[:, i * d:(i + 1) * d])
+                rqkv = _arena_run([P["bq"], P["bk"], P["bv"]]) if (tok_sums is not None and not bv_fused and all(P["b" + nm] is not None and P["b" + nm].requires_grad for nm in "qkv")) else None
+                if rqkv is not None:   # (BERT: the three biases adjacent in the gradient arena -- one launch over the [B, 3d] sums)
+                    ops.colsum_(rqkv[0].grad[rqkv[1]:rqkv[1] + 3 * d], bsrc)
+                else:
+                    for i, nm in enumerate("qkv"):
+                        if not (nm == "v" and bv_fused):
+                            _bgrad(sink, P["b" + nm], bsrc[:, i * d:(i + 1) * d])
         del h
         if ctx.needs_input_grad[0]:
             if not pre_ln:

@@ -562,8 +562,15 @@ def attention_key_importance_(out, q, k, lse, heads, scale, key_bias=None, dropo
     return out
 
 
-def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dropout_p=0.0, dropout_seed=0):
-    _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv)
+def attention_bwd_sums_ok(head_dim, Nq, Nk, dropout_p=0.0):
+    """True when attention_bwd(..., sums=...) is served: the one-kernel backward's shapes (head size 64, no dropout, 129 ... 272 keys)."""
+    return bool(_lib.load().antmmf_attention_bwd_sums_ok(int(head_dim), int(Nq), int(Nk), float(dropout_p)))
+
+
+def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk=None, dv=None, dropout_p=0.0, dropout_seed=0, sums=None, sums_v=True):
+    """`sums` [B, 3 * D] fp32 (contiguous): also filled with the per-batch-item token sums of dQ | dK | dV -- the q / k / v bias gradients are its column sums
+    (check attention_bwd_sums_ok first: only the one-kernel backward's shapes are served); sums_v=False leaves the dV third unwritten."""
+    _dev_ok(q, k, v, o, lse, d_o, key_bias, dq, dk, dv, sums)
     B, Nq, D = q.shape
     Nk = k.shape[1]
     dh = _head_dim(D, heads)
@@ -574,6 +581,15 @@ def attention_bwd(q, k, v, o, lse, d_o, heads, scale, key_bias=None, dq=None, dk
         dk = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
     if dv is None:
         dv = torch.empty(B, Nk, D, dtype=torch.bfloat16, device=q.device)
+    if sums is not None:
+        _c(sums, "sums"); _f32(sums, "sums")
+        if tuple(sums.shape) != (B, 3 * D) or dh != 64 or dropout_p:
+            raise ValueError("attention_bwd: sums must be [B, 3 * D] fp32 with head size 64 and no dropout")
+        _rc(_lib.load().antmmf_attention_bwd_sums(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv), _p(sums),
+                                                  1 if sums_v else 0, B, heads, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
+                                                  _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), _stream()),
+            "antmmf_attention_bwd_sums")
+        return dq, dk, dv
     _rc(_lib.load().antmmf_attention_bwd_hd(_p(q), _p(k), _p(v), _p(key_bias), _p(o), _p(lse), _p(d_o), _p(dq), _p(dk), _p(dv),
                                             B, heads, dh, Nq, Nk, _tok_ld(q, "q"), _tok_ld(k, "k"), _tok_ld(v, "v"), D, D,
                                             _tok_ld(dq, "dq"), _tok_ld(dk, "dk"), _tok_ld(dv, "dv"), float(scale), float(dropout_p),

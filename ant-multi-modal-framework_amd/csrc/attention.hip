@@ -68,6 +68,10 @@ struct AttnArgs {
     float drop_scale;       // 1 / (1 - p)
     uint32_t drop_thr;      // 0 = no dropout
     uint64_t drop_seed;
+    // one-kernel backward only (antmmf_attention_bwd_sums): per batch item, the sums over the tokens of dQ | dK | dV -- what the q / k / v bias gradients are made of --
+    // sums[(b * 3 + {0: q, 1: k, 2: v}) * heads * 64 + h * 64 + e], fp32; NULL = not wanted
+    float* sums;
+    int sums_v;   // 0: the dV sums are not wanted (their slots stay unwritten) -- torchscale's value bias comes out of the inner LayerNorm's backward
 };
 
 // Head size DH = 64 (every tower of the contrastive path) or 128 (ViLBERT co-attention, vilbert.py:326-416 with bi_hidden_size 1024 / 8 heads):
@@ -845,12 +849,18 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_bwd_dkv_k
 // (16 consecutive keys x one slot) and the transposing reads (8 consecutive keys x 4 slots of one query tile) sweep all banks.
 __device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
 __device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
-static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool early = false) {
+// token sums of dQ | dK | dV (AttnArgs::sums): per-wave partials [dK: 8 x 64 | dV: 8 x 64 | dQ: 8 x 16 | the extra key tile: 8 x 16] floats behind the row statistics
+#define ATTN_SUMS_FLOATS 1280
+
+static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool early = false, bool sums = false) {
     const int nqp = ((Nq + 31) / 32) * 32;
-    return (size_t)nqp * 256 * (early ? 2 : 1) + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8;
+    return (size_t)nqp * 256 * (early ? 2 : 1) + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8 + (sums ? ATTN_SUMS_FLOATS * 4 : 0);
 }
 static inline bool attn_fused_ok(const AttnArgs& a) {
-    return !a.drop_thr && a.Nk > 32 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;   // (one or two key tiles: the two-kernel form)
+    // the token sums cost the kernel ~ 1 us per (b, h) item: 1.4 % of the 257-token form against a column-sum pass of 12 % of its time, but 15 % of the 77 - 86-token
+    // forms, more than the pass they would save (profiles/r6b_attn_bwd_token_sums_ab.txt) -- served from nine key tiles on
+    if (a.sums && a.Nk <= 128) return false;
+    return !a.drop_thr && a.Nk > 32 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk, false, a.sums != nullptr) <= 160 * 1024;   // (one or two key tiles: the two-kernel form)
 }
 
 // one score block: 16 queries (tile at q0) x the 16 keys of (kf, vf): p = softmax probabilities, ds = p * (dP - D).  Lane: key l15, queries q0 + 4 grp + r.
@@ -951,6 +961,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
                 *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi_) * a.lddq + h * 64 + 16 * qdt + 4 * grp) =                           \
                     make_uint2(pack_bf2((g0_[0] + g1_[0]) * a.scale, (g0_[1] + g1_[1]) * a.scale),                                          \
                                pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
+            if constexpr (SUMS) FUSED_QSUM_ACC(g0_, g1_);   /* (padding queries: their dS^T rows are exactly 0) */                           \
         }                                                                                                                                   \
     } while (0)
 #define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
@@ -975,7 +986,9 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
 // forms: 128 K^T fragments NOT in registers, 256 the dQ contraction one chunk late (see the main loop).
 // EARLY (persistent form of the short towers, where LDS and registers allow it): Q / dO tiles double-buffered and EVERYTHING of the next item -- K, Q, dO, the register
 // prefetch -- requested at the START of the current one, so the item boundary waits for nothing.  (The long towers have neither the 74 KB nor the 45 VGPRs.)
-template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0, bool EARLY = false>
+// SUMS (round 6): the token sums of dQ | dK | dV of every item -> a.sums (the q / k / v bias gradients' column-sum passes over the three tensors disappear): the dK / dV
+// accumulators are closed over their 16 key lanes at the end of the item, the dQ^T tiles chunk by chunk, per-wave partials in LDS, three waves add them up and store.
+template <int NKS, bool HASE, bool FULL, int NQC, bool PERSIST, int ABL = 0, bool EARLY = false, int SUMS = 0>   // SUMS: 0 none, 1 dQ | dK | dV, 2 dQ | dK
 __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const AttnArgs a, int NQP, int n_items) {
     ANTMMF_DYN_LDS(char, smem);
     const int nkt = (a.Nk + 15) >> 4, nkr = nkt < 16 ? nkt : 16, nqc = NQC ? NQC : NQP >> 5;   // key tiles, resident key tiles, query chunks
@@ -984,6 +997,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     char* Sb = Ks + 288 * 128;
     char* Se = Sb + 2 * 16384;
     float* stats = reinterpret_cast<float*>(Se + (HASE ? nqc * 1024 : 0));   // [lse | dsum][NQP], both negated: accumulator start values
+    float* sums = stats + 2 * NQP;                                           // SUMS: ATTN_SUMS_FLOATS per-wave partial token sums
+    (void)sums;
     const int lane_w = threadIdx.x & 63;
 #ifdef ANTMMF_EMULATE
     const int wave = threadIdx.x >> 6;
@@ -1040,7 +1055,32 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         }                                                                                                                                   \
     } while (0)
 
+    // SUMS: the per-wave partials of item ITEM (parked in LDS at the end of that item, a workgroup barrier ago) -> its 3 x 64 token sums.  Wave 0: dQ, 1: dK, 2: dV;
+    // lane = head-dim element (= [head-dim tile][element of the tile]).  Runs behind the NEXT item's opening barrier (which exists anyway) -- as a block of its own at
+    // the end of the item, with a barrier of its own, it cost the short towers 10 - 16 % (0.46 -> 0.51 ms at 77 tokens: ~ 1 us per item of 6 us)
+#define FUSED_SUMS_FINALIZE(ITEM)                                                                                                            \
+    do {                                                                                                                                    \
+        if (wave < (SUMS == 1 ? 3 : 2)) {                                                                                                   \
+            const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                         \
+            FUSED_OPAQUE_LANE(le_);                                                                                                         \
+            float s_;                                                                                                                       \
+            if (wave == 0) s_ = (sums[1024 + le_] + sums[1024 + 64 + le_]) * a.scale;   /* the two query tiles of a chunk: waves qdt and 4 + qdt */ \
+            else {                                                                                                                          \
+                const float* w_ = sums + (wave == 1 ? 0 : 512) + le_;                                                                       \
+                s_ = ((w_[0] + w_[64]) + (w_[128] + w_[192])) + ((w_[256] + w_[320]) + (w_[384] + w_[448]));                                \
+                if constexpr (HASE && !(ABL & 32)) s_ += sums[1152 + (wave == 1 ? 64 : 0) + le_];                                           \
+                if (wave == 1) s_ *= a.scale;                                                                                               \
+            }                                                                                                                               \
+            a.sums[((long)b_ * 3 + wave) * (a.heads * 64) + h_ * 64 + le_] = s_;                                                            \
+        }                                                                                                                                   \
+    } while (0)
+#ifdef ANTMMF_EMULATE
+#define FUSED_OPAQUE_LANE(x) int x = lane_w
+#else
+#define FUSED_OPAQUE_LANE(x) int x = lane_w; asm volatile("" : "+v"(x))   /* (offsets derived from it are recomputed at the point of use, not kept alive from the top of the item) */
+#endif
     int item = blockIdx.x, cur = 0;
+    int pitem = -1;   // SUMS: the item whose partial sums sit in LDS
     if constexpr (PERSIST) {
         const int lane = lane_w;
         if (item < n_items) {
@@ -1067,6 +1107,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     if constexpr (PERSIST) {
         glds_wait_all();         // this wave's pieces of the item, its register prefetch (and everything older) have landed ...
         wg_barrier_lds_only();   // ... and so have the other waves' pieces
+        if constexpr (SUMS) { if (pitem >= 0) FUSED_SUMS_FINALIZE(pitem); }   // (the previous item's; this item's first write of that region is behind the next barrier)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {   // D = rowsum(dO o O): eight lanes per row, dO from the LDS tile
             const int id = wave * 64 + lane + i * ATTN_THREADS, row = id >> 3 < NQP ? id >> 3 : NQP - 1, slot = id & 7;
@@ -1167,6 +1208,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
                 bf16_t* dst = (is_k ? a.dk + ((long)b * a.Nk + ki) * a.lddk : a.dv + ((long)b * a.Nk + ki) * a.lddv) + h * 64 + 16 * dt + 4 * grp;
                 *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2((g0[0] + g1[0]) * sc, (g0[1] + g1[1]) * sc), pack_bf2((g0[2] + g1[2]) * sc, (g0[3] + g1[3]) * sc));
             }
+            if (SUMS == 1 || (SUMS == 2 && is_k)) {   // this tile's share of the token sums (padding keys: exactly 0); waves 0 - 3: dV, 4 - 7: dK (unscaled), head-dim tile dt
+                const float4 es = make_float4(row16_sum(g0[0] + g1[0]), row16_sum(g0[1] + g1[1]), row16_sum(g0[2] + g1[2]), row16_sum(g0[3] + g1[3]));
+                if (l15 == 0) *reinterpret_cast<float4*>(sums + 1152 + wave * 16 + 4 * grp) = es;
+            }
         }
         wg_barrier_lds_only();
     }
@@ -1204,6 +1249,19 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         }
     }
     const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
+    // SUMS: ... summed over the chunks (unscaled) in this wave's own 16 floats of LDS (four accumulator registers across the main loop are four too many: 256 VGPRs + 156 B
+    // of scratch in the 257-token form): closed over the 16 query lanes per chunk, read-modify-write by one lane per head-dim group -- only this wave touches the slot
+    if constexpr (SUMS) { if (l15 == 0) *reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * grp) = make_float4(0.f, 0.f, 0.f, 0.f); }
+#define FUSED_QSUM_ACC(G0, G1)                                                                                                      \
+    do {                                                                                                                            \
+        const float4 t_ = make_float4(row16_sum((G0)[0] + (G1)[0]), row16_sum((G0)[1] + (G1)[1]), row16_sum((G0)[2] + (G1)[2]), row16_sum((G0)[3] + (G1)[3])); \
+        FUSED_OPAQUE_LANE(ln_);                                                                                                     \
+        if ((ln_ & 15) == 0) {                                                                                                      \
+            float4* p_ = reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * (ln_ >> 4));                                       \
+            const float4 o_ = *p_;                                                                                                  \
+            *p_ = make_float4(o_.x + t_.x, o_.y + t_.y, o_.z + t_.z, o_.w + t_.w);                                                  \
+        }                                                                                                                           \
+    } while (0)
     const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
     // KREG: the K^T fragments of this wave's head-dim tile -- the same for every chunk -- in registers (36 VGPRs): 18 transposing reads less per chunk, and the K tile is
     // free as soon as every wave holds its fragments, so the NEXT item's K is requested here, under the whole main loop, instead of at the item boundary where nothing hides
@@ -1280,9 +1338,34 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         store_rows_paired<4>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * 64, vw, lane, grp, ki < a.Nk, dkv_al16);
         store_rows_paired<4>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * 64, kw, lane, grp, ki < a.Nk, dkv_al16);
     }
+    if constexpr (SUMS) {
+        // token sums of this wave's dK / dV tiles (lane: key l15, head-dim 16 dt + 4 grp + r; tiles the wave does not own are zero): closed over the 16 lanes of a DPP
+        // row, parked per wave in LDS
+        FUSED_OPAQUE_LANE(ln);
+        float* sw = sums + wave * 64 + 4 * (ln >> 4);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4_t ks = dk[0][dt] + dk[1][dt];
+            const float4 k4 = make_float4(row16_sum(ks[0]), row16_sum(ks[1]), row16_sum(ks[2]), row16_sum(ks[3]));
+            if ((ln & 15) == 0) *reinterpret_cast<float4*>(sw + 16 * dt) = k4;
+            if constexpr (SUMS == 1) {
+                const f32x4_t vs = dv[0][dt] + dv[1][dt];
+                const float4 v4 = make_float4(row16_sum(vs[0]), row16_sum(vs[1]), row16_sum(vs[2]), row16_sum(vs[3]));
+                if ((ln & 15) == 0) *reinterpret_cast<float4*>(sw + 512 + 16 * dt) = v4;
+            }
+        }
+    }
     if constexpr (PERSIST && !EARLY) { if (has_next) FUSED_PREFETCH_REGS(nxt); }   // (behind the stores: the accumulators' registers are free now; all of it lands under the K tile's latency)
+    pitem = item;
     } while (PERSIST && (item += gridDim.x) < n_items);
+    if constexpr (SUMS) {   // the last item's
+        wg_barrier_lds_only();
+        FUSED_SUMS_FINALIZE(pitem);
+    }
+#undef FUSED_SUMS_FINALIZE
 #undef FUSED_KT
+#undef FUSED_QSUM_ACC
+#undef FUSED_OPAQUE_LANE
 #undef FUSED_DMA_K
 #undef FUSED_DMA_QD
 #undef FUSED_PREFETCH_REGS
@@ -1345,7 +1428,7 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
         bool fused = attn_fused_ok(a);
 #ifdef ANTMMF_LAB
         static const char* bv_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_VARIANT");   // bit 3: the two-kernel backward everywhere (same-box A/B)
-        if (bv_env && (atoi(bv_env) & 8)) fused = false;
+        if (bv_env && (atoi(bv_env) & 8) && !a.sums) fused = false;
 #endif
         if (fused) {
 #ifdef ANTMMF_LAB
@@ -1353,21 +1436,24 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
 #endif
             const int nqp = ((a.Nq + 31) / 32) * 32, nkt = (a.Nk + 15) / 16, n_items = a.B * a.heads;
             // all sixteen resident key tiles present (the 197- / 257-token towers): the persistent form, one workgroup per CU walking the items
-            const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
-            const bool early = persist && nkt <= 8 && attn_fused_lds_bytes(a.Nq, a.Nk, true) <= 160 * 1024;
-            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk, early);
+            const bool sm = a.sums != nullptr;
+            const bool persist = (nkt <= 16 || nqp == 288) && attn_fused_lds_bytes(a.Nq, a.Nk, false, sm) <= 160 * 1024;   // (a 17th key tile with other query counts: run-time chunk loops, spills in the persistent form)
+            const bool early = persist && nkt <= 8 && attn_fused_lds_bytes(a.Nq, a.Nk, true, sm) <= 160 * 1024;
+            const size_t lds = attn_fused_lds_bytes(a.Nq, a.Nk, early, sm);
             unsigned pwgs = 256u;
 #ifdef ANTMMF_LAB
             static const char* pw_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_PERSIST_WGS");   // lab / emulator tests: a small grid makes every workgroup walk several items
             if (pw_env) pwgs = (unsigned)atoi(pw_env);
 #endif
             const dim3 pgrid(persist ? ((unsigned)n_items < pwgs ? (unsigned)n_items : pwgs) : (unsigned)n_items);
-#define BWDF(NKS, HASE, FULL, NQC, PERS, ABL) do { set_lds(attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL>, lds); \
-            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL>), pgrid, block, lds, stream, a, nqp, n_items); } while (0)
+#define BWDF_(NKS, HASE, FULL, NQC, PERS, ABL, EARLY, SUMS) do { set_lds(attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL, EARLY, SUMS>, lds); \
+            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, HASE, FULL, NQC, PERS, ABL, EARLY, SUMS>), pgrid, block, lds, stream, a, nqp, n_items); } while (0)
+#define BWDF(NKS, HASE, FULL, NQC, PERS, ABL) do { if (sm && a.sums_v) BWDF_(NKS, HASE, FULL, NQC, PERS, 0, false, 1); else if (sm) BWDF_(NKS, HASE, FULL, NQC, PERS, 0, false, 2); \
+                                                   else BWDF_(NKS, HASE, FULL, NQC, PERS, ABL, false, 0); } while (0)
 #ifdef ANTMMF_LAB
             static const char* abl_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_FUSED_ABL");   // timing-only ablations of the 257-token kernel (wrong results)
             const int abl = abl_env ? atoi(abl_env) : 0;
-            if (abl && persist && nkt > 16 && nqp == 288) {
+            if (abl && !sm && persist && nkt > 16 && nqp == 288) {
                 switch (abl) {
                     case 1: BWDF(8, true, true, 9, true, 1); return antmmf_check_launch();
                     case 2: BWDF(8, true, true, 9, true, 2); return antmmf_check_launch();
@@ -1388,16 +1474,16 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                 else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0, true, 0); else BWDF(7, false, false, 0, true, 0); }
                 else if (nkt > 8) { if (nkt > 10) BWDF(6, false, false, 0, true, 0); else BWDF(5, false, false, 0, true, 0); }
                 else if (early) {
-#define BWDE(NKS) do { set_lds(attn_bwd_fused64_kernel<NKS, false, false, 0, true, 0, true>, lds); \
-            hipLaunchKernelGGL((attn_bwd_fused64_kernel<NKS, false, false, 0, true, 0, true>), pgrid, block, lds, stream, a, nqp, n_items); } while (0)
+#define BWDE(NKS) BWDF_(NKS, false, false, 0, true, 0, true, 0)   /* (at most eight key tiles: never with the token sums, see attn_fused_ok) */
                     if (nkt > 6) BWDE(4); else if (nkt > 4) BWDE(3); else BWDE(2);
 #undef BWDE
                 }
-                else if (nkt > 6) BWDF(4, false, false, 0, true, 0);
-                else if (nkt > 4) BWDF(3, false, false, 0, true, 0);
-                else BWDF(2, false, false, 0, true, 0);
+                else if (nkt > 6) BWDF_(4, false, false, 0, true, 0, false, 0);
+                else if (nkt > 4) BWDF_(3, false, false, 0, true, 0, false, 0);
+                else BWDF_(2, false, false, 0, true, 0, false, 0);
             } else BWDF(8, true, true, 0, false, 0);
 #undef BWDF
+#undef BWDF_
             return antmmf_check_launch();
         }
     }
@@ -1460,6 +1546,33 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
                                     uint64_t dropout_seed, hipStream_t stream) {
     return antmmf_attention_bwd_hd(q, k, v, key_bias, o, lse, d_o, dq, dk, dv, B, heads, 64, Nq, Nk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, scale,
                                    dropout_p, dropout_seed, stream);
+}
+
+// The backward plus the per-batch-item token sums of dQ | dK | dV (fp32 sums of the unrounded gradients): sums[(b * 3 + {0: q, 1: k, 2: v}) * heads * 64 + h * 64 + e] =
+// sum_n dX[b, n, h, e] (the dV third only with want_dv != 0).  The q / k / v bias gradients of the layer are the column sums of this [B, 3 * heads * 64] matrix -- B rows instead of B * N: the column-sum passes
+// over dQ | dK | dV (one tensor pass each per layer) disappear.  Served by the one-kernel backward only (head size 64, 129 ... 272 keys, no dropout):
+// antmmf_attention_bwd_sums_ok says whether a shape is; anything else is ANTMMF_EINVAL (the caller then sums the columns of dq / dk / dv itself).
+extern "C" int antmmf_attention_bwd_sums_ok(int head_dim, int Nq, int Nk, float dropout_p) {
+    AttnArgs a{};
+    float dummy = 0.f;
+    a.Nq = Nq; a.Nk = Nk; a.drop_thr = (dropout_p > 0.f) ? 1u : 0u; a.sums = &dummy;
+    return head_dim == 64 && Nq > 0 && Nq <= 288 && Nk > 0 && attn_fused_ok(a) ? 1 : 0;
+}
+extern "C" int antmmf_attention_bwd_sums(const void* q, const void* k, const void* v, const float* key_bias, const void* o, const float* lse,
+                                         const void* d_o, void* dq, void* dk, void* dv, float* sums, int want_dv, int B, int heads, int Nq, int Nk, long ldq, long ldk,
+                                         long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale, hipStream_t stream) {
+    AttnArgs a{};
+    a.drop_thr = 0; a.drop_scale = 1.0f; a.drop_seed = 0;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)const_cast<void*>(o);
+    a.lse = const_cast<float*>(lse); a.d_o = (const bf16_t*)d_o; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.sums = sums; a.sums_v = want_dv ? 1 : 0;
+    if (!q || !k || !v || !o || !lse || !d_o || !dq || !dk || !dv || !sums || !attn_args_ok(a, 64) || (lddo & 7) || (lddq & 3) || (lddk & 3) || (lddv & 3) || (ldo & 7))
+        return ANTMMF_EINVAL;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o | (uintptr_t)o) & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7))
+        return ANTMMF_EINVAL;
+    if (!attn_fused_ok(a)) return ANTMMF_EINVAL;
+    return attn_bwd_launch<64>(a, stream);
 }
 
 // ---- key importance: column sums of the attention probabilities --------------------------------------------------------------------------------

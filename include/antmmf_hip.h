@@ -221,6 +221,20 @@ int antmmf_attention_bwd_hd(const void* q, const void* k, const void* v, const f
                             int64_t lddk, int64_t lddv, float scale, float dropout_p, uint64_t dropout_seed,
                             antmmf_stream_t stream);
 
+/* antmmf_attention_bwd (head size 64, no dropout) that also returns, per batch item, the sums over the tokens of dQ | dK | dV (fp32, of the unrounded gradients):
+ *   sums[(b * 3 + {0: q, 1: k, 2: v}) * heads * 64 + h * 64 + e] = sum_n dX[b, n, h, e]            ([B, 3 * heads * 64], caller-owned; every element is written,
+ *   the dV third only with want_dv != 0: torchscale's value-bias gradient comes out of the inner LayerNorm's backward, sum_k dV[k] = sum_q dO[q] per head)
+ * The bias gradients of the q / k / v projections (nn.MultiheadAttention in_proj_bias clip/model.py:222-251; BertSelfAttention query / key / value
+ * modeling_bert.py:140-146; torchscale q_proj / k_proj / v_proj multihead_attention.py:66-71) are the column sums of that B-row matrix -- autograd's sum over the
+ * B * N rows of dQ | dK | dV (one pass over each tensor per layer) is not needed any more.  Served by the one-kernel backward only: antmmf_attention_bwd_sums_ok
+ * returns 1 for the shapes it takes (head size 64, no dropout, 129 ... 272 keys: below that the sums cost the kernel more than the pass they save), antmmf_attention_bwd_sums returns ANTMMF_EINVAL for any other --
+ * the caller then runs antmmf_attention_bwd and sums the columns itself (antmmf_colsum). */
+int antmmf_attention_bwd_sums_ok(int head_dim, int Nq, int Nk, float dropout_p);
+int antmmf_attention_bwd_sums(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
+                              const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* sums, int want_dv, int B, int heads,
+                              int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                              int64_t lddk, int64_t lddv, float scale, antmmf_stream_t stream);
+
 /* dropout_p > 0: attention-probability dropout (BertSelfAttention, modeling_bert.py:157) with a counter-based mask
  * keep(seed, ((b * heads + h) * Nq + q) * Nk + k) that forward and backward regenerate identically (nothing is stored);
  * pass the same (dropout_p, dropout_seed) to both calls. */

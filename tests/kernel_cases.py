@@ -505,6 +505,20 @@ def case_attention(ops, dev, B=2, heads=2, Nq=17, Nk=17, bias_kind="none", packe
     check(tag + ".dq", dq, qr.grad, 3e-2, 3e-2)
     check(tag + ".dk", dk, kr.grad, 3e-2, 3e-2)
     check(tag + ".dv", dv, vr.grad, 3e-2, 3e-2)
+    if head_dim == 64 and ops.attention_bwd_sums_ok(head_dim, Nq, Nk):
+        # the same backward with the per-batch-item token sums of dQ | dK | dV (the q / k / v bias gradients' raw material): gradients bit-identical to the
+        # plain call, sums = fp32 sums of the unrounded gradients -- against the oracle's gradients and against the sums of the bf16 outputs
+        sums = torch.full((B, 3 * D), float("nan"), dtype=torch.float32, device=dev)
+        dq2, dk2, dv2 = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, kb, sums=sums)
+        assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv), tag + ": gradients differ with sums requested"
+        ref_s = torch.cat([qr.grad.sum(1), kr.grad.sum(1), vr.grad.sum(1)], dim=1)
+        own_s = torch.cat([dq.float().sum(1), dk.float().sum(1), dv.float().sum(1)], dim=1)
+        check(tag + ".sums", sums, ref_s, 3e-2, 3e-2)
+        check(tag + ".sums_vs_outputs", sums, own_s, 2e-2, 2e-2)
+        sums2 = torch.full((B, 3 * D), 7.0, dtype=torch.float32, device=dev)   # without the dV third: left as it was, the rest the same bits
+        dq3, dk3, dv3 = ops.attention_bwd(qd, kd, vd, o, lse, d_o.to(dev, BF), heads, scale, kb, sums=sums2, sums_v=False)
+        assert torch.equal(dq3, dq) and torch.equal(dk3, dk) and torch.equal(dv3, dv)
+        assert torch.equal(sums2[:, :2 * D], sums[:, :2 * D]) and bool((sums2[:, 2 * D:] == 7.0).all()), tag + ": sums without dV"
 
 
 # ------------------------------------------------------------------------------ losses

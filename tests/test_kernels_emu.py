@@ -279,9 +279,12 @@ def test_attention_backward_one_kernel(ops):
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=150, Nk=130, bias_kind="bert", packed=False)
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=20, Nk=256, bias_kind="none", packed=False)
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=288, Nk=272, bias_kind="inf", packed=False)
-    assert lib.antmmf_debug_attn_fused_launches() == n0 + 6, "the one-kernel backward did not run"
+    assert lib.antmmf_debug_attn_fused_launches() == n0 + 18, "the one-kernel backward did not run"   # (each case three times: without the token sums, with them, with them but dV's)
     kc.case_attention(ops, DEV, B=1, heads=1, Nq=40, Nk=32, bias_kind="none", packed=False)   # (one or two key tiles: two kernels)
-    assert lib.antmmf_debug_attn_fused_launches() == n0 + 6
+    assert lib.antmmf_debug_attn_fused_launches() == n0 + 18
+    kc.case_attention(ops, DEV, B=2, heads=1, Nq=230, Nk=230, bias_kind="bert")               # (fifteen key tiles)
+    assert lib.antmmf_debug_attn_fused_launches() == n0 + 21
+    assert not ops.attention_bwd_sums_ok(64, 257, 257, 0.1) and not ops.attention_bwd_sums_ok(128, 257, 257) and not ops.attention_bwd_sums_ok(64, 77, 77) and ops.attention_bwd_sums_ok(64, 257, 257)
 
 
 def test_attention_backward_one_kernel_persistent_walk():

@@ -318,6 +318,38 @@ def test_attention_backward_one_kernel_runs_and_repeats():
             assert err <= 2.0 ** -6 * b.abs().max().item(), (name, err, b.abs().max().item())   # both round fp32 sums of the same products to bf16 (different summation orders)
 
 
+@pytest.mark.parametrize("B,h,N,masked", [(48, 16, 257, False), (70, 16, 129, True), (40, 12, 197, False), (300, 12, 160, True)])
+def test_attention_backward_token_sums_at_tower_shapes(ops, B, h, N, masked):
+    """antmmf_attention_bwd_sums at the towers' shapes, more (b, h) items than the 256 persistent workgroups (every workgroup walks several items: the per-wave partials in
+    LDS are rewritten per item): gradients bit-identical to the plain backward, the [B, 3 D] token sums equal to the sums of the gradients it stored (to their bf16
+    rounding), every element written; the q / k / v bias gradient = their column sums against the column sums of dQ | dK | dV."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    D = h * 64
+    qkv = torch.randn(B, N, 3 * D, generator=g, device=DEV).bfloat16()
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    kb = None
+    if masked:
+        lengths = torch.randint(3, N + 1, (B,), generator=g, device=DEV)
+        kb = torch.zeros(B, N, device=DEV).masked_fill(torch.arange(N, device=DEV)[None, :] >= lengths[:, None], float("-inf"))
+    o, lse = ops.attention_fwd(q, k, v, h, 0.125, kb)
+    do = torch.randn(B, N, D, generator=g, device=DEV).bfloat16()
+    assert ops.attention_bwd_sums_ok(64, N, N)
+    r1 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, kb)
+    sums = torch.full((B, 3 * D), float("nan"), device=DEV)
+    r2 = ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, kb, sums=sums)
+    assert all(torch.equal(a, b) for a, b in zip(r1, r2))
+    assert torch.isfinite(sums).all()
+    own = torch.cat([t.float().sum(1) for t in r1], dim=1)
+    scale = own.abs().max().item()
+    err = (sums - own).abs().max().item()
+    assert err <= 2e-2 * scale, (err, scale)   # N bf16 roundings of 2^-9 relative each, random signs
+    bias = torch.zeros(3 * D, device=DEV)
+    ops.colsum_(bias, sums)
+    ref = torch.zeros(3 * D, device=DEV)
+    ops.colsum_(ref, torch.cat(r1, dim=2).view(B * N, 3 * D))
+    assert (bias - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("variant", [4, 6])
 def test_attention_fwd32_opt_in(variant):
     """The opt-in forward on 32 x 32 x 16 MFMA tiles (ANTMMF_ATTN_VARIANT bit 2; bit 1: 64-key softmax blocks) at the towers' sizes: 257 tokens x 16 heads (ViT-L/14),

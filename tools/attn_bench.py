@@ -42,12 +42,20 @@ def main():
         dq, dk, dv = dqkv[..., :h * 64], dqkv[..., h * 64:2 * h * 64], dqkv[..., 2 * h * 64:]
         o, lse = ops.attention_fwd(q, k, v, h, 0.125)
         do = torch.randn_like(o)
+        sums = torch.empty(B, 3 * h * 64, dtype=torch.float32, device=dev)
+        bias_grad = torch.zeros(3 * h * 64, dtype=torch.float32, device=dev)
         fl = 4.0 * B * h * N * N * 64
         e = B * N * h * 64 * 2  # bytes of one [B, N, 1024] bf16 tensor
         for name, fn, flops, nbytes in (
             (f"attention.fwd.N{N}", lambda: ops.attention_fwd(q, k, v, h, 0.125), fl, 4 * e),
             (f"attention.bwd.N{N}", lambda: ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, dq=dq, dk=dk, dv=dv), 2.5 * fl, 8 * e),
+            # the same with the per-item token sums of dQ | dK | dV (round 6), and what they replace: a column-sum pass over the [B * N, 3 * D] gradient
+            (f"attention.bwd_sums.N{N}", lambda: ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, dq=dq, dk=dk, dv=dv, sums=sums), 2.5 * fl, 8 * e),
+            (f"colsum.dqkv.N{N}", lambda: ops.colsum_(bias_grad, dqkv.view(B * N, 3 * h * 64)), 0.0, 3 * e),
+            (f"colsum.sums.N{N}", lambda: ops.colsum_(bias_grad, sums), 0.0, B * 3 * h * 64 * 4),
         ):
+            if "sums" in name and not ops.attention_bwd_sums_ok(64, N, N):
+                continue
             ms = timeit(fn, iters)
             d = {"tag": tag, "kernel": name, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1), "gbs_min": round(nbytes / ms / 1e6, 1)}
             print(json.dumps(d), flush=True)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 6 (second session): q / k / v bias gradients out of the attention backward's token sums.
+#   gpu_r6b.sh sums     attention tests, isolated bench (with / without the sums, the column-sum passes they replace), step A/B on l14 and vtp8
+mkdir -p gpurun_out; export TMPDIR=/tmp
+case "$1" in
+sums)
+  python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "attention" --timeout 900 2>&1 | tail -5
+  python -m pytest tests/test_e2e_gpu.py -m gpu -q -k "layer or m2 or bert or univl_stage1" --timeout 900 2>&1 | tail -5
+  python tools/attn_bench.py r6b_sums 10
+  ATTN_BENCH_SHAPES="1024x12x197,512x12x197" python tools/attn_bench.py r6b_sums_b16 10
+  for rep in 1 2; do
+    for fl in 1 0; do
+      echo "=== l14 ATTN_BWD_SUMS=$fl (rep $rep)"
+      timeout 600 python tools/bench_flag.py ATTN_BWD_SUMS=$fl -- --no-cpu-baseline --steps 8 --warmup 3 2> gpurun_out/r6b_l14_sums$fl.err | tee gpurun_out/r6b_bench_l14_sums${fl}_rep$rep.json | cut -c1-260
+    done
+  done
+  for fl in 1 0; do
+    echo "=== rocprofv3 stats, l14 ATTN_BWD_SUMS=$fl"
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r6b_prof_sums$fl -o prof -- python $GRAFT_REPO_ROOT/tools/bench_flag.py ATTN_BWD_SUMS=$fl -- --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r6b_prof_sums$fl.log 2>&1)
+    f=$(find gpurun_out/r6b_prof_sums$fl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r6b_l14_sums${fl}_kernel_stats.csv && python tools/kernel_families.py "$f" | tee gpurun_out/r6b_l14_sums${fl}_families.txt
+    find gpurun_out/r6b_prof_sums$fl -type f ! -name "*stats*" -delete 2>/dev/null
+  done
+  for fl in 1 0; do
+    echo "=== vtp8 ATTN_BWD_SUMS=$fl"
+    timeout 600 python tools/bench_flag.py ATTN_BWD_SUMS=$fl -- --workload vtp8 --no-cpu-baseline --steps 5 --warmup 2 2> gpurun_out/r6b_vtp8_sums$fl.err | tee gpurun_out/r6b_bench_vtp8_sums$fl.json | cut -c1-260
+  done
+  ;;
+esac
