@@ -270,6 +270,12 @@ def test_transformer_layer_real_width_vs_oracle(kind, d, heads, N, pad):
     print(mc.case_layer_real_width(DEV, kind=kind, d=d, heads=heads, N=N, B=2, pad_tail=pad))
 
 
+def test_bert_last_layer_cls_only_gradient_vs_oracle():
+    """The last BertLayer under the gradient the contrastive step gives it ([CLS] row only): every parameter gradient -- the ~ 1e-4-share query / key projections
+    included -- against the fp32 oracle layer on the same inputs (these two were 'excused, not pinned' in the whole-model cases)."""
+    print(mc.case_bert_layer_cls_only_gradient(DEV))
+
+
 @pytest.mark.parametrize("N,B,pad", [(257, 2, 0), (77, 3, 30), (256, 32, 0)])
 def test_m2_layer_real_width_sub_ln_fold(N, B, pad, lab_lib):
     """(lab library) The M2 layer at ViT-L/14 width with the optional sub-LN fold (kept-activation policy, functional.set_ffn_fold) vs the fp32 oracle at the same gates (cosine >= 0.999, norm
