@@ -71,6 +71,7 @@ struct AttnArgs {
     // one-kernel backward only (antmmf_attention_bwd_sums): per batch item, the sums over the tokens of dQ | dK | dV -- what the q / k / v bias gradients are made of --
     // sums[(b * 3 + {0: q, 1: k, 2: v}) * heads * 64 + h * 64 + e], fp32; NULL = not wanted
     float* sums;
+    int fwd_stagger;   // (lab experiment, see attn_fwd_kernel; 0 in the product)
     int sums_v;   // 0: the dV sums are not wanted (their slots stay unwritten) -- torchscale's value bias comes out of the inner LayerNorm's backward
 };
 
@@ -177,7 +178,9 @@ __device__ __forceinline__ void store_rows_paired(bf16_t* rowp, uint2 (&w)[NDT],
     }
 }
 
-template <int NCH, bool DROP, int DH>  // keys padded to 32 * NCH
+// ABL (lab library only, TIMING-ONLY, wrong results -- what each part of the forward costs, same box, same process; profiles/r6b_attn_fwd_ablations.txt): 1 the exponential
+// replaced by its argument, 2 no O / lse stores, 4 K / V not fetched (zeros staged), 8 no P.V contraction, 16 no Q.K contraction, 32 Q not fetched
+template <int NCH, bool DROP, int DH, int ABL = 0>  // keys padded to 32 * NCH
 __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kernel(const AttnArgs a) {
     ANTMMF_DYN_LDS(char, smem);
     constexpr int NKP = 32 * NCH, NT = 2 * NCH, RB = 2 * DH, KM = DH / 32, DT = DH / 16;
@@ -186,7 +189,19 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
     float* kb = reinterpret_cast<float*>(Vs + NKP * RB);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, grp = lane >> 4;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    stage_rows2<DH, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, a.Nk, NKP);
+#if defined(ANTMMF_LAB) && !defined(ANTMMF_EMULATE)
+    // LAB experiment (round 6, measured: no effect -- profiles/r6b_attn_fwd_stagger.txt).  Two workgroups share a CU, and each is "fetch K / V (nothing to compute), then
+    // compute (nothing to fetch)"; the timing-only ablations (profiles/r6b_attn_fwd_ablations.txt: 0.41 ms with no memory traffic, 0.50 without the K / V fetch, 0.63 without
+    // the stores, 0.72 - 0.73 with everything) read like "no overlap", and one explanation would be that the launch's first 2 x 256 workgroups start together, every item takes the
+    // same time, and the two on a CU stay in phase.  So: the workgroup in the UPPER half of its CU's LDS (HW_REG_LDS_ALLOC: a non-zero base) starts ANTMMF_ATTN_FWD_STAGGER x 4 us
+    // late, once.  0.73 - 0.75 ms for 0 ... 24 us: the pairs are not in lock step; what is exposed is that ONE workgroup computing alone (2 waves per SIMD of dependent
+    // LDS -> MFMA -> VALU chains) does not run the CU at the rate two do, while its partner waits ~ 3.4 us per item for K / V.
+    if (a.fwd_stagger > 0 && blockIdx.x < 512u) {
+        const unsigned lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // LDS_BASE in the low bits
+        if (lds_alloc & 0xfffu) for (int i = 0; i < a.fwd_stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    stage_rows2<DH, NKP>(Ks, a.k + (long)b * a.Nk * a.ldk + h * DH, a.ldk, Vs, a.v + (long)b * a.Nk * a.ldv + h * DH, a.ldv, (ABL & 4) ? 0 : a.Nk, NKP);
     stage_key_bias(kb, a, b, NKP);
     __syncthreads();
 
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
         return a.q + ((long)b * a.Nq + (qi < a.Nq ? qi : a.Nq - 1)) * a.ldq + h * DH + grp * 8;
     };
     bf16x8_t nq[KM] = {};
-    if (wave < nqt) {
+    if (wave < nqt && !(ABL & 32)) {
         const bf16_t* p0 = q_ptr(wave);
 #pragma unroll
         for (int j = 0; j < KM; ++j) nq[j] = load_frag_global(p0 + 32 * j);
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
         bf16x8_t qf[KM];
 #pragma unroll
         for (int j = 0; j < KM; ++j) qf[j] = nq[j];
-        if (qt + ATTN_THREADS / 64 < nqt) {
+        if (qt + ATTN_THREADS / 64 < nqt && !(ABL & 32)) {
             const bf16_t* p1 = q_ptr(qt + ATTN_THREADS / 64);
 #pragma unroll
             for (int j = 0; j < KM; ++j) nq[j] = load_frag_global(p1 + 32 * j);
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < KM; ++j)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, 16 * t + l15, 4 * j + grp), qf[j], acc, 0, 0, 0);
+                if constexpr (!(ABL & 16)) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, 16 * t + l15, 4 * j + grp), qf[j], acc, 0, 0, 0);
             const float4 bias = *reinterpret_cast<const float4*>(kb + 16 * t + 4 * grp);
             s[t][0] = acc[0] * scale2 + bias.x; s[t][1] = acc[1] * scale2 + bias.y;
             s[t][2] = acc[2] * scale2 + bias.z; s[t][3] = acc[3] * scale2 + bias.w;
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = EXP2F(s[t][r] - m); sum += s[t][r]; }
+            for (int r = 0; r < 4; ++r) { s[t][r] = (ABL & 1) ? (s[t][r] - m) : EXP2F(s[t][r] - m); sum += s[t][r]; }
         sum = grp_sum(sum);
         float inv = sum > 0.f ? fast_rcp(sum) : 0.f;  // applied to the 16 output values, not the Nk probabilities
         if (DROP) {  // drop probabilities (the softmax denominator keeps every key, as in the reference)
@@ -258,11 +273,19 @@ __global__ __launch_bounds__(ATTN_THREADS, DH == 64 ? 2 : 1) void attn_fwd_kerne
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
+                if constexpr (!(ABL & 8)) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokens<DH>(Vs, c, dt, grp, l15), pf[c], o, 0, 0, 0);
+                else if (c == 0) { union { bf16x8_t f; uint4 u; } cv_; cv_.f = pf[dt]; o[0] = __uint_as_float(cv_.u.x); o[1] = __uint_as_float(cv_.u.y); o[2] = __uint_as_float(cv_.u.z); o[3] = __uint_as_float(cv_.u.w); }   // (keeps the probabilities alive)
             ow[dt] = make_uint2(pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv));
         }
+        if constexpr (ABL & 2) {   // (one dword per wave and tile keeps every value alive)
+            float keep_ = sum + m;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) keep_ += __uint_as_float(ow[dt].x) + __uint_as_float(ow[dt].y);
+            if (keep_ == 1.2345f) a.lse[0] = keep_;
+        } else {
         store_rows_paired<DT>(a.o + ((long)b * a.Nq + qrow) * a.ldo + h * DH, ow, lane, grp, qi < a.Nq, o_al16);
         if (grp == 0 && qi < a.Nq) a.lse[((long)b * a.heads + h) * a.Nq + qi] = sum > 0.f ? (m + LOG2F(sum)) * LN2 : -INFINITY;
+        }
     }
 }
 
@@ -1411,6 +1434,18 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t stream) {
         }
     }
 #endif
+#ifdef ANTMMF_LAB
+    if constexpr (DH == 64) {
+        static const char* fa_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_FWD_ABL");   // timing-only ablations of the 257-token forward (wrong results)
+        const int fa = fa_env ? atoi(fa_env) : 0;
+        if (fa && nch == 9 && !a.drop_thr) {
+            const size_t lds = (size_t)(32 * 9) * (4 * DH) + (32 * 9) * 4;
+#define FWDA(A) case A: set_lds(attn_fwd_kernel<9, false, 64, A>, lds); hipLaunchKernelGGL((attn_fwd_kernel<9, false, 64, A>), grid, block, lds, stream, a); return antmmf_check_launch();
+            switch (fa) { FWDA(1) FWDA(2) FWDA(4) FWDA(8) FWDA(16) FWDA(32) FWDA(24) FWDA(25) FWDA(38) FWDA(63) FWDA(27) default: break; }
+#undef FWDA
+        }
+    }
+#endif
     if (nch <= 1) FWD(1); else if (nch <= 3) FWD(3); else if (nch <= 7) FWD(7); else FWD(9);
 #undef FWD
     return antmmf_check_launch();
@@ -1512,6 +1547,11 @@ extern "C" int antmmf_attention_fwd_hd(const void* q, const void* k, const void*
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.key_bias = key_bias; a.o = (bf16_t*)o; a.lse = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     if (!q || !k || !v || !o || !lse || !attn_args_ok(a, head_dim)) return ANTMMF_EINVAL;
+    a.fwd_stagger = 0;
+#ifdef ANTMMF_LAB
+    static const char* st_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_FWD_STAGGER");
+    if (st_env) a.fwd_stagger = atoi(st_env);
+#endif
     return head_dim == 64 ? attn_fwd_launch<64>(a, stream) : attn_fwd_launch<128>(a, stream);
 }
 

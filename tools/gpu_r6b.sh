@@ -25,4 +25,22 @@ sums)
     timeout 600 python tools/bench_flag.py ATTN_BWD_SUMS=$fl -- --workload vtp8 --no-cpu-baseline --steps 5 --warmup 2 2> gpurun_out/r6b_vtp8_sums$fl.err | tee gpurun_out/r6b_bench_vtp8_sums$fl.json | cut -c1-260
   done
   ;;
+fwdabl)
+  # timing-only ablations of the 257-token attention forward (lab library): what each part costs, same box, same process order A B A B
+  export ANTMMF_HIP_LIB=$PWD/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so
+  for rep in 1 2; do
+    for abl in 0 1 2 4 8 16 32 24 25 38 27 63; do
+      ANTMMF_ATTN_FWD_ABL=$abl ATTN_BENCH_SHAPES="1024x16x257" python tools/attn_bench.py fwdabl_$abl 20 2>/dev/null | grep "attention.fwd" | sed "s/^/abl=$abl rep=$rep /"
+    done
+  done | tee gpurun_out/r6b_attn_fwd_ablations.txt
+  ;;
+stagger)
+  # attention forward with the first-wave stagger (lab knob ANTMMF_ATTN_FWD_STAGGER = number of 4-us sleeps of the upper-LDS-half workgroups), A B A B
+  export ANTMMF_HIP_LIB=$PWD/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so
+  for rep in 1 2; do
+    for st in 0 1 2 3 4 6; do
+      ANTMMF_ATTN_FWD_STAGGER=$st ATTN_BENCH_SHAPES="1024x16x257,1024x16x77,1024x12x197" python tools/attn_bench.py stagger_$st 20 2>/dev/null | grep "attention.fwd" | sed "s/^/stagger=$st rep=$rep /"
+    done
+  done | tee gpurun_out/r6b_attn_fwd_stagger.txt
+  ;;
 esac
