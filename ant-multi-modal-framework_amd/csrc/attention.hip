@@ -1275,14 +1275,18 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     // SUMS: ... summed over the chunks (unscaled) in this wave's own 16 floats of LDS (four accumulator registers across the main loop are four too many: 256 VGPRs + 156 B
     // of scratch in the 257-token form): closed over the 16 query lanes per chunk, read-modify-write by one lane per head-dim group -- only this wave touches the slot
     if constexpr (SUMS) { if (l15 == 0) *reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * grp) = make_float4(0.f, 0.f, 0.f, 0.f); }
+#ifdef ANTMMF_EMULATE
+#define FUSED_LDS_ADD(P, V) (*(P) += (V))
+#else
+#define FUSED_LDS_ADD(P, V) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(P), (V), 0, 0, false)
+#endif
 #define FUSED_QSUM_ACC(G0, G1)                                                                                                      \
     do {                                                                                                                            \
         const float4 t_ = make_float4(row16_sum((G0)[0] + (G1)[0]), row16_sum((G0)[1] + (G1)[1]), row16_sum((G0)[2] + (G1)[2]), row16_sum((G0)[3] + (G1)[3])); \
         FUSED_OPAQUE_LANE(ln_);                                                                                                     \
-        if ((ln_ & 15) == 0) {                                                                                                      \
-            float4* p_ = reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * (ln_ >> 4));                                       \
-            const float4 o_ = *p_;                                                                                                  \
-            *p_ = make_float4(o_.x + t_.x, o_.y + t_.y, o_.z + t_.z, o_.w + t_.w);                                                  \
+        if ((ln_ & 15) == 0) {   /* (return-less LDS adds: nothing to wait for -- a read-modify-write would park the wave on lgkmcnt(0) in the middle of the chunk pipeline) */ \
+            float* p_ = sums + 1024 + wave * 16 + 4 * (ln_ >> 4);                                                                   \
+            FUSED_LDS_ADD(p_, t_.x); FUSED_LDS_ADD(p_ + 1, t_.y); FUSED_LDS_ADD(p_ + 2, t_.z); FUSED_LDS_ADD(p_ + 3, t_.w);         \
         }                                                                                                                           \
     } while (0)
     const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
@@ -1388,6 +1392,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
 #undef FUSED_SUMS_FINALIZE
 #undef FUSED_KT
 #undef FUSED_QSUM_ACC
+#undef FUSED_LDS_ADD
 #undef FUSED_OPAQUE_LANE
 #undef FUSED_DMA_K
 #undef FUSED_DMA_QD
