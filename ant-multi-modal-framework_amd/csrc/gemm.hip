@@ -1810,7 +1810,13 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
             }                                                                                                                       \
             if (ACT2) {                                                                                                             \
                 char* ab = reinterpret_cast<char*>(g.aux) + ((long)((ti0) + wi * 128 + it * 16) * g.ldaux + (tj0) + wj * 64) * 2;   \
-                if (ABL & 128) { K64R_GSTORE16(avoff, av2[0], ab, 0); K64R_GSTORE16(avoff, av2[1], ab, 64); }                       \
+                if (ABL & 2048) { K64R_KEEP(av2[0]); K64R_KEEP(av2[1]); }   /* timing only: the second output is not stored at all */ \
+                else if (ABL & 1024) {   /* timing only: the second output as ONE byte per element (dense [rows][ldaux] bytes in the first half of the buffer): what an 8-bit gate would store */ \
+                    char* ab1 = reinterpret_cast<char*>(g.aux) + ((long)((ti0) + wi * 128 + it * 16) * g.ldaux + (tj0) + wj * 64);  \
+                    const k64_u2_t h0 = {av2[0][0], av2[0][1]}, h1 = {av2[1][0], av2[1][1]};                                        \
+                    K64R_GSTORE8(avoff_t0 >> 1, h0, ab1); K64R_GSTORE8(avoff_t1 >> 1, h1, ab1);                                     \
+                }                                                                                                                   \
+                else if (ABL & 128) { K64R_GSTORE16(avoff, av2[0], ab, 0); K64R_GSTORE16(avoff, av2[1], ab, 64); }                  \
                 else { K64R_GSTORE16(avoff_t0, av2[0], ab, 0); K64R_GSTORE16(avoff_t1, av2[1], ab, 0); }                            \
             }                                                                                                                       \
             if (ABL & 1) { K64R_KEEP(ov2[0]); K64R_KEEP(ov2[1]); }                                                                  \
@@ -2619,6 +2625,11 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
             const unsigned gridp = pwgs < t8 ? pwgs : t8;
             static bool once5 = false;
             if (!once5) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once5 = true; }
+            // LAB, timing only (variant bits 28 / 29): the second output as one byte per element / not stored at all -- what an 8-bit stored derivative could buy (profiles/r6b_gemm_two_output_store_ablation.txt)
+            LAB_ONLY(if (g_gemm_variant & (1 << 28)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                       hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 1024>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); } else)
+            LAB_ONLY(if (g_gemm_variant & (1 << 29)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+                       hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 2048>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); } else)
             hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
         } else
         if (k64p && gate && !g.gate_grad && act != ANTMMF_ACT_NONE && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {

@@ -43,4 +43,7 @@ stagger)
     done
   done | tee gpurun_out/r6b_attn_fwd_stagger.txt
   ;;
+twoout)
+  ANTMMF_HIP_LIB=$PWD/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so python tools/gemm_two_output_bench.py 10 2>/dev/null | tee gpurun_out/r6b_gemm_two_output_store_ablation.txt
+  ;;
 esac
