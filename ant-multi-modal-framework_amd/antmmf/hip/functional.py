@@ -404,6 +404,9 @@ def set_keep_ffn_norm(flag):
 FFN_FOLD = False
 # q / k / v bias gradients out of the attention backward's per-item token sums (round 6; module flag for the A/B, tools/colsum_ab.py)
 ATTN_BWD_SUMS = True
+# Keep the output of the pre-LN layers' second LayerNorm (fc1's input, + 2 B per token-channel: 15.7 GiB on the l14 step at 1024 pairs) for backward instead of having the
+# LayerNorm backward re-emit it (5 -> 4 tensor streams in that kernel).  EXPERIMENT (round 6, tools/bench_flag.py KEEP_LN2_OUT=1): off; see docs/rounds/round-6.md
+KEEP_LN2_OUT = False
 if os.environ.get("ANTMMF_FFN_FOLD"):   # rounds 3 - 4 read this variable; since round 5 the fold is an experiment of the lab library behind set_ffn_fold()
     import warnings
 
@@ -518,6 +521,7 @@ class _TransformerLayer(torch.autograd.Function):
         saved.append(kept_gn)
         y3 = y.view(B, N, d)
         saved.append(y3 if fold else None)   # the fold's backward takes one of the LayerNorm's row means from the layer output (an output may be saved)
+        saved.append(h2 if (KEEP_LN2_OUT and pre_ln) else None)
         ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.shape, ctx.nsaved, ctx.drop = spec, (B, N, d), len(saved), (p_att, p_hid, seed)
         ctx.u_is_grad = bool(KEEP_FFN_NORM and spec.kind != "m2")
@@ -532,7 +536,7 @@ class _TransformerLayer(torch.autograd.Function):
         sv = ctx.saved_tensors
         x2, qkv, o, lse, mid, u, key_bias = sv[:7]
         (m1, r1, mi, ri, m2_, r2, mf, rf, my, ry) = sv[7:17]
-        s2, kept_gn, y_out = sv[17], sv[18], sv[19]
+        s2, kept_gn, y_out, kept_h2 = sv[17], sv[18], sv[19], sv[20]
         params = sv[ctx.nsaved:]
         P = dict(zip(SLOTS, params))
         sink = GradSink()
@@ -618,7 +622,10 @@ class _TransformerLayer(torch.autograd.Function):
         bo_sum = sink.buf(P["bo"]) if bo_fused else None
         if pre_ln:
             dh2 = dgrad(du, P["w1"])
-            dmid, h2 = ops.layernorm_bwd_renorm(dh2, mid, m2_, r2, f32(P["ln2_w"]), f32(P["ln2_b"]), dgw, dgb, dres=ds2, dxsum=bo_sum)  # + residual path
+            if kept_h2 is not None:   # (experiment: the normalised tensor was kept -- the plain backward, four streams)
+                dmid, h2 = ops.layernorm_bwd(dh2, mid, m2_, r2, f32(P["ln2_w"]), dgw, dgb, dres=ds2, dxsum=bo_sum), kept_h2
+            else:
+                dmid, h2 = ops.layernorm_bwd_renorm(dh2, mid, m2_, r2, f32(P["ln2_w"]), f32(P["ln2_b"]), dgw, dgb, dres=ds2, dxsum=bo_sum)  # + residual path
             del dh2
         else:
             da = dgrad(du, P["w1"], residual=ds2)  # bert: a feeds the MLP and the residual

@@ -46,4 +46,18 @@ stagger)
 twoout)
   ANTMMF_HIP_LIB=$PWD/ant-multi-modal-framework_amd/lib/libantmmf_hip_lab.so python tools/gemm_two_output_bench.py 10 2>/dev/null | tee gpurun_out/r6b_gemm_two_output_store_ablation.txt
   ;;
+keepln2)
+  # EXPERIMENT: keep the second LayerNorm's output for backward (4 instead of 5 streams in its backward kernel, + 2 B per token-channel): step A/B at 896 pairs (room for the 13.7 GiB), A B A B
+  for rep in 1 2; do
+    for fl in 1 0; do
+      echo "=== l14 batch 896 KEEP_LN2_OUT=$fl (rep $rep)"
+      timeout 600 python tools/bench_flag.py KEEP_LN2_OUT=$fl -- --batch 896 --no-cpu-baseline --steps 8 --warmup 3 2> gpurun_out/r6b_keepln2_$fl.err | tee gpurun_out/r6b_bench_l14_b896_keepln2_${fl}_rep$rep.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['config'].get('peak_hbm_gib'), d['config'].get('reserved_hbm_gib'))"
+    done
+  done
+  for fl in 1 0; do
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r6b_prof_keepln2_$fl -o prof -- python $GRAFT_REPO_ROOT/tools/bench_flag.py KEEP_LN2_OUT=$fl -- --batch 896 --no-cpu-baseline --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/r6b_prof_keepln2_$fl.log 2>&1)
+    f=$(find gpurun_out/r6b_prof_keepln2_$fl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/kernel_families.py "$f" | tee gpurun_out/r6b_l14_b896_keepln2_${fl}_families.txt | head -12
+    find gpurun_out/r6b_prof_keepln2_$fl -type f ! -name "*stats*" -delete 2>/dev/null
+  done
+  ;;
 esac
