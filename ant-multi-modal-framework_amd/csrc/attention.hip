@@ -984,7 +984,7 @@ __device__ __forceinline__ void attn_dma_piece(char* tile, uint32_t tile_lds, co
                 *reinterpret_cast<uint2*>(a.dq + ((long)b * a.Nq + qi_) * a.lddq + h * 64 + 16 * qdt + 4 * grp) =                           \
                     make_uint2(pack_bf2((g0_[0] + g1_[0]) * a.scale, (g0_[1] + g1_[1]) * a.scale),                                          \
                                pack_bf2((g0_[2] + g1_[2]) * a.scale, (g0_[3] + g1_[3]) * a.scale));                                         \
-            if constexpr (SUMS) FUSED_QSUM_ACC(g0_, g1_);   /* (padding queries: their dS^T rows are exactly 0) */                           \
+            if constexpr (SUMS && !(SUMS & 16)) FUSED_QSUM_ACC(g0_, g1_);   /* (padding queries: their dS^T rows are exactly 0) */                           \
         }                                                                                                                                   \
     } while (0)
 #define FUSED_CHUNK(C, NH, BEFORE, AFTER)                                                                                                   \
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     // the end of the item, with a barrier of its own, it cost the short towers 10 - 16 % (0.46 -> 0.51 ms at 77 tokens: ~ 1 us per item of 6 us)
 #define FUSED_SUMS_FINALIZE(ITEM)                                                                                                            \
     do {                                                                                                                                    \
-        if (wave < (SUMS == 1 ? 3 : 2)) {                                                                                                   \
+        if (wave < ((SUMS & 3) == 1 ? 3 : 2)) {                                                                                                   \
             const int b_ = (ITEM) / a.heads, h_ = (ITEM) % a.heads;                                                                         \
             FUSED_OPAQUE_LANE(le_);                                                                                                         \
             float s_;                                                                                                                       \
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     if constexpr (PERSIST) {
         glds_wait_all();         // this wave's pieces of the item, its register prefetch (and everything older) have landed ...
         wg_barrier_lds_only();   // ... and so have the other waves' pieces
-        if constexpr (SUMS) { if (pitem >= 0) FUSED_SUMS_FINALIZE(pitem); }   // (the previous item's; this item's first write of that region is behind the next barrier)
+        if constexpr (SUMS && !(SUMS & 64)) { if (pitem >= 0) FUSED_SUMS_FINALIZE(pitem); }   // (the previous item's; this item's first write of that region is behind the next barrier)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {   // D = rowsum(dO o O): eight lanes per row, dO from the LDS tile
             const int id = wave * 64 + lane + i * ATTN_THREADS, row = id >> 3 < NQP ? id >> 3 : NQP - 1, slot = id & 7;
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
                 bf16_t* dst = (is_k ? a.dk + ((long)b * a.Nk + ki) * a.lddk : a.dv + ((long)b * a.Nk + ki) * a.lddv) + h * 64 + 16 * dt + 4 * grp;
                 *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2((g0[0] + g1[0]) * sc, (g0[1] + g1[1]) * sc), pack_bf2((g0[2] + g1[2]) * sc, (g0[3] + g1[3]) * sc));
             }
-            if (SUMS == 1 || (SUMS == 2 && is_k)) {   // this tile's share of the token sums (padding keys: exactly 0); waves 0 - 3: dV, 4 - 7: dK (unscaled), head-dim tile dt
+            if ((SUMS & 3) == 1 || ((SUMS & 3) == 2 && is_k)) {   // this tile's share of the token sums (padding keys: exactly 0); waves 0 - 3: dV, 4 - 7: dK (unscaled), head-dim tile dt
                 const float4 es = make_float4(row16_sum(g0[0] + g1[0]), row16_sum(g0[1] + g1[1]), row16_sum(g0[2] + g1[2]), row16_sum(g0[3] + g1[3]));
                 if (l15 == 0) *reinterpret_cast<float4*>(sums + 1152 + wave * 16 + 4 * grp) = es;
             }
@@ -1274,21 +1274,14 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
     const int qdt = wave & 3, qqt = wave >> 2;   // this wave's dQ^T tile of every chunk
     // SUMS: ... summed over the chunks (unscaled) in this wave's own 16 floats of LDS (four accumulator registers across the main loop are four too many: 256 VGPRs + 156 B
     // of scratch in the 257-token form): closed over the 16 query lanes per chunk, read-modify-write by one lane per head-dim group -- only this wave touches the slot
-    if constexpr (SUMS) { if (l15 == 0) *reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * grp) = make_float4(0.f, 0.f, 0.f, 0.f); }
+    f32x4_t qsum = {0.f, 0.f, 0.f, 0.f};
+    (void)qsum;
 #ifdef ANTMMF_EMULATE
 #define FUSED_LDS_ADD(P, V) (*(P) += (V))
 #else
 #define FUSED_LDS_ADD(P, V) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(P), (V), 0, 0, false)
 #endif
-#define FUSED_QSUM_ACC(G0, G1)                                                                                                      \
-    do {                                                                                                                            \
-        const float4 t_ = make_float4(row16_sum((G0)[0] + (G1)[0]), row16_sum((G0)[1] + (G1)[1]), row16_sum((G0)[2] + (G1)[2]), row16_sum((G0)[3] + (G1)[3])); \
-        FUSED_OPAQUE_LANE(ln_);                                                                                                     \
-        if ((ln_ & 15) == 0) {   /* (return-less LDS adds: nothing to wait for -- a read-modify-write would park the wave on lgkmcnt(0) in the middle of the chunk pipeline) */ \
-            float* p_ = sums + 1024 + wave * 16 + 4 * (ln_ >> 4);                                                                   \
-            FUSED_LDS_ADD(p_, t_.x); FUSED_LDS_ADD(p_ + 1, t_.y); FUSED_LDS_ADD(p_ + 2, t_.z); FUSED_LDS_ADD(p_ + 3, t_.w);         \
-        }                                                                                                                           \
-    } while (0)
+#define FUSED_QSUM_ACC(G0, G1) do { qsum += (G0) + (G1); } while (0)
     const int s_q = 4 * qqt + (l15 & 3), rr = 4 * grp + (l15 >> 2);
     // KREG: the K^T fragments of this wave's head-dim tile -- the same for every chunk -- in registers (36 VGPRs): 18 transposing reads less per chunk, and the K tile is
     // free as soon as every wave holds its fragments, so the NEXT item's K is requested here, under the whole main loop, instead of at the item boundary where nothing hides
@@ -1365,17 +1358,21 @@ __global__ __launch_bounds__(ATTN_THREADS, 1) void attn_bwd_fused64_kernel(const
         store_rows_paired<4>(a.dv + ((long)b * a.Nk + krow) * a.lddv + h * 64, vw, lane, grp, ki < a.Nk, dkv_al16);
         store_rows_paired<4>(a.dk + ((long)b * a.Nk + krow) * a.lddk + h * 64, kw, lane, grp, ki < a.Nk, dkv_al16);
     }
-    if constexpr (SUMS) {
+    if constexpr (SUMS && !(SUMS & 32)) {
         // token sums of this wave's dK / dV tiles (lane: key l15, head-dim 16 dt + 4 grp + r; tiles the wave does not own are zero): closed over the 16 lanes of a DPP
         // row, parked per wave in LDS
         FUSED_OPAQUE_LANE(ln);
         float* sw = sums + wave * 64 + 4 * (ln >> 4);
+        {
+            const float4 q4 = make_float4(row16_sum(qsum[0]), row16_sum(qsum[1]), row16_sum(qsum[2]), row16_sum(qsum[3]));
+            if ((ln & 15) == 0) *reinterpret_cast<float4*>(sums + 1024 + wave * 16 + 4 * (ln >> 4)) = q4;
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const f32x4_t ks = dk[0][dt] + dk[1][dt];
             const float4 k4 = make_float4(row16_sum(ks[0]), row16_sum(ks[1]), row16_sum(ks[2]), row16_sum(ks[3]));
             if ((ln & 15) == 0) *reinterpret_cast<float4*>(sw + 16 * dt) = k4;
-            if constexpr (SUMS == 1) {
+            if constexpr ((SUMS & 3) == 1) {
                 const f32x4_t vs = dv[0][dt] + dv[1][dt];
                 const float4 v4 = make_float4(row16_sum(vs[0]), row16_sum(vs[1]), row16_sum(vs[2]), row16_sum(vs[3]));
                 if ((ln & 15) == 0) *reinterpret_cast<float4*>(sw + 512 + 16 * dt) = v4;
@@ -1504,6 +1501,20 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                     case 15: BWDF(8, true, true, 9, true, 15); return antmmf_check_launch();
                     case 128: BWDF(8, true, true, 9, true, 128); return antmmf_check_launch();
                     case 256: BWDF(8, true, true, 9, true, 256); return antmmf_check_launch();
+                    default: break;
+                }
+            }
+#endif
+#ifdef ANTMMF_LAB
+            static const char* sa_env = ANTMMF_LAB_ENV("ANTMMF_ATTN_SUMS_ABL");   // timing-only (wrong sums): 16 no per-chunk dQ sums, 32 no end-of-item partials, 64 no finalisation
+            const int sa = sa_env ? atoi(sa_env) : 0;
+            if (sa && sm && persist && nkt > 16) {
+                switch (sa) {
+                    case 16: BWDF_(8, true, true, 9, true, 0, false, 2 | 16); return antmmf_check_launch();
+                    case 32: BWDF_(8, true, true, 9, true, 0, false, 2 | 32); return antmmf_check_launch();
+                    case 64: BWDF_(8, true, true, 9, true, 0, false, 2 | 64); return antmmf_check_launch();
+                    case 48: BWDF_(8, true, true, 9, true, 0, false, 2 | 48); return antmmf_check_launch();
+                    case 112: BWDF_(8, true, true, 9, true, 0, false, 2 | 112); return antmmf_check_launch();
                     default: break;
                 }
             }
