@@ -404,6 +404,7 @@ def set_keep_ffn_norm(flag):
 FFN_FOLD = False
 # q / k / v bias gradients out of the attention backward's per-item token sums (round 6; module flag for the A/B, tools/colsum_ab.py)
 ATTN_BWD_SUMS = True
+ATTN_BWD_SUMS_MIN_TOKENS = 33    # (tools/bench_flag.py A/B: 129 = the long towers only)
 # Keep the output of the pre-LN layers' second LayerNorm (fc1's input, + 2 B per token-channel: 15.7 GiB on the l14 step at 1024 pairs) for backward instead of having the
 # LayerNorm backward re-emit it (5 -> 4 tensor streams in that kernel).  EXPERIMENT (round 6, tools/bench_flag.py KEEP_LN2_OUT=1): off; see docs/rounds/round-6.md
 KEEP_LN2_OUT = False
@@ -661,8 +662,8 @@ class _TransformerLayer(torch.autograd.Function):
         # sums are the bias gradients, so the column-sum passes over the B * N rows of dQ | dK | dV (0.19 ms per image-tower layer of the flagship) are not run
         qkv_biases = [P["bqkv"]] if spec.packed_qkv else [P["bq"], P["bk"], P["bv"]]
         tok_sums = None
-        # (the library serves the long towers only -- at 77 - 86 tokens the sums cost the kernel more than the pass they save: profiles/r6b_attn_bwd_token_sums_ab.txt)
-        if (ATTN_BWD_SUMS and d == 64 * spec.heads and any(b_ is not None and b_.requires_grad for b_ in qkv_biases)
+        # (ATTN_BWD_SUMS_MIN_TOKENS = 129 restricts it to the long towers: the A/B of profiles/r6b_attn_bwd_token_sums_ab.txt -- the short towers gain too, a little)
+        if (ATTN_BWD_SUMS and N >= ATTN_BWD_SUMS_MIN_TOKENS and d == 64 * spec.heads and any(b_ is not None and b_.requires_grad for b_ in qkv_biases)
                 and ops.attention_bwd_sums_ok(64, N, N, p_att)):
             tok_sums = torch.empty(B, 3 * d, dtype=torch.float32, device=qkv.device)
         ops.attention_bwd(q3[..., :d], q3[..., d:2 * d], q3[..., 2 * d:], o, lse, do.view(B, N, d), spec.heads, scale, key_bias,

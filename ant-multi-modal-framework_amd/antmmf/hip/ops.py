@@ -563,7 +563,7 @@ def attention_key_importance_(out, q, k, lse, heads, scale, key_bias=None, dropo
 
 
 def attention_bwd_sums_ok(head_dim, Nq, Nk, dropout_p=0.0):
-    """True when attention_bwd(..., sums=...) is served: the one-kernel backward's shapes (head size 64, no dropout, 129 ... 272 keys)."""
+    """True when attention_bwd(..., sums=...) is served: the one-kernel backward's shapes (head size 64, no dropout, 33 ... 272 keys)."""
     return bool(_lib.load().antmmf_attention_bwd_sums_ok(int(head_dim), int(Nq), int(Nk), float(dropout_p)))
 
 

@@ -874,15 +874,19 @@ __device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 2) 
 __device__ __forceinline__ int ds_off(int key, int s) { return key * 64 + ((s ^ ds_swz(key)) << 3); }
 // token sums of dQ | dK | dV (AttnArgs::sums): per-wave partials [dK: 8 x 64 | dV: 8 x 64 | dQ: 8 x 16 | the extra key tile: 8 x 16] floats behind the row statistics
 #define ATTN_SUMS_FLOATS 1280
+#ifndef ATTN_SUMS_MIN_KEYS
+#define ATTN_SUMS_MIN_KEYS 32
+#endif
 
 static inline size_t attn_fused_lds_bytes(int Nq, int Nk, bool early = false, bool sums = false) {
     const int nqp = ((Nq + 31) / 32) * 32;
     return (size_t)nqp * 256 * (early ? 2 : 1) + 288 * 128 + 2 * 16384 + (Nk > 256 ? (size_t)(nqp / 32) * 1024 : 0) + (size_t)nqp * 8 + (sums ? ATTN_SUMS_FLOATS * 4 : 0);
 }
 static inline bool attn_fused_ok(const AttnArgs& a) {
-    // the token sums cost the kernel ~ 1 us per (b, h) item: 1.4 % of the 257-token form against a column-sum pass of 12 % of its time, but 15 % of the 77 - 86-token
-    // forms, more than the pass they would save (profiles/r6b_attn_bwd_token_sums_ab.txt) -- served from nine key tiles on
-    if (a.sums && a.Nk <= 128) return false;
+    // (every shape of the one-kernel backward is served.  With the per-chunk dQ sums in LDS the sums cost ~ 1 us per (b, h) item -- 15 % of the 77 - 86-token forms, more than the
+    // column-sum pass they save -- and the short towers were excluded; with the dQ tiles summed in registers it is 0.025 ms of 0.41 at 1024 x 16 x 77 against a pass of 0.055:
+    // profiles/r6b_attn_bwd_token_sums_ab.txt)
+    if (a.sums && a.Nk <= ATTN_SUMS_MIN_KEYS) return false;
     return !a.drop_thr && a.Nk > 32 && a.Nk <= 272 && attn_fused_lds_bytes(a.Nq, a.Nk, false, a.sums != nullptr) <= 160 * 1024;   // (one or two key tiles: the two-kernel form)
 }
 
@@ -1525,13 +1529,13 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t stream) {
                 else if (nkt > 12) { if (nkt > 14) BWDF(8, false, false, 0, true, 0); else BWDF(7, false, false, 0, true, 0); }
                 else if (nkt > 8) { if (nkt > 10) BWDF(6, false, false, 0, true, 0); else BWDF(5, false, false, 0, true, 0); }
                 else if (early) {
-#define BWDE(NKS) BWDF_(NKS, false, false, 0, true, 0, true, 0)   /* (at most eight key tiles: never with the token sums, see attn_fused_ok) */
+#define BWDE(NKS) do { if (sm && a.sums_v) BWDF_(NKS, false, false, 0, true, 0, true, 1); else if (sm) BWDF_(NKS, false, false, 0, true, 0, true, 2); else BWDF_(NKS, false, false, 0, true, 0, true, 0); } while (0)
                     if (nkt > 6) BWDE(4); else if (nkt > 4) BWDE(3); else BWDE(2);
 #undef BWDE
                 }
-                else if (nkt > 6) BWDF_(4, false, false, 0, true, 0, false, 0);
-                else if (nkt > 4) BWDF_(3, false, false, 0, true, 0, false, 0);
-                else BWDF_(2, false, false, 0, true, 0, false, 0);
+                else if (nkt > 6) BWDF(4, false, false, 0, true, 0);
+                else if (nkt > 4) BWDF(3, false, false, 0, true, 0);
+                else BWDF(2, false, false, 0, true, 0);
             } else BWDF(8, true, true, 0, false, 0);
 #undef BWDF
 #undef BWDF_
@@ -1606,7 +1610,7 @@ extern "C" int antmmf_attention_bwd(const void* q, const void* k, const void* v,
 
 // The backward plus the per-batch-item token sums of dQ | dK | dV (fp32 sums of the unrounded gradients): sums[(b * 3 + {0: q, 1: k, 2: v}) * heads * 64 + h * 64 + e] =
 // sum_n dX[b, n, h, e] (the dV third only with want_dv != 0).  The q / k / v bias gradients of the layer are the column sums of this [B, 3 * heads * 64] matrix -- B rows instead of B * N: the column-sum passes
-// over dQ | dK | dV (one tensor pass each per layer) disappear.  Served by the one-kernel backward only (head size 64, 129 ... 272 keys, no dropout):
+// over dQ | dK | dV (one tensor pass each per layer) disappear.  Served by the one-kernel backward only (head size 64, 33 ... 272 keys, no dropout):
 // antmmf_attention_bwd_sums_ok says whether a shape is; anything else is ANTMMF_EINVAL (the caller then sums the columns of dq / dk / dv itself).
 extern "C" int antmmf_attention_bwd_sums_ok(int head_dim, int Nq, int Nk, float dropout_p) {
     AttnArgs a{};

@@ -227,7 +227,7 @@ int antmmf_attention_bwd_hd(const void* q, const void* k, const void* v, const f
  * The bias gradients of the q / k / v projections (nn.MultiheadAttention in_proj_bias clip/model.py:222-251; BertSelfAttention query / key / value
  * modeling_bert.py:140-146; torchscale q_proj / k_proj / v_proj multihead_attention.py:66-71) are the column sums of that B-row matrix -- autograd's sum over the
  * B * N rows of dQ | dK | dV (one pass over each tensor per layer) is not needed any more.  Served by the one-kernel backward only: antmmf_attention_bwd_sums_ok
- * returns 1 for the shapes it takes (head size 64, no dropout, 129 ... 272 keys: below that the sums cost the kernel more than the pass they save), antmmf_attention_bwd_sums returns ANTMMF_EINVAL for any other --
+ * returns 1 for the shapes it takes (head size 64, no dropout, 33 ... 272 keys), antmmf_attention_bwd_sums returns ANTMMF_EINVAL for any other --
  * the caller then runs antmmf_attention_bwd and sums the columns itself (antmmf_colsum). */
 int antmmf_attention_bwd_sums_ok(int head_dim, int Nq, int Nk, float dropout_p);
 int antmmf_attention_bwd_sums(const void* q, const void* k, const void* v, const float* key_bias, const void* o,

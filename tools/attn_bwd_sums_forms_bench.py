@@ -28,7 +28,12 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     dev = torch.device("cuda:0")
-    B, h, N = 1024, 16, 257
+    shapes = [tuple(int(x) for x in sp.split("x")) for sp in os.environ.get("ATTN_BENCH_SHAPES", "1024x16x257").split(",")]
+    for B, h, N in shapes:
+        bench(dev, B, h, N)
+
+
+def bench(dev, B, h, N):
     qkv = torch.randn(B, N, 3 * h * 64, device=dev).bfloat16()
     q, k, v = qkv[..., :h * 64], qkv[..., h * 64:2 * h * 64], qkv[..., 2 * h * 64:]
     dqkv = torch.empty_like(qkv)
@@ -41,7 +46,7 @@ def main():
         for name, fn in (("plain", lambda: ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, dq=dq, dk=dk, dv=dv)),
                          ("sums q|k|v", lambda: ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, dq=dq, dk=dk, dv=dv, sums=sums)),
                          ("sums q|k", lambda: ops.attention_bwd(q, k, v, o, lse, do, h, 0.125, dq=dq, dk=dk, dv=dv, sums=sums, sums_v=False))):
-            print(json.dumps({"abl": abl, "rep": rep, "form": name, "ms": round(timeit(fn), 4)}), flush=True)
+            print(json.dumps({"shape": f"{B}x{h}x{N}", "abl": abl, "rep": rep, "form": name, "ms": round(timeit(fn), 4)}), flush=True)
 
 
 if __name__ == "__main__":
