@@ -52,6 +52,8 @@ _SIGNATURES = {
     "antmmf_attention_fwd_hd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, F, U64, P],
     "antmmf_attention_key_importance": [P, P, P, P, P, I, I, I, I, L, L, F, F, U64, F, P],
     "antmmf_attention_bwd_hd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, F, U64, P],
+    "antmmf_gemm_bf16_gated_colsum_ok": [I, I, I, L, L],
+    "antmmf_gemm_bf16_gated_colsum": [P, P, P, I, I, I, L, L, L, P, L, P, P],
     "antmmf_attention_bwd_sums_ok": [I, I, I, F],
     "antmmf_attention_bwd_sums": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
     "antmmf_milnce_fwd": [P, P, I, I, I, I, I, P, P, P],

@@ -404,6 +404,8 @@ def set_keep_ffn_norm(flag):
 FFN_FOLD = False
 # q / k / v bias gradients out of the attention backward's per-item token sums (round 6; module flag for the A/B, tools/colsum_ab.py)
 ATTN_BWD_SUMS = True
+# fc1's bias gradient of the CLIP / BERT feed-forwards out of the gated dgrad's epilogue (round 6; module flag for the A/B)
+GATED_DGRAD_COLSUM = True
 ATTN_BWD_SUMS_MIN_TOKENS = 33    # (tools/bench_flag.py A/B: 129 = the long towers only)
 # Keep the output of the pre-LN layers' second LayerNorm (fc1's input, + 2 B per token-channel: 15.7 GiB on the l14 step at 1024 pairs) for backward instead of having the
 # LayerNorm backward re-emit it (5 -> 4 tensor streams in that kernel).  EXPERIMENT (round 6, tools/bench_flag.py KEEP_LN2_OUT=1): off; see docs/rounds/round-6.md
@@ -614,7 +616,16 @@ class _TransformerLayer(torch.autograd.Function):
             del dgn
         else:
             b1_fused = False
-            du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act, gate_is_grad=ctx.u_is_grad)  # (d(dense out) W2) * act'(u)
+            w2t = compute_copy_t(P["w2"]) if isinstance(P["w2"], torch.nn.Parameter) else None
+            if (GATED_DGRAD_COLSUM and ctx.u_is_grad and w2t is not None and P["b1"] is not None and P["b1"].requires_grad and dy_w2.is_contiguous()
+                    and ops.gemm_gated_colsum_ok(T, w2t.shape[0], w2t.shape[1])):
+                # (d(dense out) W2) * act'(u) with the column sums of the result as 256 partial rows out of the same kernel: fc1's bias gradient = their column sums --
+                # no pass over the 4d-wide du (0.39 ms per cross-encoder layer of the video workloads)
+                du, parts = ops.gemm_gated_colsum(dy_w2, w2t, u, act=spec.act)
+                ops.colsum_(sink.buf(P["b1"]), parts)
+                b1_fused = True
+            else:
+                du = dgrad(dy_w2, P["w2"], gate=u, act=spec.act, gate_is_grad=ctx.u_is_grad)  # (d(dense out) W2) * act'(u)
         # The normalised tensors the wgrads need (h2, o_n, h) are not kept by the forward pass and not recomputed either: the LayerNorm
         # backward of the same tensor re-emits them (layernorm_bwd_renorm: one extra write instead of a read + write pass).
         ln_mid = ("ln2" if pre_ln else "ln1")

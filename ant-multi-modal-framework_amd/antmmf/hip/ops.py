@@ -341,6 +341,36 @@ def gemm(P, Q, out=None, p_rmajor=False, q_rmajor=False, out_dtype=torch.bfloat1
     return out
 
 
+def gemm_gated_colsum_ok(I, J, R, ldc=None, ldgate=None):
+    """True when gemm_gated_colsum serves the shape (the rolling-epilogue kernel's shapes: I, J multiples of 256, J <= 4096, R % 64 == 0, R >= 192, >= 512 tiles)."""
+    return bool(_lib.load().antmmf_gemm_bf16_gated_colsum_ok(int(I), int(J), int(R), int(J if ldc is None else ldc), int(J if ldgate is None else ldgate)))
+
+
+def gemm_gated_colsum(P, Q, gate, act=None):
+    """(out, parts): out[i, j] = (sum_r P[i, r] Q[j, r]) * gate[i, j]  (gate = the activation derivative the forward stored) and parts [256, J] fp32 whose column sums
+    are the column sums of out -- the bias gradient of the Linear in front of the activation without a pass over the [I, J] tensor.  P [I, R], Q [J, R] bf16."""
+    _dev_ok(P, Q, gate)
+    for t, n in ((P, "P"), (Q, "Q"), (gate, "gate")):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.bfloat16:
+            raise ValueError(f"gemm_gated_colsum: {n} must be a 2-D bf16 tensor with unit inner stride")
+    I, R = P.shape
+    J = Q.shape[0]
+    if Q.shape[1] != R or tuple(gate.shape) != (I, J):
+        raise ValueError("gemm_gated_colsum: shape mismatch")
+    out = torch.empty(I, J, dtype=torch.bfloat16, device=P.device)
+    parts = torch.zeros(256, J, dtype=torch.float32, device=P.device)
+    ev = None
+    if GEMM_TRACE is not None and _lib.backend() == 1:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _rc(_lib.load().antmmf_gemm_bf16_gated_colsum(_p(P), _p(Q), _p(out), I, J, R, P.stride(0), Q.stride(0), out.stride(0), _p(gate), gate.stride(0), _p(parts), _stream()),
+        "antmmf_gemm_bf16_gated_colsum")
+    if ev is not None:
+        ev[1].record()
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * I * J * R, "nt", (I, J, R, (act or "") + "g")))
+    return out, parts
+
+
 _WGRAD_WS = {}
 
 

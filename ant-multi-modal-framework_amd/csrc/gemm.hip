@@ -1569,6 +1569,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 #define K64R_VMWAIT(N) do {} while (0)
 #define K64R_LREAD16(dst, addr, OFF) dst = *reinterpret_cast<const f32x4_t*>(smem + (addr) + (OFF))
 #define K64R_OPAQUE(x) do {} while (0)
+#define K64R_OPAQUE_V(x) do {} while (0)
 #define K64R_KEEP(x) do {} while (0)
 #else
 #define K64R_KEEP(x) asm volatile("" :: "v"(x))
@@ -1582,6 +1583,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64p_kernel(const GemmArgs g, int
 #define K64R_VMWAIT(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
 #define K64R_LREAD16(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds0 + (addr)), "n"(OFF))
 #define K64R_OPAQUE(x) asm volatile("" : "+s"(x))
+#define K64R_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
 // tools/k64r_ladder.py: end-of-phase waits W[role][phase] (roles T0 = first K-tile of an output tile, TR = steady, TE = last), the waits INIT[q] in
 // front of the accumulator initialisation of row quarter q, BIASW in front of the bias strip read of a bias-only kernel
@@ -1594,6 +1596,7 @@ template <> struct K64RWaits<5> { static constexpr int W[3][4] = {{41, 41, 42, 7
 template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
 // EPI 8 (out = acc * gate, round 5): INIT[q] = the wait in front of the multiplication of row quarter q by its gate vectors, requested one phase earlier (only the two DMA
 // pieces of the phase in between are younger; tools/k64r_ladder.py ladder_gate)
+template <> struct K64RWaits<10> { static constexpr int W[3][4] = {{40, 37, 38, 7}, {8, 9, 10, 7}, {12, 21, 30, 35}}; static constexpr int INIT[4] = {2, 2, 2, 2}; static constexpr int BIASW = 0; };   // = EPI 8 (the column sums add LDS operations only)
 template <> struct K64RWaits<8> { static constexpr int W[3][4] = {{40, 37, 38, 7}, {8, 9, 10, 7}, {12, 21, 30, 35}}; static constexpr int INIT[4] = {2, 2, 2, 2}; static constexpr int BIASW = 0; };
 
 // ABL 8 (timing only, EPI 0, R = 1024): every K-tile stores ONE 16-row x 32-column block of the tile (out of the running sums: wrong values, right bytes,
@@ -1612,7 +1615,11 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     ANTMMF_DYN_LDS(char, smem);
     constexpr int BM = 256, BN = 256, TI = 8, TJ = 4, NWJ = 4;
     constexpr int STAGE = 65536, QOFF = 32768, BIASOFF = 2 * STAGE;
-    constexpr bool GATE = EPI == 8, BIAS = !GATE && (EPI & 1), RES = !GATE && (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
+    // EPI 10 (round 6): EPI 8 plus the column sums of the stored tile rows -- the bias gradient of the Linear in FRONT of the activation (fc1 of the CLIP / BERT feed-forwards: db1 = column
+    // sums of du = (dy W2) * act'), which was a column-sum pass over the 4d-wide du per layer.  Per row quarter: the two fragments of a column are added, closed over the 16 row lanes by
+    // DPP, and added into a per-workgroup strip of J floats in LDS (return-less ds_add_f32; the 30 KB behind the bias strips); the strip leaves as row blockIdx.x of g.part at the end.
+    constexpr bool CSUM = EPI == 10, GATE = EPI == 8 || CSUM, BIAS = !GATE && (EPI & 1), RES = !GATE && (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
+    constexpr int CSOFF = 2 * 65536 + 2048;   // float strip [J <= 4096]
     using WT = K64RWaits<EPI>;
     const bf16_t* const rsrc = GATE ? g.gate : g.residual;   // what the "residual" vector loads fetch: the residual tile, or the gate tile
     const long rld = GATE ? g.ldgate : g.ldr;
@@ -1736,6 +1743,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     int i0, j0;
     tile_origin(local, i0, j0);
     tile_bases(i0, j0, pgc, qgc);
+    if (CSUM) for (int c = threadIdx.x; c < g.J; c += 512) *reinterpret_cast<float*>(smem + CSOFF + c * 4) = 0.f;
     // prologue: K-tile 0 and the Q half of K-tile 1 (12 pieces per wave), the first tile's bias strip and residual quarters 0 - 2; drained once
 #pragma unroll
     for (int pq = 0; pq < 4; ++pq) { dma_p(pgc, pq, 0, 0); dma_q(qgc, pq, 0, 0); dma_q(qgc, pq, 1, STAGE); }
@@ -1884,6 +1892,27 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
             }                                                                                                                       \
         }                                                                                                                           \
     } while (0)
+#ifdef ANTMMF_EMULATE
+#define K64R_LDS_ADD(OFF, V) (*reinterpret_cast<float*>(smem + (OFF)) += (V))
+#else
+#define K64R_LDS_ADD(OFF, V) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(smem + (OFF)), (V), 0, 0, false)
+#endif
+    // column sums of row quarter QQ (after the gate): lane (l15, grp) holds row l15 of fragment it, columns jt 16 + 4 pbg + rr
+#define K64R_CSUM(QQ, tj0)                                                                                                          \
+    do {                                                                                                                            \
+        int ln_ = lane;                                                                                                             \
+        K64R_OPAQUE_V(ln_);   /* (the strip offset is rebuilt here, not kept alive across the K loop) */                              \
+        const int g_ = ln_ >> 4;                                                                                                    \
+        const int cb_ = CSOFF + ((tj0) + wj * 64 + 4 * (((g_ & 1) << 1) | (g_ >> 1))) * 4;                                          \
+        _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                                          \
+            _Pragma("unroll") for (int rr = 0; rr < 4; rr += 2) {   /* (two columns at a time: a handful of live temporaries) */     \
+                const float c0 = row16_sum(acc[2 * (QQ)][jt][rr] + acc[2 * (QQ) + 1][jt][rr]);                                      \
+                const float c1 = row16_sum(acc[2 * (QQ)][jt][rr + 1] + acc[2 * (QQ) + 1][jt][rr + 1]);                              \
+                if ((ln_ & 15) == 0) { K64R_LDS_ADD(cb_ + jt * 64 + rr * 4, c0); K64R_LDS_ADD(cb_ + jt * 64 + rr * 4 + 4, c1); }    \
+                SCHED_FENCE();                                                                                                      \
+            }                                                                                                                       \
+        }                                                                                                                           \
+    } while (0)
 #define K64R_PIECE(IDX)                                                                                                             \
     do {                                                                                                                            \
         int kk = t + (IDX < 4 ? 1 : 2);                                                                                             \
@@ -1951,7 +1980,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
 #define K64R_HOOK(ROLE, PH)                                                                                                         \
     do {                                                                                                                            \
         if (ROLE == 0 && PH == 0) {                                                                                                 \
-            if (pending) { if (GATE) K64R_GATEMUL(3); K64R_EPIQ(3, ei0, ej0); }                                                     \
+            if (pending) { if (GATE) K64R_GATEMUL(3); if (CSUM) K64R_CSUM(3, ej0); K64R_EPIQ(3, ei0, ej0); }                        \
             if (RES) K64R_RESLOAD(3, i0, j0);                                                                                       \
             if (BIAS) {                                                                                                             \
                 if (!RES) K64R_VMWAIT(WT::BIASW);   /* with a residual the wait in front of K64R_INIT(0) is the stronger one */      \
@@ -1966,6 +1995,7 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
         if (GATE && ROLE == 2 && PH == 0) K64R_RESLOAD(0, i0, j0);                                                                  \
         if (ROLE == 2 && PH >= 1) {                                                                                                 \
             if (GATE) K64R_GATEMUL(PH - 1);                                                                                         \
+            if (CSUM) K64R_CSUM(PH - 1, j0);                                                                                        \
             K64R_EPIQ(PH - 1, i0, j0);                                                                                              \
             if (RES) K64R_RESLOAD(PH - 1, ni0, nj0);                                                                                \
             if (GATE) K64R_RESLOAD(PH, i0, j0);                                                                                     \
@@ -2010,7 +2040,12 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     glds_wait_all();
     SCHED_FENCE();
     if (GATE) K64R_GATEMUL(3);   // (its wait allows 2 younger operations: none are in flight any more)
+    if (CSUM) K64R_CSUM(3, ej0);
     if (!(ABL & 8)) K64R_EPIQ(3, ei0, ej0);
+    if (CSUM) {   // this workgroup's column sums -> row blockIdx.x of g.part ([gridDim.x][J] fp32; workgroups without a tile returned above: the host zero-fills)
+        wg_barrier_lds_only();
+        for (int c = threadIdx.x; c < g.J; c += 512) g.part[(long)blockIdx.x * g.J + c] = *reinterpret_cast<const float*>(smem + CSOFF + c * 4);
+    }
     if (tail_r > 0 && lx < 16 * tail_r) {
         // ---- leftover tiles as cells.  Cell c of the chunk = tile c >> 4, phase (c >> 2) & 3, Q fragment c & 3: per wave 2 P fragments (rows wi 128 + 32 ph + [0, 32)) x 1 Q
         // fragment (columns wj 64 + 16 jt + [0, 16)), i.e. 4 MFMAs per K-tile; operands per K-tile: the P quarter `ph` and the Q quarter `jt` of the tile's stage image
@@ -2451,6 +2486,7 @@ static constexpr int g_gemm_variant = 4;
 static long g_k64_launches = 0;   // launch counter read by the tests (which kernel family served a call); not dispatch state
 extern "C" long antmmf_debug_gemm_k64_launches() { return g_k64_launches; }
 
+static thread_local float* tl_colsum_part = nullptr;   // set around gemm_impl by antmmf_gemm_bf16_gated_colsum only
 // C ABI: see include/antmmf_hip.h for the contract.
 static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc,
                      int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
@@ -2479,7 +2515,7 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
     g.aux = (bf16_t*)aux; g.gate = (const bf16_t*)gate;
     g.ldp = ldp; g.ldq = ldq; g.ldc = ldc; g.ldr = ldr; g.ldaux = ldaux; g.ldgate = ldgate;
     g.aux_grad = (act & 0x100) ? 1 : 0; g.gate_grad = (act & 0x200) ? 1 : 0;
-    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = nullptr;
+    g.ffn_mode = 0; g.rowv = nullptr; g.colv = nullptr; g.part = tl_colsum_part;   // (antmmf_gemm_bf16_gated_colsum: per-workgroup column sums of the gated dgrad)
     g.tail_cells = 0;
     act &= 0xff;
     // aux = act'(pre-activation) is defined for an activation epilogue without a gate only (the three epilogue forms would otherwise disagree
@@ -2651,6 +2687,11 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                 static bool once8 = false;
                 if (!once8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once8 = true; }
                 g.tail_cells = 0;
+                if (g.part && J <= 4096) {   // ... with the per-workgroup column sums (antmmf_gemm_bf16_gated_colsum)
+                    static bool once10 = false;
+                    if (!once10) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<10, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once10 = true; }
+                    hipLaunchKernelGGL((gemm_nt_k64r_kernel<10, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+                } else
                 hipLaunchKernelGGL((gemm_nt_k64r_kernel<8, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
             } else
             K64P_LAUNCH(8, K64F_ONEBAR | K64F_DIST11 | K64F_PRIO);
@@ -3034,6 +3075,27 @@ extern "C" int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, in
                                 int accumulate, int split_k, hipStream_t stream) {
     return gemm_impl(P, Q, C, I, J, R, ldp, ldq, ldc, p_rmajor, q_rmajor, c_dtype, alpha, bias, act, residual, ldr, aux, ldaux, gate, ldgate,
                      accumulate, split_k, nullptr, 0, stream);
+}
+
+// out = (P Q^T) * gate (gate = the activation derivative the forward stored) PLUS the column sums of `out`, as 256 partial rows: colsum_part [256][J] fp32, ZERO-FILLED by the
+// caller (row w = what workgroup w's tiles contributed; workgroups without a tile leave theirs untouched) -- the bias gradient of the Linear in front of the activation is the column
+// sum of those 256 rows instead of a pass over the [I][J] tensor.  Served by the rolling-epilogue kernel only: antmmf_gemm_bf16_gated_colsum_ok says whether a shape is.
+extern "C" int antmmf_gemm_bf16_gated_colsum_ok(int I, int J, int R, long ldc, long ldgate) {
+    const long tiles256 = (long)((I + 255) / 256) * ((J + 255) / 256);
+    bool enough = tiles256 >= 512;
+#ifdef ANTMMF_LAB
+    static const char* force = ANTMMF_LAB_ENV("ANTMMF_GEMM_FORCE_TILE");   // (lab / emulator tests: "k" forces the BK = 64 kernels on small problems)
+    if (force) enough = force[0] == 'k';
+#endif
+    return I > 0 && J > 0 && !(I & 255) && !(J & 255) && J <= 4096 && !(R & 63) && R >= 192 && enough && !(ldc & 7) && !(ldgate & 7) ? 1 : 0;
+}
+extern "C" int antmmf_gemm_bf16_gated_colsum(const void* P, const void* Q, void* C, int I, int J, int R, long ldp, long ldq, long ldc, const void* gate, long ldgate,
+                                             float* colsum_part, hipStream_t stream) {
+    if (!gate || !colsum_part || !antmmf_gemm_bf16_gated_colsum_ok(I, J, R, ldc, ldgate)) return ANTMMF_EINVAL;
+    tl_colsum_part = colsum_part;
+    const int rc = gemm_impl(P, Q, C, I, J, R, ldp, ldq, ldc, 0, 0, ANTMMF_BF16, 1.0f, nullptr, ANTMMF_ACT_GELU_ERF | 0x200, nullptr, 0, nullptr, 0, gate, ldgate, 0, 1, nullptr, 0, stream);
+    tl_colsum_part = nullptr;
+    return rc;
 }
 
 // dW[n_out][k_in] += dY[tokens][n_out]^T X[tokens][k_in]  (fp32 accumulate), with a caller-owned fp32 workspace for the token-split

@@ -160,6 +160,14 @@ int antmmf_gemm_bf16(const void* P, const void* Q, void* C, int I, int J, int R,
                      int64_t ldc, int p_rmajor, int q_rmajor, int c_dtype, float alpha, const float* bias, int act,
                      const void* residual, int64_t ldr, void* aux, int64_t ldaux, const void* gate, int64_t ldgate,
                      int accumulate, int split_k, antmmf_stream_t stream);
+/* The dgrad through an activation whose derivative the forward stored, C = (P Q^T) * gate (antmmf_gemm_bf16 with gate + ANTMMF_ACT_GATE_GRAD), that also returns the column
+ * sums of C as 256 partial rows: colsum_part [256][J] fp32, ZERO-FILLED by the caller; the bias gradient of the Linear in front of the activation -- c_fc of CLIP's MLP
+ * (clip/model.py:222-241), BertIntermediate.dense (clip/modeling_bert.py:210-238): db = column sums of dU = (dY W2) * act' -- is the column sum of those 256 rows
+ * (antmmf_colsum) instead of autograd's sum over the I rows of the 4d-wide dU.  Served by the rolling-epilogue kernel only (I, J multiples of 256, J <= 4096, R a multiple
+ * of 64 >= 192, >= 512 tiles): antmmf_gemm_bf16_gated_colsum_ok returns 1 for those, the call ANTMMF_EINVAL otherwise. */
+int antmmf_gemm_bf16_gated_colsum_ok(int I, int J, int R, int64_t ldc, int64_t ldgate);
+int antmmf_gemm_bf16_gated_colsum(const void* P, const void* Q, void* C, int I, int J, int R, int64_t ldp, int64_t ldq, int64_t ldc, const void* gate, int64_t ldgate,
+                                  float* colsum_part, antmmf_stream_t stream);
 /* The same GEMM with a caller-owned DEVICE scratch buffer (fp32): used by the r-major / r-major layout (the weight-gradient kernels' token split: partial tiles ->
  * workspace, summed in split order by a second launch; NULL -> fp32 atomics).  The all-r-contiguous layouts need none: the persistent kernel finishes the leftover
  * tiles of its tile walk inside the same launch (round 4's K-split through this scratch is gone).  NULL / 0 is always valid. */

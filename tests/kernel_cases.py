@@ -424,6 +424,13 @@ def case_gemm_k64(ops, dev, I=512, J=512, R=192, quick=False):
     check("gemm.k64.aux_grad.y", y2, oops.gelu_erf(ref + bias), 2e-2, 1e-2)
     dx2 = ops.gemm(Xd, Wd, gate=u.to(dev, BF), act="gelu", gate_is_grad=True)
     check("gemm.k64.gate_is_grad", dx2, ref * u, 2e-2, 1e-2)
+    if ops.gemm_gated_colsum_ok(I, J, R):
+        # the same gated dgrad with its column sums as 256 partial rows (the bias gradient of the Linear in front of the activation): the product bit-identical,
+        # the partial rows' column sums = the column sums of the fp32 product
+        dx3, parts = ops.gemm_gated_colsum(Xd, Wd, u.to(dev, BF))
+        assert torch.equal(dx3, dx2), "gemm.k64.gated_colsum: product differs"
+        assert tuple(parts.shape) == (256, J)
+        check("gemm.k64.gated_colsum", parts.sum(0), (ref * u).sum(0), 2e-2, 1e-2)
     packed = torch.zeros(I, 2 * J, dtype=BF, device=dev)
     ops.gemm(Xd, Wd, out=packed[:, J:])
     check("gemm.k64.ldc", packed[:, J:], ref, 2e-2, 1e-2)
