@@ -92,10 +92,10 @@ def audit(lines, name, gate=False):
 if __name__ == "__main__":
     S = open(sys.argv[1]).read().split("\n")
     total = 0
-    for e in (0, 1, 2, 3, 8):
+    for e in (0, 1, 2, 3, 8, 10):   # (10 = 8 + the column sums of the stored rows)
         st = [i for i, l in enumerate(S) if l.startswith("_Z19gemm_nt_k64r_kernelILi%dE" % e)]
         if not st:
             continue
         en = [i for i, l in enumerate(S) if i > st[0] and ".amdhsa_kernel" in l][0]
-        total += audit(S[st[0]:en], "k64r<%d>" % e, gate=(e == 8))
+        total += audit(S[st[0]:en], "k64r<%d>" % e, gate=(e in (8, 10)))
     sys.exit(1 if total else 0)
