@@ -160,8 +160,8 @@ def test_k64r_isa_audit(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "k64r_audit.py"), str(out)], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("k64r<")]
-    assert len(lines) == 5 and all("problems 0" in ln or "no residual loads" in ln for ln in lines), p.stdout
-    assert sum("loads 28 problems 0" in ln for ln in lines) == 2 and sum("loads 16 problems 0" in ln for ln in lines) == 1, p.stdout    # the two residual kernels and the gate kernel were really audited
+    assert len(lines) == 6 and all("problems 0" in ln or "no residual loads" in ln for ln in lines), p.stdout   # plain, bias, residual, bias + residual, gate, gate + column sums
+    assert sum("loads 28 problems 0" in ln for ln in lines) == 2 and sum("loads 16 problems 0" in ln for ln in lines) == 2, p.stdout    # the two residual kernels and the two gate kernels were really audited
 
 
 def test_attention_m0_audit(tmp_path):
