@@ -555,11 +555,14 @@ class _TransformerLayer(torch.autograd.Function):
             return (sink.buf(w) if w.requires_grad else None), (sink.buf(b) if b.requires_grad else None)
 
         # ---- MLP half
+        b2_fused = False
         if pre_ln:
             ds2 = dy2
         else:
             dgw, dgb = lnw("ln2")
-            ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb)
+            # (post-LN layers without hidden dropout: the fc2 output's gradient IS this LayerNorm backward's dx -- its column sums, fc2's bias gradient, come out of the same kernel)
+            b2_fused = p_hid == 0 and not ctx.fold and P["b2"] is not None and P["b2"].requires_grad
+            ds2 = ops.layernorm_bwd(dy2, s2, my, ry, f32(P["ln2_w"]), dgw, dgb, dxsum=sink.buf(P["b2"]) if b2_fused else None)
         if ctx.fold:
             g_n = None
         elif kept_gn is not None:
@@ -602,7 +605,7 @@ class _TransformerLayer(torch.autograd.Function):
         elif (handed_ok and P["b2"] is not None and P["b2"].requires_grad):
             sink.buf(P["b2"]).add_(handed[0])
             COLSUM_HANDOFFS[0] += 1
-        else:
+        elif not b2_fused:
             _bgrad(sink, P["b2"], dy_w2)
         del g_n
         if ctx.fold:
