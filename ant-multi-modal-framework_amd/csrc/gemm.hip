@@ -3086,6 +3086,8 @@ extern "C" int antmmf_gemm_bf16_gated_colsum_ok(int I, int J, int R, long ldc, l
 #ifdef ANTMMF_LAB
     static const char* force = ANTMMF_LAB_ENV("ANTMMF_GEMM_FORCE_TILE");   // (lab / emulator tests: "k" forces the BK = 64 kernels on small problems)
     if (force) enough = force[0] == 'k';
+    GEMM_VARIANT_INIT();
+    if (!(g_gemm_variant & 4) || (g_gemm_variant & 16384)) return 0;       // (lab A/B variants that send the gated dgrad to another kernel: that one has no column sums)
 #endif
     return I > 0 && J > 0 && !(I & 255) && !(J & 255) && J <= 4096 && !(R & 63) && R >= 192 && enough && !(ldc & 7) && !(ldgate & 7) ? 1 : 0;
 }
