@@ -404,6 +404,8 @@ def set_keep_ffn_norm(flag):
 FFN_FOLD = False
 # q / k / v bias gradients out of the attention backward's per-item token sums (round 6; module flag for the A/B, tools/colsum_ab.py)
 ATTN_BWD_SUMS = True
+# q / k / v wgrads as one segmented launch on the long towers too when the merged launch fills at least this many of the 256 CUs (d = 768: 27 tiles x 9 splits = 243; d = 1024: 48 x 5 = 240, measured a loss)
+QKV_WGRAD_MERGE_MIN_WGS = 243
 # fc1's bias gradient of the CLIP / BERT feed-forwards out of the gated dgrad's epilogue (round 6; module flag for the A/B)
 GATED_DGRAD_COLSUM = True
 ATTN_BWD_SUMS_MIN_TOKENS = 33    # (tools/bench_flag.py A/B: 129 = the long towers only)
@@ -699,7 +701,9 @@ class _TransformerLayer(torch.autograd.Function):
             _bgrad(sink, P["bqkv"], bsrc)
         else:
             ws_ = [P["w" + nm] for nm in "qkv"]
-            if all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and 4096 <= T <= 131072 and T % 64 == 0:
+            seg_tiles = 3 * d * d // 65536   # 256 x 256 tiles of the merged launch; it runs tiles x (256 // tiles) workgroups
+            if (all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and T >= 4096 and T % 64 == 0
+                    and (T <= 131072 or seg_tiles * (256 // max(1, seg_tiles)) >= QKV_WGRAD_MERGE_MIN_WGS)):
                 # separate q / k / v projections (BERT, torchscale): ONE wgrad GEMM over the packed dQ | dK | dV, its reduce launch scatters the three row segments into the
                 # three parameters' gradient buffers.  Measured in the l14 step (profiles/r6_gemm_table_l14_qkv_wgrad_merged.txt): 3072 x 1024 is 48 tiles x 5 token splits
                 # = 240 workgroups against 3 x (16 tiles x 16 splits = 256) -- on the 77-token text tower (78848 tokens: 77 K-tiles per split before) 402 us instead of
