@@ -406,6 +406,7 @@ FFN_FOLD = False
 ATTN_BWD_SUMS = True
 # q / k / v wgrads as one segmented launch on the long towers too when the merged launch fills at least this many of the 256 CUs (d = 768: 27 tiles x 9 splits = 243; d = 1024: 48 x 5 = 240, measured a loss)
 QKV_WGRAD_MERGE_MIN_WGS = 243
+QK_WGRAD_MERGE = True   # (d = 1024, long tower: q | k as one launch of 256 workgroups, v alone)
 # fc1's bias gradient of the CLIP / BERT feed-forwards out of the gated dgrad's epilogue (round 6; module flag for the A/B)
 GATED_DGRAD_COLSUM = True
 ATTN_BWD_SUMS_MIN_TOKENS = 33    # (tools/bench_flag.py A/B: 129 = the long towers only)
@@ -709,6 +710,11 @@ class _TransformerLayer(torch.autograd.Function):
                 # = 240 workgroups against 3 x (16 tiles x 16 splits = 256) -- on the 77-token text tower (78848 tokens: 77 K-tiles per split before) 402 us instead of
                 # 3 x 150 us, on the image tower (263168 tokens) 1359 us instead of 3 x 445 us: the merged launch leaves 16 CUs idle and loses; hence the token bound
                 ops.gemm_wgrad_seg_([sink.buf(w) for w in ws_], dqkv2, h)
+            elif (QK_WGRAD_MERGE and all(w is not None and w.requires_grad for w in ws_) and d % 256 == 0 and T >= 4096 and T % 64 == 0
+                    and (2 * d * d // 65536) * (256 // max(1, 2 * d * d // 65536)) >= QKV_WGRAD_MERGE_MIN_WGS):
+                # (d = 1024 on the long tower: all three merged would run 240 workgroups, q | k merged runs 32 tiles x 8 splits = all 256 with twice the K depth per workgroup; v on its own)
+                ops.gemm_wgrad_seg_([sink.buf(ws_[0]), sink.buf(ws_[1])], dqkv2[:, :2 * d], h)
+                _wgrad(sink, P["wv"], dqkv2[:, 2 * d:], h)
             else:
                 for i, nm in enumerate("qkv"):
                     _wgrad(sink, P["w" + nm], dqkv2[:, i * d:(i + 1) * d], h)
