@@ -2,7 +2,7 @@
 
     python tools/bench_flag.py ATTN_BWD_SUMS=0 -- --no-cpu-baseline --steps 5
 
-Everything after `--` goes to bench.py unchanged; the JSON line's config gains {"flags": {...}}-free output -- the flags are echoed on stderr."""
+Everything after `--` goes to bench.py unchanged; the JSON line is bench.py's own, the flags are echoed on stderr."""
 import os
 import runpy
 import sys
