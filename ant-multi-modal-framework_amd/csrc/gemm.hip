@@ -1592,6 +1592,8 @@ template <> struct K64RWaits<0> { static constexpr int W[3][4] = {{24, 25, 26, 7
 template <> struct K64RWaits<1> { static constexpr int W[3][4] = {{25, 25, 26, 7}, {8, 9, 10, 7}, {9, 14, 19, 20}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 24; };
 template <> struct K64RWaits<2> { static constexpr int W[3][4] = {{40, 41, 42, 11}, {8, 9, 10, 7}, {8, 17, 26, 31}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 0; };
 template <> struct K64RWaits<21> { static constexpr int W[3][4] = {{49, 49, 50, 7}, {8, 9, 10, 7}, {9, 20, 31, 38}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 48; };   // 8 stores + 2 row-sum stores per quarter
+template <> struct K64RWaits<37> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };   // = EPI 5
+template <> struct K64RWaits<69> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };   // = EPI 5
 template <> struct K64RWaits<5> { static constexpr int W[3][4] = {{41, 41, 42, 7}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {0, 0, 0, 0}; static constexpr int BIASW = 40; };
 template <> struct K64RWaits<3> { static constexpr int W[3][4] = {{41, 41, 42, 11}, {8, 9, 10, 7}, {9, 18, 27, 32}}; static constexpr int INIT[4] = {30, 22, 14, 6}; static constexpr int BIASW = 40; };
 // EPI 8 (out = acc * gate, round 5): INIT[q] = the wait in front of the multiplication of row quarter q by its gate vectors, requested one phase earlier (only the two DMA
@@ -1618,7 +1620,9 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
     // EPI 10 (round 6): EPI 8 plus the column sums of the stored tile rows -- the bias gradient of the Linear in FRONT of the activation (fc1 of the CLIP / BERT feed-forwards: db1 = column
     // sums of du = (dy W2) * act'), which was a column-sum pass over the 4d-wide du per layer.  Per row quarter: the two fragments of a column are added, closed over the 16 row lanes by
     // DPP, and added into a per-workgroup strip of J floats in LDS (return-less ds_add_f32; the 30 KB behind the bias strips); the strip leaves as row blockIdx.x of g.part at the end.
-    constexpr bool CSUM = EPI == 10, GATE = EPI == 8 || CSUM, BIAS = !GATE && (EPI & 1), RES = !GATE && (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || FFN1;
+    constexpr bool CSUM = EPI == 10, GATE = EPI == 8 || CSUM, BIAS = !GATE && (EPI & 1), RES = !GATE && (EPI & 2) != 0, FFN1 = EPI == 21, ACT2 = EPI == 5 || EPI == 37 || EPI == 69 || FFN1;
+    // EPI 37 / 69: EPI 5 with the activation (erf-GELU / QuickGELU) and the stored-derivative policy fixed at compile time (no wave-uniform branches inside the conversion)
+    constexpr int ACTC = EPI == 37 ? ANTMMF_ACT_GELU_ERF : -1;
     constexpr int CSOFF = 2 * 65536 + 2048;   // float strip [J <= 4096]
     using WT = K64RWaits<EPI>;
     const bf16_t* const rsrc = GATE ? g.gate : g.residual;   // what the "residual" vector loads fetch: the residual tile, or the gate tile
@@ -1782,11 +1786,11 @@ __global__ __launch_bounds__(512) void gemm_nt_k64r_kernel(const GemmArgs g, int
                     if (ACT2) {   /* two column pairs: activation and derivative out of one evaluation each (packed fp32 math) */           \
                         const f2_t u0 = (f2_t){__uint_as_float(s0[0]), __uint_as_float(s1[0])}, u1 = (f2_t){__uint_as_float(s0[1]), __uint_as_float(s1[1])}; \
                         f2_t z0, d0, z1, d1;                                                                                        \
-                        act_fwd_grad2<-1>(u0, g.act, z0, d0);                                                                       \
-                        act_fwd_grad2<-1>(u1, g.act, z1, d1);                                                                       \
+                        act_fwd_grad2<ACTC>(u0, EPI == 69 ? ANTMMF_ACT_QUICK_GELU : g.act, z0, d0);                                 \
+                        act_fwd_grad2<ACTC>(u1, EPI == 69 ? ANTMMF_ACT_QUICK_GELU : g.act, z1, d1);                                 \
                         ov[rr >> 1] = pack_bf2(z0.x, z0.y); ov[2 + (rr >> 1)] = pack_bf2(z1.x, z1.y);                               \
-                        av[rr >> 1] = g.aux_grad ? pack_bf2(d0.x, d0.y) : pack_bf2(u0.x, u0.y);                                     \
-                        av[2 + (rr >> 1)] = g.aux_grad ? pack_bf2(d1.x, d1.y) : pack_bf2(u1.x, u1.y);                               \
+                        av[rr >> 1] = (EPI == 37 || EPI == 69 || g.aux_grad) ? pack_bf2(d0.x, d0.y) : pack_bf2(u0.x, u0.y);         \
+                        av[2 + (rr >> 1)] = (EPI == 37 || EPI == 69 || g.aux_grad) ? pack_bf2(d1.x, d1.y) : pack_bf2(u1.x, u1.y);   \
                     } else {                                                                                                        \
                         ov[rr >> 1] = pack_bf2(__uint_as_float(s0[0]), __uint_as_float(s1[0]));                                     \
                         ov[2 + (rr >> 1)] = pack_bf2(__uint_as_float(s0[1]), __uint_as_float(s1[1]));                               \
@@ -2666,6 +2670,15 @@ static int gemm_impl(const void* P, const void* Q, void* C, int I, int J, int R,
                        hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 1024>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); } else)
             LAB_ONLY(if (g_gemm_variant & (1 << 29)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<5, 2048>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
                        hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 2048>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256); } else)
+            if (g.aux_grad && act == ANTMMF_ACT_GELU_ERF LAB_ONLY(&& !(g_gemm_variant & (1 << 30)))) {   // (lab variant bit 30: the run-time-activation form, the A/B)
+                static bool once37 = false;
+                if (!once37) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<37, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once37 = true; }
+                hipLaunchKernelGGL((gemm_nt_k64r_kernel<37, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+            } else if (g.aux_grad && act == ANTMMF_ACT_QUICK_GELU LAB_ONLY(&& !(g_gemm_variant & (1 << 30)))) {
+                static bool once69 = false;
+                if (!once69) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_k64r_kernel<69, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840); once69 = true; }
+                hipLaunchKernelGGL((gemm_nt_k64r_kernel<69, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
+            } else
             hipLaunchKernelGGL((gemm_nt_k64r_kernel<5, 0>), dim3(gridp), dim3(512), 163840, stream, g, (int)tiles256);
         } else
         if (k64p && gate && !g.gate_grad && act != ANTMMF_ACT_NONE && !aux && !bias && !residual && alpha == 1.0f && !(ldgate & 7)) {

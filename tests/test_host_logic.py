@@ -121,10 +121,10 @@ def test_product_kernel_resources():
     ks = inv.kernels(lib_path)
     dm = inv.demangle(list(ks))
     by = {re.sub(r"^void ", "", dm[n]).split("(")[0]: v for n, v in ks.items()}
-    assert 150 <= len(by) <= 270, len(by)    # 234 in round 5 (292 before the lab split); round 6: + 14 forms of the attention backward with token sums
+    assert 150 <= len(by) <= 275, len(by)    # 234 in round 5 (292 before the lab split); round 6: + 14 forms of the attention backward with token sums
     # (name, max VGPRs): 512-thread GEMM workgroups run 2 waves per SIMD -> <= 256; the 8-wave attention workgroups 2 per CU -> <= 128 (the one-kernel backward: 1 per CU -> <= 256)
     must = [("gemm_nt_k64r_kernel<0, 0>", 240), ("gemm_nt_k64r_kernel<1, 0>", 240), ("gemm_nt_k64r_kernel<2, 0>", 240), ("gemm_nt_k64r_kernel<3, 0>", 240),
-            ("gemm_nt_k64r_kernel<5, 0>", 256), ("gemm_nt_k64r_kernel<8, 0>", 248), ("gemm_nt_k64r_kernel<10, 0>", 256), ("gemm_tn_k64_kernel<1>", 256), ("gemm_nt_k64p_kernel<8, 37>", 256), ("gemm_nt_k64p_kernel<9, 37>", 256),
+            ("gemm_nt_k64r_kernel<5, 0>", 256), ("gemm_nt_k64r_kernel<37, 0>", 240), ("gemm_nt_k64r_kernel<69, 0>", 240), ("gemm_nt_k64r_kernel<8, 0>", 248), ("gemm_nt_k64r_kernel<10, 0>", 256), ("gemm_tn_k64_kernel<1>", 256), ("gemm_nt_k64p_kernel<8, 37>", 256), ("gemm_nt_k64p_kernel<9, 37>", 256),
             ("attn_fwd_kernel<9, false, 64, 0>", 128), ("attn_fwd_kernel<3, false, 64, 0>", 128), ("attn_bwd_dq64_kernel<9, false>", 128), ("attn_bwd_dq64_kernel<3, false>", 128),
             ("attn_bwd_dkv_kernel<false, 64>", 128),
             ("attn_bwd_fused64_kernel<8, true, true, 9, true, 0, false, 0>", 256), ("attn_bwd_fused64_kernel<7, false, false, 0, true, 0, false, 0>", 256),

@@ -42,7 +42,8 @@ def main():
         for rep in (1, 2):
             for name, variant, fn in (
                 ("bias only (one output)", 4, lambda: ops.gemm(X, W, bias=b)),
-                ("bias + act, two outputs (product)", 4, lambda: ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)),
+                ("bias + act, two outputs (product: activation fixed at compile time)", 4, lambda: ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)),
+                ("bias + act, two outputs, run-time activation id (the form before)", 4 | (1 << 30), lambda: ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)),
                 ("... second output 1 B / element (timing only)", 4 | (1 << 28), lambda: ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)),
                 ("... second output not stored (timing only)", 4 | (1 << 29), lambda: ops.gemm(X, W, bias=b, act=act, aux=aux, aux_grad=True)),
             ):
